@@ -1,0 +1,259 @@
+"""Golden-vector case definitions shared by the generator (real reference), the oracle tests
+(CPU restatement) and the GPU parity tests (HIP path).
+
+Every case is a pure function of seeds: inputs and weights come from `valle2_amd.synth`, so the
+.npz fixtures hold only the reference's OUTPUTS.  `REFERENCE_RUNNERS[name](ref)` runs the real
+reference modules (only in the build container); `ORACLE_RUNNERS[name]()` runs oracle/ on the
+same inputs and must reproduce the fixture.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from valle2_amd import synth
+from valle2_amd.config import ConfigValle
+
+# ---------------------------------------------------------------------------------------------
+# configs
+# ---------------------------------------------------------------------------------------------
+TINY = dict(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, dropout=0.0)
+MID = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0)
+
+
+def cfg_of(kw, cls=ConfigValle):
+    return cls(**kw)
+
+
+AR_TINY = dict(TINY, norm='LayerNorm', num_beams=4, top_k=1, max_audio_len=64)
+AR_MID = dict(MID, norm='LayerNorm', num_beams=2, top_k=1, max_audio_len=48)
+NAR_TINY = dict(TINY, norm='AdaptiveLayerNorm')
+MHA_SHAPES = [(512, 8, 4, 5), (256, 4, 8, 10), (128, 2, 16, 20)]  # reference tests/test_modules.py:9-13
+
+
+def _randn(shape, seed):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+def mha_inputs(d, h, b, t):
+    g = torch.Generator().manual_seed(100 + d + t)
+    sd = {'qkv.weight': 0.05 * torch.randn(3 * d, d, generator=g),
+          'out.weight': 0.05 * torch.randn(d, d, generator=g),
+          'out.bias': 0.05 * torch.randn(d, generator=g)}
+    x = torch.randn(b, t, d, generator=g)
+    causal = torch.triu(torch.ones(t, t), diagonal=1)          # float mask, as the reference test
+    lens = torch.tensor([max(1, t - (i % t)) for i in range(b)])
+    pad = (torch.arange(t)[None, :] >= lens[:, None]).to(torch.int64)
+    return sd, x, causal, pad
+
+
+def transformer_inputs(norm):
+    kw = dict(TINY, norm=norm)
+    cfg = cfg_of(kw)
+    sd = synth.make_state_dict(cfg, 'Transformer', seed=7, rich=True, std=0.05)
+    b, xl, yl = 3, 8, 16
+    x = _randn((b, xl + yl, cfg.d_model), 11)
+    lens = torch.tensor([16, 11, 5])
+    pad = F.pad(torch.arange(yl)[None, :] >= lens[:, None], (xl, 0), value=False)
+    emb = _randn((1, cfg.d_model), 12)
+    return kw, sd, x, xl, yl, pad, emb
+
+
+def ar_train_inputs():
+    cfg = cfg_of(AR_TINY)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True)
+    batch = synth.synth_ar_batch(cfg, 3, tok_range=(5, 12), code_range=(13, 30), seed=21)
+    return AR_TINY, sd, batch
+
+
+def ar_generate_inputs(which):
+    kw = AR_TINY if which == 'tiny' else AR_MID
+    cfg = cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=5, rich=True), cfg)
+    if which == 'tiny':   # BASELINE.json configs[0]: 128 text + 256 EnCodec tokens (255 + BOS)
+        utt = synth.synth_utterance(cfg, 64, 64, 255, seed=1234)
+    else:                 # reduced configs[1]: 12L/512d, short prompt so the fixture stays small
+        utt = synth.synth_utterance(cfg, 24, 24, 47, seed=1234)
+    return kw, sd, utt
+
+
+def ar_eos_inputs(eos_row=None):
+    """A run that really reaches EOS.  `eos_row` (stored in the fixture by the generator, which
+    derives it from a free run of the reference: 1.05 x the head row of the token emitted at
+    step 5) is planted as the EOS row of the head, so EOS overtakes that token no later than
+    step 5 and every beam stops (valle/models/valle_ar.py:167-170)."""
+    kw = dict(AR_TINY, max_audio_len=40)
+    cfg = cfg_of(kw)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=9, rich=True)
+    if eos_row is not None:
+        sd['proj.weight'][cfg.num_audio_tokens] = torch.as_tensor(eos_row)
+    else:
+        synth.silence_eos(sd, cfg)
+    utt = synth.synth_utterance(cfg, 6, 7, 9, seed=77)
+    return kw, sd, utt
+
+
+def nar_inputs():
+    cfg = cfg_of(NAR_TINY)
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=13, rich=True)
+    batch = synth.synth_nar_batch(cfg, 2, n_tokens=10, n_frames=36, seed=31)
+    return NAR_TINY, sd, batch
+
+
+def nar_generate_inputs():
+    cfg = cfg_of(NAR_TINY)
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=13, rich=True)
+    g = torch.Generator().manual_seed(55)
+    pt = torch.randint(0, cfg.vocab_size, (6,), generator=g)
+    tt = torch.randint(0, cfg.vocab_size, (9,), generator=g)
+    pc = torch.randint(0, cfg.num_audio_tokens, (12, cfg.num_quantizers), generator=g)
+    first = torch.randint(0, cfg.num_audio_tokens, (20,), generator=g)
+    return NAR_TINY, sd, (pt, pc, tt, first)
+
+
+def sampling_inputs():
+    logits = 3.0 * _randn((6, 1025), 41)
+    x = torch.tensor([[5, 9, 1024, 1024, 1024], [5, 7, 3, 2, 1024], [1, 2, 3, 4, 5]])
+    lp = torch.tensor([-1.0, -3.5, -3.0])
+    return logits, x, lp
+
+
+# ---------------------------------------------------------------------------------------------
+# reference runners (real reference modules)
+# ---------------------------------------------------------------------------------------------
+def _ref_masks(ref):
+    u = ref['utils']
+    out = {'attn_5_5': u.build_attn_mask(5, 5, device='cpu'),
+           'attn_3_7': u.build_attn_mask(3, 7, device='cpu'),
+           'pad_a': u.build_pad_mask(torch.tensor([5, 5, 5, 5]), device='cpu'),
+           'pad_b': u.build_pad_mask(torch.tensor([5, 4, 3, 2]), device='cpu')}
+    for d, h, b, t in MHA_SHAPES[:2]:
+        _, _, causal, pad = mha_inputs(d, h, b, t)
+        m = ref['modules'].MultiHeadAttention(d, h)
+        out[f'merge_{d}'] = m.merge_masks(b, causal, pad)
+    return out
+
+
+def _ref_mha(ref):
+    out = {}
+    for d, h, b, t in MHA_SHAPES:
+        sd, x, causal, pad = mha_inputs(d, h, b, t)
+        m = ref['modules'].MultiHeadAttention(d, h).eval()
+        m.load_state_dict(sd)
+        o, (k, v) = m(x, attn_mask=causal, use_cache=True)
+        o2, _ = m(x, attn_mask=causal, padding_mask=pad)
+        o3, _ = m(x)                                     # no mask at all
+        # one cached decode step: append one new row to the cache just returned
+        xn = _randn((b, 1, d), 300 + d)
+        o4, (k4, v4) = m(xn, kv_cache=(k, v), use_cache=True)
+        out.update({f'out_{d}': o, f'k_{d}': k, f'v_{d}': v, f'out_pad_{d}': o2,
+                    f'out_nomask_{d}': o3, f'out_step_{d}': o4, f'k_step_{d}': k4})
+    return out
+
+
+def _ref_transformer(ref):
+    out = {}
+    for norm in ('LayerNorm', 'AdaptiveLayerNorm'):
+        kw, sd, x, xl, yl, pad, emb = transformer_inputs(norm)
+        cfg = cfg_of(kw, ref['config'].ConfigValle)
+        m = ref['modules'].Transformer(cfg).eval()
+        m.load_state_dict(sd)
+        mask = ref['utils'].build_attn_mask(xl, yl, device='cpu')
+        e = emb if norm != 'LayerNorm' else None
+        y, kv = m(x, padding_mask=pad, attn_mask=mask, embedding=e, use_cache=True)
+        yfull, _ = m(x, embedding=e)                      # full attention (NAR shape)
+        xn = torch.cat([x, _randn((x.shape[0], 1, x.shape[2]), 19)], dim=1)
+        ystep, kv2 = m(xn, attn_mask=mask, embedding=e, kv_cache=kv, use_cache=True)
+        out.update({f'{norm}_y': y, f'{norm}_yfull': yfull, f'{norm}_ystep': ystep,
+                    f'{norm}_k0': kv[0][0], f'{norm}_vlast': kv2[-1][1]})
+    return out
+
+
+def _ref_ar_train(ref):
+    kw, sd, batch = ar_train_inputs()
+    with torch.enable_grad():
+        cfg = cfg_of(kw, ref['config'].ConfigValle)
+        m = ref['ar'].ValleAR(cfg).eval()
+        m.load_state_dict(sd)
+        loss = m.training_step({k: v.clone() for k, v in batch.items()})
+        loss.backward()
+        grads = {n: p.grad.norm() for n, p in m.named_parameters()}
+    names = sorted(grads)
+    return {'loss': loss.detach(), 'grad_norms': torch.stack([grads[n] for n in names]).detach()}
+
+
+def _ref_generate(ref, which):
+    kw, sd, utt = ar_generate_inputs(which)
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['ar'].ValleAR(cfg).eval()
+    m.load_state_dict(sd)
+    # record per-step logits of the real loop through a hook on the head
+    rows = []
+    hook = m.proj.register_forward_hook(lambda mod, i, o: rows.append(o[:, -1].clone()))
+    torch.manual_seed(0)
+    tokens = m.generate(*utt)
+    hook.remove()
+    logits = torch.stack(rows)                            # (steps, beams, V)
+    top2 = torch.topk(logits[:, 0], 2, dim=-1)[0]
+    return {'tokens': tokens, 'margin': top2[:, 0] - top2[:, 1],
+            'logits_row0': logits[:, 0][:: max(1, len(rows) // 8)], 'steps': torch.tensor(len(rows))}
+
+
+def _ref_generate_eos(ref):
+    kw, sd, utt = ar_eos_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['ar'].ValleAR(cfg).eval()
+    m.load_state_dict(sd)
+    torch.manual_seed(0)
+    free = m.generate(*utt)                               # EOS silenced: runs all 40 steps
+    eos_row = 1.05 * sd['proj.weight'][int(free[5])].clone()
+    kw, sd, utt = ar_eos_inputs(eos_row)
+    m.load_state_dict(sd)
+    rows = []
+    hook = m.proj.register_forward_hook(lambda mod, i, o: rows.append(o[:, -1].clone()))
+    torch.manual_seed(0)
+    stopped = m.generate(*utt)
+    hook.remove()
+    return {'eos_row': eos_row, 'free_tokens': free, 'tokens': stopped,
+            'steps': torch.tensor(len(rows))}
+
+
+def _ref_nar(ref):
+    kw, sd, batch = nar_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['nar'].ValleNAR(cfg).eval()
+    m.load_state_dict(sd)
+    out = {}
+    for stage in (1, 4, 7):
+        y, p = m._prepare_audio_codes(batch['codes'], stage)   # works in the reference
+        out[f'prep_{stage}'] = y
+        out[f'prefix_{stage}'] = torch.tensor(p)
+        # sub-expression chain of the intended forward, each piece computed by reference modules
+        tx = int(batch['tokens_lens'].max())
+        tok = m.tokens_position_emb(m.tokens_emb(batch['tokens']))
+        yy = m.audio_position_emb(y)
+        z, _ = m.transformer(torch.cat([tok, yy], dim=1), embedding=m.stage_embs[stage - 1].weight)
+        out[f'logits_{stage}'] = m.proj_layers[stage - 1](z[:, tx + p:])
+    return out
+
+
+def _ref_sampling(ref):
+    logits, x, lp = sampling_inputs()
+    torch.manual_seed(0)
+    tok, cur = ref['utils'].topk_sampling(logits, top_k=1, tok_p=1.0, temperature=1.0)
+    return {'greedy_tok': tok, 'greedy_lp': cur,
+            'best_beam_1': ref['utils'].get_best_beam(x, lp, 1024, 1.0),
+            'best_beam_2': ref['utils'].get_best_beam(x, lp, 1024, 0.0)}
+
+
+REFERENCE_RUNNERS = {
+    'masks': _ref_masks,
+    'mha': _ref_mha,
+    'transformer': _ref_transformer,
+    'ar_train': _ref_ar_train,
+    'ar_generate_tiny': lambda ref: _ref_generate(ref, 'tiny'),
+    'ar_generate_mid': lambda ref: _ref_generate(ref, 'mid'),
+    'ar_generate_eos': _ref_generate_eos,
+    'nar': _ref_nar,
+    'sampling': _ref_sampling,
+}

@@ -1,0 +1,127 @@
+"""Run oracle/ on the golden cases' inputs (same keys as tests/golden/cases.REFERENCE_RUNNERS)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import valle_oracle as O
+from tests.golden import cases as C
+
+GOLDEN_DIR = C.__file__.rsplit('/', 1)[0]
+
+
+def load_golden(name):
+    with np.load(f'{GOLDEN_DIR}/{name}.npz') as z:
+        return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+def masks():
+    out = {'attn_5_5': O.build_attn_mask(5, 5), 'attn_3_7': O.build_attn_mask(3, 7),
+           'pad_a': O.build_pad_mask(torch.tensor([5, 5, 5, 5])),
+           'pad_b': O.build_pad_mask(torch.tensor([5, 4, 3, 2]))}
+    for d, h, b, t in C.MHA_SHAPES[:2]:
+        _, _, causal, pad = C.mha_inputs(d, h, b, t)
+        out[f'merge_{d}'] = O.merge_masks(b, h, causal, pad)
+    return out
+
+
+def mha():
+    out = {}
+    for d, h, b, t in C.MHA_SHAPES:
+        sd, x, causal, pad = C.mha_inputs(d, h, b, t)
+        o, (k, v) = O.multi_head_attention(sd, '', x, h, attn_mask=causal, use_cache=True)
+        o2, _ = O.multi_head_attention(sd, '', x, h, attn_mask=causal, padding_mask=pad)
+        o3, _ = O.multi_head_attention(sd, '', x, h)
+        xn = C._randn((b, 1, d), 300 + d)
+        o4, (k4, _) = O.multi_head_attention(sd, '', xn, h, kv_cache=(k, v), use_cache=True)
+        out.update({f'out_{d}': o, f'k_{d}': k, f'v_{d}': v, f'out_pad_{d}': o2,
+                    f'out_nomask_{d}': o3, f'out_step_{d}': o4, f'k_step_{d}': k4})
+    return out
+
+
+def transformer():
+    out = {}
+    for norm in ('LayerNorm', 'AdaptiveLayerNorm'):
+        kw, sd, x, xl, yl, pad, emb = C.transformer_inputs(norm)
+        cfg = C.cfg_of(kw)
+        mask = O.build_attn_mask(xl, yl)
+        e = emb if norm != 'LayerNorm' else None
+        y, kv = O.transformer(sd, '', x, cfg, padding_mask=pad, attn_mask=mask, embedding=e,
+                              use_cache=True)
+        yfull, _ = O.transformer(sd, '', x, cfg, embedding=e)
+        xn = torch.cat([x, C._randn((x.shape[0], 1, x.shape[2]), 19)], dim=1)
+        ystep, kv2 = O.transformer(sd, '', xn, cfg, attn_mask=mask, embedding=e, kv_cache=kv,
+                                   use_cache=True)
+        out.update({f'{norm}_y': y, f'{norm}_yfull': yfull, f'{norm}_ystep': ystep,
+                    f'{norm}_k0': kv[0][0], f'{norm}_vlast': kv2[-1][1]})
+    return out
+
+
+def ar_train():
+    kw, sd, batch = C.ar_train_inputs()
+    cfg = C.cfg_of(kw)
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    with torch.enable_grad():
+        loss = O.ar_training_loss(params, cfg, batch)
+        loss.backward()
+    names = sorted(k for k in params if not k.endswith('.pe'))
+    return {'loss': loss.detach(),
+            'grad_norms': torch.stack([params[n].grad.norm() for n in names])}
+
+
+def _generate(kw, sd, utt):
+    cfg = C.cfg_of(kw)
+    trace = {}
+    torch.manual_seed(0)
+    tokens = O.ar_generate(sd, cfg, *utt, trace=trace)
+    logits = torch.stack(trace['logits'])
+    n = logits.shape[0]
+    return {'tokens': tokens, 'margin': torch.tensor(trace['margin']),
+            'logits_row0': logits[:, 0][:: max(1, n // 8)], 'steps': torch.tensor(n)}
+
+
+def ar_generate_tiny():
+    return _generate(*C.ar_generate_inputs('tiny'))
+
+
+def ar_generate_mid():
+    return _generate(*C.ar_generate_inputs('mid'))
+
+
+def ar_generate_eos():
+    gold = load_golden('ar_generate_eos')
+    kw, sd, utt = C.ar_eos_inputs()
+    torch.manual_seed(0)
+    free = O.ar_generate(sd, C.cfg_of(kw), *utt)
+    kw, sd, utt = C.ar_eos_inputs(gold['eos_row'])
+    res = _generate(kw, sd, utt)
+    return {'eos_row': gold['eos_row'], 'free_tokens': free, 'tokens': res['tokens'],
+            'steps': res['steps']}
+
+
+def nar():
+    kw, sd, batch = C.nar_inputs()
+    cfg = C.cfg_of(kw)
+    out = {}
+    for stage in (1, 4, 7):
+        y, p = O.nar_prepare_audio_codes(sd, cfg, batch['codes'], stage)
+        out[f'prep_{stage}'] = y
+        out[f'prefix_{stage}'] = torch.tensor(p)
+        out[f'logits_{stage}'] = O.nar_stage_logits(sd, cfg, batch, stage)[0]
+    return out
+
+
+def sampling():
+    logits, x, lp = C.sampling_inputs()
+    torch.manual_seed(0)
+    tok, cur = O.topk_sampling(logits, top_k=1, tok_p=1.0, temperature=1.0)
+    return {'greedy_tok': tok, 'greedy_lp': cur,
+            'best_beam_1': O.get_best_beam(x, lp, 1024, 1.0),
+            'best_beam_2': O.get_best_beam(x, lp, 1024, 0.0)}
+
+
+ORACLE_RUNNERS = {
+    'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
+    'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,
+    'ar_generate_eos': ar_generate_eos, 'nar': nar, 'sampling': sampling,
+}
