@@ -1,0 +1,193 @@
+/*
+ * valle_hip.h — C ABI of libvalle_hip.so: the MI355X (gfx950) kernels behind the AR + NAR
+ * codec-token transformer path of KubiakJakub01/Valle2.
+ *
+ * The reference has no native layer and no FFI: its hot path is PyTorch ops
+ * issued from valle/models/ (*.py).  Each entry point below therefore cites the reference
+ * *call site* whose arithmetic it replaces (paths relative to the reference root).
+ *
+ * Conventions (every entry point):
+ *   - returns 0 when the work was enqueued, a negative VH_E* code when an argument is rejected
+ *     (nothing is launched then); vh_last_error() gives the thread-local reason string;
+ *   - no allocation, no synchronisation, no host read of device memory: every call may be
+ *     captured in a hipGraph; the caller owns all buffers including workspaces;
+ *   - all tensors fp32, contiguous in the stated layout, base pointers 16-byte aligned,
+ *     leading dimensions multiples of 4 elements; token ids int64; lengths int32;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - one device per process; calls are thread-safe for distinct streams.
+ *
+ * Arithmetic is fp32 end to end (fp32 MFMA v_mfma_f32_32x32x2_f32 / 16x16x4_f32, exact f32
+ * FMA chains) because greedy-token parity with the reference needs it.
+ */
+#ifndef VALLE_HIP_H
+#define VALLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_VERSION 100            /* 0.1.0 */
+#define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
+#define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
+
+enum { VH_OK = 0, VH_EINVAL = -1, VH_EALIGN = -2, VH_EUNSUPPORTED = -3, VH_ELAUNCH = -4,
+       VH_ESTATE = -5 };
+
+/* activation fused in a GEMM epilogue */
+enum { VH_ACT_NONE = 0, VH_ACT_GELU_ERF = 1 };
+
+/* attention mask modes (analytic; no (B,h,T,T) tensor is ever materialised) */
+enum {
+    VH_MASK_FULL = 0,    /* every key < kv_len visible                (NAR, valle_nar.py:94-96) */
+    VH_MASK_PREFIX = 1,  /* prefix-LM of build_attn_mask(x_len, y_len) (valle/models/utils.py:17-43):
+                            keys < x_len visible to all rows; rows >= x_len also see keys <= row */
+    VH_MASK_EXPLICIT = 2 /* caller-supplied u8 (Tq,Tk) mask + optional u8 (B,Tk) key padding,
+                            nonzero = masked (API mask convention, valle/models/modules.py:160-164) */
+};
+
+int vh_version(void);
+const char* vh_last_error(void);
+
+/* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------
+ * replaces TokenEmbedding.forward + PositionalEncoding.forward (valle/models/modules.py:33-37,
+ * 78-80) and the 8-codebook sum of ValleNAR._prepare_audio_codes (valle/models/valle_nar.py:
+ * 179-185).  For b<B, t<T (t < lens[b] when lens != NULL):
+ *   out[b*out_bstride + (out_t0 + t)*d + :] =
+ *       sum_{j<n_tables} tables[j][ ids[b*ids_bstride + t*ids_tstride + j*ids_jstride] ][:]
+ *       + pe[(pos0 + t)*d + :]                      (pe == NULL: no position term)
+ * `tables` is a HOST array of n_tables device pointers, each (vocab, d). */
+int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
+                    int64_t ids_jstride, const float* const* tables, int n_tables,
+                    const float* pe, int pos0, const int32_t* lens, float* out,
+                    int64_t out_bstride, int out_t0, int B, int T, int d, void* stream);
+
+/* ---- K3/K4: LayerNorm (eps) with optional adaptive scale/shift ------------------------------
+ * replaces nn.LayerNorm (valle/models/modules.py:284) and AdaptiveLayerNorm.forward (:93-99):
+ *   out[r,:] = ada_scale[:] * (gamma * (x[r,:]-mean)/sqrt(var+eps) + beta) + ada_shift[:]
+ * ada_scale/ada_shift (d) may both be NULL (plain LayerNorm). */
+int vh_layernorm(const float* x, const float* gamma, const float* beta, const float* ada_scale,
+                 const float* ada_shift, float* out, int rows, int d, float eps, void* stream);
+
+/* ---- K5/K9/K10/K11: out = act(LN?(A) W^T + bias) + residual ---------------------------------
+ * replaces nn.Linear at valle/models/modules.py:146 (qkv), :171 (out), :221 (linear_1 +
+ * exact-erf GELU, linear_2) and the heads valle_ar.py:83,158 / valle_nar.py:100.
+ * A (M,K) lda; W (N,K) row-major (the nn.Linear weight as stored); bias (N)|NULL;
+ * residual (M,N) ldr |NULL (may alias out); out (M,N) ldo.
+ * ln_gamma/ln_beta (K)|NULL: when given (M <= 64 only) A's rows are LayerNorm-ed (eps ln_eps,
+ * then optional ada_scale/ada_shift (K)) on the fly in the operand load — the decode path. */
+int vh_linear(const float* A, int lda, const float* W, const float* bias, const float* residual,
+              int ldr, float* out, int ldo, int M, int N, int K, int act, const float* ln_gamma,
+              const float* ln_beta, const float* ada_scale, const float* ada_shift, float ln_eps,
+              void* stream);
+
+/* ---- K5+K6: QKV projection with the K/V rows appended in place to the cache -----------------
+ * replaces qkv Linear + chunk + rearrange + torch.cat cache growth (valle/models/modules.py:
+ * 146-157).  A (M=B*T, K=d) lda; Wqkv (3d, d) rows [Q | K | V], head j = rows j*64..j*64+63.
+ * q_out (M, d) ldq receives the Q columns; K and V columns of row (b,t) go to
+ * kcache/vcache[(b*h + head)*S_max + pos0(b) + t][0..63] with pos0(b) = cache_len ? cache_len[b] : 0.
+ * Optional fused LayerNorm on A's rows as in vh_linear (M <= 64 only). */
+int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int ldq, float* kcache,
+                  float* vcache, const int32_t* cache_len, int B, int T, int d_model, int n_heads,
+                  int S_max, const float* ln_gamma, const float* ln_beta, const float* ada_scale,
+                  const float* ada_shift, float ln_eps, void* stream);
+
+/* ---- K7+K8a: multi-row attention (prefill / NAR / training forward) -------------------------
+ * replaces merge_masks + F.scaled_dot_product_attention (valle/models/modules.py:160-167,
+ * 175-207).  q (B,Tq,ldq) heads at columns head*64; K/V from the cache layout (B,h,S_max,64);
+ * out (B,Tq,ldo).  Query row i sits at key position q_off + i (q_off = Tk - Tq).
+ *   VH_MASK_FULL   : key j visible iff j < kvl(b)
+ *   VH_MASK_PREFIX : key j visible iff j < kvl(b) && (j < xl(b) || (q_off+i >= xl(b) && j <= q_off+i))
+ *   VH_MASK_EXPLICIT: key j visible iff !mask[i*Tk+j] && !(pad && pad[b*Tk+j])
+ * kvl(b) = kv_len ? kv_len[b] : Tk ; xl(b) = x_len_dev ? x_len_dev[b] : x_len.
+ * softmax scale = 1/sqrt(64). */
+int vh_attn_rows(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
+                 int ldo, int B, int n_heads, int Tq, int Tk, int S_max, int mode, int x_len,
+                 const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+                 const uint8_t* pad, void* stream);
+
+/* ---- K8b: single-row decode attention over the KV cache (HBM-bound) -------------------------
+ * replaces SDPA with q-len 1 (valle/models/modules.py:167 reached via :336-338).
+ * q (B, ldq); keys 0 .. cache_len[b] + len_bias - 1 of row b are attended (len_bias = 1 when the
+ * new K/V row was just appended by vh_linear_qkv and cache_len is not yet incremented).
+ * n_split >= 1 splits the key range of one (b,head) over n_split workgroups; then `partial`
+ * must hold vh_attn_decode_ws_bytes(B, n_heads, n_split) bytes. out (B, ldo). */
+size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
+int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
+                   int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,
+                   int n_split, void* partial, void* stream);
+
+/* ---- K12/K13: greedy sampling + decode-state update + next-token embedding ------------------
+ * replaces topk_sampling(top_k=1) (valle/models/utils.py:46-68: argmax, lowest index on ties),
+ * the EOS bookkeeping valle/models/valle_ar.py:167-171 and the re-embedding :143-144 for the
+ * next step.  `codes` (B, codes_stride) int64 is the growing `prompt_codes` of the reference
+ * (BOS + prompt pre-filled); audio_pos[b] = index of the token produced now.  Per row b:
+ *   p = audio_pos[b]; tok = (codes[b][p-1]==eos) ? eos : argmax(logits[b,:V]); codes[b][p] = tok;
+ *   if (tok==eos) eos_count[p - (pos_base?pos_base[b]:0)] += 1;
+ *   x_next[b,:] = audio_emb[tok,:] + pe[p*d + :]; audio_pos[b] = p+1; cache_len[b] += 1.
+ * eos_count[s] == B means every row had finished at step s (the reference's break, :169-170);
+ * the host polls it every few steps instead of synchronising every step. */
+int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
+                   int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
+                   const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
+                   float* x_next, int B, int d, void* stream);
+
+/* ---- composite: one AR decode step / hipGraph replay ----------------------------------------
+ * The ~5 launches per layer of one decode step (LN1+QKV+append, decode attention, out-proj+
+ * residual, LN2+FFN1+GELU, FFN2+residual) plus head GEMM and vh_greedy_step, enqueued natively
+ * (valle/models/valle_ar.py:141-171 with modules.py:336-352).  */
+typedef struct {
+    const float *ln1_g, *ln1_b, *wqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
+    float *kcache, *vcache;           /* this layer's (B,h,S_max,64) caches */
+} vh_layer;
+
+typedef struct {
+    int B, d_model, n_heads, dff, n_layers, S_max, V, eos, n_split;
+    float ln_eps;
+    const vh_layer* layers;           /* host array of n_layers */
+    const float *proj_w;              /* (V, d) */
+    const float *audio_emb, *audio_pe;
+    float *x;                         /* (B,d) residual stream, holds the current token's embedding */
+    float *q, *attn, *hidden, *logits;/* (B,d) (B,d) (B,dff) (B,ldl) scratch; ldl = round_up(V,4) */
+    void *attn_partial;               /* vh_attn_decode_ws_bytes() or NULL when n_split == 1 */
+    int32_t *cache_len, *audio_pos, *eos_count;
+    const int32_t *pos_base;          /* (B) or NULL */
+    int64_t *codes;                   /* (B, codes_stride) growing code sequence */
+    int64_t codes_stride;
+} vh_ar_decoder_desc;
+
+typedef struct vh_ar_decoder vh_ar_decoder;
+vh_ar_decoder* vh_ar_decoder_create(const vh_ar_decoder_desc* desc);   /* NULL on bad desc */
+void vh_ar_decoder_destroy(vh_ar_decoder* dec);
+/* enqueue one step eagerly (no graph) */
+int vh_ar_decoder_step(vh_ar_decoder* dec, void* stream);
+/* capture one step into a hipGraph on `stream` (which must be a non-null, idle stream) */
+int vh_ar_decoder_capture(vh_ar_decoder* dec, void* stream);
+/* replay the captured step n_steps times on `stream` */
+int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream);
+/* eager steps with hipEvents around every decode-attention launch; returns the mean duration in
+ * milliseconds of those launches via *mean_ms (synchronises the stream; measurement only). */
+int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream, float* mean_ms);
+
+/* ---- composite: full-sequence transformer forward (prefill / NAR stage / training forward) --
+ * valle/models/modules.py:305-352 without cache input: x (B*T, d) in/out in place, every
+ * layer's K/V written to its cache at positions 0..T-1.  scratch: xn (B*T,d), q (B*T,d),
+ * attn (B*T,d), hidden (B*T,dff).  ada_* per layer (L,2,2,d) = [layer][norm1|norm2][scale|shift]
+ * or NULL for plain LayerNorm. */
+typedef struct {
+    int B, T, d_model, n_heads, dff, n_layers, S_max, mode, x_len;
+    float ln_eps;
+    const vh_layer* layers;
+    const float* ada;                 /* (L,2,2,d) or NULL */
+    const int32_t *x_len_dev, *kv_len;
+    const uint8_t *mask, *pad;
+    float *x, *xn, *q, *attn, *hidden;
+} vh_forward_desc;
+int vh_transformer_forward(const vh_forward_desc* desc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLE_HIP_H */

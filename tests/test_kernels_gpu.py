@@ -1,0 +1,266 @@
+"""GPU parity of each C-ABI primitive against plain torch fp32 on the CPU (same seeded inputs).
+
+Tolerances (fp32 everywhere; the only differences are summation order and exp/erf/rsqrt ulps):
+GEMM/attention outputs atol 2e-5 + rtol 2e-5 on O(1) values unless stated; integer-valued
+operands must come out exactly (that is the MFMA operand/accumulator layout check: asymmetric
+integer data, cdna_hip_programming.md §3)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.fixture(scope='module')
+def K():
+    from valle2_amd import kernels
+    return kernels
+
+
+def close(a, b, atol=2e-5, rtol=2e-5):
+    torch.testing.assert_close(a.cpu(), b, atol=atol, rtol=rtol)
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K_', [(5, 16, 16), (32, 1536, 512), (32, 512, 2048), (4, 1025, 128),
+                                    (64, 48, 64), (1, 256, 128), (17, 20, 1040)])
+def test_linear_skinny_integer_exact(K, M, N, K_):
+    a = torch.randint(-3, 4, (M, K_), generator=g(1)).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g(2)).float()
+    w[:, 0] += torch.arange(N).float() % 5          # asymmetric
+    out = K.linear(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), a @ w.T)
+
+
+@pytest.mark.parametrize('M,N,K_', [(65, 16, 16), (128, 128, 32), (300, 1025, 128), (257, 1536, 512),
+                                    (1000, 100, 2048)])
+def test_linear_tile_integer_exact(K, M, N, K_):
+    a = torch.randint(-3, 4, (M, K_), generator=g(3)).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g(4)).float()
+    w[:, 1] += torch.arange(N).float() % 7
+    out = K.linear(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), a @ w.T)
+
+
+@pytest.mark.parametrize('M', [7, 32, 200])
+@pytest.mark.parametrize('act', [0, 1])
+def test_linear_epilogues(K, M, act):
+    N, K_ = 520, 128
+    a = torch.randn(M, K_, generator=g(5))
+    w = 0.1 * torch.randn(N, K_, generator=g(6))
+    bias = torch.randn(N, generator=g(7))
+    res = torch.randn(M, N, generator=g(8))
+    ref = F.linear(a, w, bias)
+    if act:
+        ref = F.gelu(ref)
+    ref = ref + res
+    resd = res.to(DEV)
+    out = K.linear(a.to(DEV), w.to(DEV), bias.to(DEV), resd, out=resd, act=act)  # in place
+    close(out, ref)
+
+
+@pytest.mark.parametrize('M,ada', [(3, False), (32, False), (32, True), (64, True)])
+def test_linear_fused_layernorm(K, M, ada):
+    N, K_ = 96, 512
+    a = 2.0 * torch.randn(M, K_, generator=g(9)) + 0.5
+    w = 0.1 * torch.randn(N, K_, generator=g(10))
+    gm, bt = 1 + 0.1 * torch.randn(K_, generator=g(11)), 0.1 * torch.randn(K_, generator=g(12))
+    sc, sh = 1 + 0.1 * torch.randn(K_, generator=g(13)), 0.1 * torch.randn(K_, generator=g(14))
+    xn = F.layer_norm(a, (K_,), gm, bt, 1e-5)
+    if ada:
+        xn = sc * xn + sh
+    ref = F.linear(xn, w)
+    ln = (gm.to(DEV), bt.to(DEV), sc.to(DEV) if ada else None, sh.to(DEV) if ada else None, 1e-5)
+    close(K.linear(a.to(DEV), w.to(DEV), ln=ln), ref, atol=5e-5)
+
+
+@pytest.mark.parametrize('rows,d', [(1, 128), (37, 512), (5, 1024), (3, 2048), (9, 132)])
+def test_layernorm(K, rows, d):
+    x = 3 * torch.randn(rows, d, generator=g(15)) + 1
+    gm, bt = torch.randn(d, generator=g(16)), torch.randn(d, generator=g(17))
+    sc, sh = torch.randn(d, generator=g(18)), torch.randn(d, generator=g(19))
+    close(K.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV)), F.layer_norm(x, (d,), gm, bt, 1e-5))
+    close(K.layernorm(x.to(DEV), gm.to(DEV), bt.to(DEV), ada_scale=sc.to(DEV), ada_shift=sh.to(DEV)),
+          sc * F.layer_norm(x, (d,), gm, bt, 1e-5) + sh)
+
+
+def test_embed_sum_pe_bit_exact(K):
+    from valle2_amd.synth import sinusoid_table
+    d, B, T, Q = 128, 3, 11, 8
+    tabs = [torch.randn(50, d, generator=g(20 + j)) for j in range(Q)]
+    ids = torch.randint(0, 50, (B, T, Q), generator=g(30))
+    pe = sinusoid_table(d, 64)
+    out = torch.zeros(B, T + 4, d, device=DEV)
+    K.embed_sum_pe(ids.to(DEV), [t.to(DEV) for t in tabs], pe.to(DEV), 2, out, out_t0=4)
+    ref = F.embedding(ids[..., 0], tabs[0])
+    for j in range(1, Q):
+        ref = ref + F.embedding(ids[..., j], tabs[j])
+    ref = ref + pe[2:2 + T, 0]
+    assert torch.equal(out[:, 4:].cpu(), ref)          # pure adds in the same order: exact
+    assert out[:, :4].abs().sum().item() == 0
+    # single table, strided ids view (first codebook of a (T,Q) tensor), ragged lens
+    out2 = torch.zeros(B, T, d, device=DEV)
+    lens = torch.tensor([11, 4, 0], dtype=torch.int32)
+    K.embed_sum_pe(ids.to(DEV)[..., 0], [tabs[0].to(DEV)], pe.to(DEV), 0, out2, lens=lens.to(DEV))
+    ref2 = F.embedding(ids[..., 0], tabs[0]) + pe[:T, 0]
+    for b in range(B):
+        assert torch.equal(out2[b, :lens[b]].cpu(), ref2[b, :lens[b]])
+        assert out2[b, lens[b]:].abs().sum().item() == 0
+
+
+def _sdpa_ref(q, k, v, mask_bool_visible):
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=mask_bool_visible)
+
+
+def _to_cache(k, S_max):
+    B, h, S, hd = k.shape
+    c = torch.zeros(B, h, S_max, hd)
+    c[:, :, :S] = k
+    return c
+
+
+@pytest.mark.parametrize('B,h,T,mode', [(2, 2, 5, 'prefix'), (3, 2, 150, 'prefix'), (2, 8, 300, 'full'),
+                                        (2, 2, 129, 'full'), (1, 1, 32, 'prefix'), (2, 2, 77, 'explicit')])
+def test_attn_rows(K, B, h, T, mode):
+    d = 64 * h
+    q = torch.randn(B, T, d, generator=g(40))
+    k = torch.randn(B, h, T, 64, generator=g(41))
+    v = torch.randn(B, h, T, 64, generator=g(42))
+    xl = T // 3
+    kvl = torch.tensor([T - (5 * i) % (T // 2 + 1) for i in range(B)], dtype=torch.int32)
+    from oracle.valle_oracle import build_attn_mask
+    keypad = torch.arange(T)[None, :] >= kvl[:, None]                     # True = masked
+    if mode == 'prefix':
+        masked = build_attn_mask(xl, T - xl)[None] | keypad[:, None, :]
+    elif mode == 'full':
+        masked = keypad[:, None, :].expand(B, T, T)
+    else:
+        rnd = torch.rand(T, T, generator=g(43)) < 0.3
+        rnd[:, 0] = False                                                 # no fully-masked row
+        keypad[:, 0] = False
+        masked = rnd[None] | keypad[:, None, :]
+    qh = q.view(B, T, h, 64).permute(0, 2, 1, 3)
+    ref = _sdpa_ref(qh, k, v, ~masked[:, None]).permute(0, 2, 1, 3).reshape(B, T, d)
+    S_max = T + 9
+    out = torch.empty(B * T, d, device=DEV)
+    kw = {}
+    if mode == 'prefix':
+        kw = dict(mode=K.MASK_PREFIX, x_len=xl, kv_len=kvl.to(DEV))
+    elif mode == 'full':
+        kw = dict(mode=K.MASK_FULL, kv_len=kvl.to(DEV))
+    else:
+        kw = dict(mode=K.MASK_EXPLICIT, mask=rnd.to(torch.uint8).to(DEV),
+                  pad=keypad.to(torch.uint8).to(DEV))
+    K.attn_rows(q.view(B * T, d).to(DEV), _to_cache(k, S_max).to(DEV), _to_cache(v, S_max).to(DEV),
+                out, B, h, T, T, **kw)
+    close(out.view(B, T, d), ref, atol=3e-5)
+
+
+def test_attn_rows_peaked_softmax(K):
+    # sharply peaked scores (|q.k| up to 100s): exercises the online-softmax rescale branch where
+    # the running max jumps by a lot at a late tile (cdna_hip_programming.md rule 26)
+    B, h, T = 1, 2, 200
+    k = torch.randn(B, h, T, 64, generator=g(44))
+    v = torch.randn(B, h, T, 64, generator=g(45))
+    q = torch.randn(B, T, h, 64, generator=g(46))
+    k[:, :, 170] *= 40.0            # a spike key in the 6th tile
+    k[:, :, 3] *= 15.0              # and a smaller one in the first
+    out = torch.empty(B * T, 64 * h, device=DEV)
+    K.attn_rows(q.reshape(B * T, -1).to(DEV), k.to(DEV), v.to(DEV), out, B, h, T, T,
+                mode=K.MASK_FULL)
+    ref = _sdpa_ref(q.permute(0, 2, 1, 3), k, v, None).permute(0, 2, 1, 3).reshape(B * T, -1)
+    close(out, ref, atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize('B,h,S,n_split', [(4, 2, 37, 1), (32, 8, 300, 1), (2, 2, 1000, 4),
+                                           (3, 16, 65, 2), (1, 1, 1, 1), (2, 2, 31, 3)])
+def test_attn_decode(K, B, h, S, n_split):
+    d = 64 * h
+    S_max = S + 40
+    q = torch.randn(B, d, generator=g(50))
+    k = torch.randn(B, h, S_max, 64, generator=g(51))
+    v = torch.randn(B, h, S_max, 64, generator=g(52))
+    lens = torch.tensor([max(1, S - 3 * i) for i in range(B)], dtype=torch.int32)
+    ref = torch.empty(B, d)
+    for b in range(B):
+        L = int(lens[b])
+        r = _sdpa_ref(q[b].view(1, h, 1, 64), k[b:b + 1, :, :L], v[b:b + 1, :, :L], None)
+        ref[b] = r.reshape(d)
+    out = torch.empty(B, d, device=DEV)
+    ws = K.attn_decode_ws(B, h, n_split, DEV)
+    K.attn_decode(q.to(DEV), k.to(DEV), v.to(DEV), out, (lens - 1).to(DEV), 1, n_split, ws)
+    close(out, ref, atol=3e-5)
+
+
+def test_linear_qkv_scatter(K):
+    B, T, h = 3, 5, 2
+    d = 64 * h
+    S_max = 12
+    a = torch.randn(B * T, d, generator=g(60))
+    w = 0.1 * torch.randn(3 * d, d, generator=g(61))
+    ref = F.linear(a, w)
+    for cache_len in (None, torch.tensor([2, 0, 7], dtype=torch.int32)):
+        kc = torch.zeros(B, h, S_max, 64, device=DEV)
+        vc = torch.zeros_like(kc)
+        qo = torch.empty(B * T, d, device=DEV)
+        K.linear_qkv(a.to(DEV), w.to(DEV), qo, kc, vc, B, T, h,
+                     cache_len=None if cache_len is None else cache_len.to(DEV))
+        close(qo, ref[:, :d])
+        kref = ref[:, d:2 * d].view(B, T, h, 64).permute(0, 2, 1, 3)
+        vref = ref[:, 2 * d:].view(B, T, h, 64).permute(0, 2, 1, 3)
+        for b in range(B):
+            p0 = 0 if cache_len is None else int(cache_len[b])
+            close(kc[b, :, p0:p0 + T], kref[b])
+            close(vc[b, :, p0:p0 + T], vref[b])
+            assert kc[b, :, :p0].abs().sum().item() == 0 and kc[b, :, p0 + T:].abs().sum().item() == 0
+    # decode shape (T=1, fused LN) through the skinny kernel
+    x = torch.randn(B, d, generator=g(62))
+    gm, bt = torch.randn(d, generator=g(63)), torch.randn(d, generator=g(64))
+    ref1 = F.linear(F.layer_norm(x, (d,), gm, bt, 1e-5), w)
+    kc = torch.zeros(B, h, S_max, 64, device=DEV)
+    vc = torch.zeros_like(kc)
+    qo = torch.empty(B, d, device=DEV)
+    cl = torch.tensor([3, 11, 0], dtype=torch.int32)
+    K.linear_qkv(x.to(DEV), w.to(DEV), qo, kc, vc, B, 1, h, cache_len=cl.to(DEV),
+                 ln=(gm.to(DEV), bt.to(DEV), None, None, 1e-5))
+    close(qo, ref1[:, :d], atol=5e-5)
+    for b in range(B):
+        close(kc[b, :, int(cl[b])], ref1[b, d:2 * d].view(h, 64), atol=5e-5)
+        close(vc[b, :, int(cl[b])], ref1[b, 2 * d:].view(h, 64), atol=5e-5)
+
+
+def test_greedy_step(K):
+    B, V, d, eos = 5, 1025, 128, 1024
+    logits = torch.randn(B, 1028, generator=g(70))
+    logits[1, 7] = logits[1, 900] = 50.0          # tie → lowest index
+    logits[2, eos] = 60.0                          # emits EOS
+    logits[:, V:] = 1e9                            # padding columns must be ignored
+    emb = torch.randn(V + 1, d, generator=g(71))
+    from valle2_amd.synth import sinusoid_table
+    pe = sinusoid_table(d, 64)
+    codes = torch.zeros(B, 20, dtype=torch.int64)
+    codes[:, :4] = torch.randint(0, 1024, (B, 4), generator=g(72))
+    codes[3, 3] = eos                              # already finished row stays EOS
+    apos = torch.full((B,), 4, dtype=torch.int32)
+    clen = torch.tensor([10, 11, 12, 13, 14], dtype=torch.int32)
+    cnt = torch.zeros(20, dtype=torch.int32)
+    dv = {k: v.to(DEV) for k, v in dict(logits=logits, emb=emb, pe=pe, codes=codes, apos=apos,
+                                        clen=clen, cnt=cnt).items()}
+    x = torch.empty(B, d, device=DEV)
+    K.greedy_step(dv['logits'], V, eos, dv['codes'], dv['cnt'], dv['emb'], dv['pe'], dv['apos'],
+                  dv['clen'], x)
+    exp = torch.argmax(logits[:, :V], dim=-1)
+    exp[1] = 7
+    exp[3] = eos
+    assert dv['codes'][:, 4].cpu().tolist() == exp.tolist()
+    assert dv['apos'].cpu().tolist() == [5] * B and dv['clen'].cpu().tolist() == [11, 12, 13, 14, 15]
+    assert dv['cnt'].cpu()[4].item() == 2 and dv['cnt'].cpu().sum().item() == 2
+    assert torch.equal(x.cpu(), emb[exp] + pe[4, 0])

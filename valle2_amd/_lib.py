@@ -1,0 +1,146 @@
+"""ctypes binding of libvalle_hip.so (include/valle_hip.h).
+
+There is no CPU fallback anywhere in this package: `lib()` raises when the shared library is
+missing or a HIP device is not visible, and every wrapper raises `VhError` on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch  # imported first so the process-wide HIP runtime is the one torch already loaded
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / 'csrc' / 'libvalle_hip.so'
+
+c_f32p = C.c_void_p   # device pointers travel as integers
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+c_u8p = C.c_void_p
+
+
+class VhError(RuntimeError):
+    pass
+
+
+class VhLayer(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        'ln1_g', 'ln1_b', 'wqkv', 'wo', 'bo', 'ln2_g', 'ln2_b', 'w1', 'b1', 'w2', 'b2',
+        'kcache', 'vcache')]
+
+
+class VhArDecoderDesc(C.Structure):
+    _fields_ = [
+        ('B', C.c_int), ('d_model', C.c_int), ('n_heads', C.c_int), ('dff', C.c_int),
+        ('n_layers', C.c_int), ('S_max', C.c_int), ('V', C.c_int), ('eos', C.c_int),
+        ('n_split', C.c_int), ('ln_eps', C.c_float),
+        ('layers', C.POINTER(VhLayer)),
+        ('proj_w', C.c_void_p), ('audio_emb', C.c_void_p), ('audio_pe', C.c_void_p),
+        ('x', C.c_void_p), ('q', C.c_void_p), ('attn', C.c_void_p), ('hidden', C.c_void_p),
+        ('logits', C.c_void_p), ('attn_partial', C.c_void_p),
+        ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
+        ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
+    ]
+
+
+class VhForwardDesc(C.Structure):
+    _fields_ = [
+        ('B', C.c_int), ('T', C.c_int), ('d_model', C.c_int), ('n_heads', C.c_int),
+        ('dff', C.c_int), ('n_layers', C.c_int), ('S_max', C.c_int), ('mode', C.c_int),
+        ('x_len', C.c_int), ('ln_eps', C.c_float),
+        ('layers', C.POINTER(VhLayer)), ('ada', C.c_void_p),
+        ('x_len_dev', C.c_void_p), ('kv_len', C.c_void_p), ('mask', C.c_void_p), ('pad', C.c_void_p),
+        ('x', C.c_void_p), ('xn', C.c_void_p), ('q', C.c_void_p), ('attn', C.c_void_p),
+        ('hidden', C.c_void_p),
+    ]
+
+
+# name → (restype, argtypes); must list every symbol include/valle_hip.h declares
+SIGNATURES = {
+    'vh_version': (C.c_int, []),
+    'vh_last_error': (C.c_char_p, []),
+    'vh_embed_sum_pe': (C.c_int, [c_i64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
+                                  C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_layernorm': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                               C.c_float, C.c_void_p]),
+    'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                            C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
+                            C.c_float, C.c_void_p]),
+    'vh_linear_qkv': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_i32p,
+                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
+                                c_f32p, C.c_float, C.c_void_p]),
+    'vh_attn_rows': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
+                               c_u8p, C.c_void_p]),
+    'vh_attn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
+                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    'vh_ar_decoder_create': (C.c_void_p, [C.POINTER(VhArDecoderDesc)]),
+    'vh_ar_decoder_destroy': (None, [C.c_void_p]),
+    'vh_ar_decoder_step': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'vh_ar_decoder_capture': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'vh_ar_decoder_replay': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    'vh_ar_decoder_profile_attn': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
+                                             C.POINTER(C.c_float)]),
+    'vh_transformer_forward': (C.c_int, [C.POINTER(VhForwardDesc), C.c_void_p]),
+}
+
+_lib = None
+
+
+def load_library(path: os.PathLike | None = None) -> C.CDLL:
+    """dlopen the library and type every entry point.  Needs no GPU (the not-gpu tests use this to
+    check that the ABI exports what the header declares)."""
+    p = Path(path or LIB_PATH)
+    if not p.exists():
+        raise VhError(f'{p} not found: build it with `python __graft_entry__.py build` '
+                      f'(make -C valle2_amd/csrc). There is no CPU fallback.')
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library drift
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def lib() -> C.CDLL:
+    """The loaded library, for compute calls: requires a visible HIP device."""
+    global _lib
+    if _lib is None:
+        if not torch.cuda.is_available():
+            raise VhError('valle2_amd needs a HIP device (MI355X): torch.cuda.is_available() is '
+                          'False and there is no CPU fallback. The CPU oracle lives in oracle/ and '
+                          'is test infrastructure only.')
+        _lib = load_library()
+        # one HIP runtime per process: ours must be the copy torch loaded
+        n = sum(1 for line in open('/proc/self/maps') if 'libamdhip64' in line and ' r-xp ' in line)
+        if n > 1:
+            raise VhError('two HIP runtimes are mapped in this process; import torch before '
+                          'loading libvalle_hip.so')
+    return _lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = lib().vh_last_error()
+        raise VhError(f'{what} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def ptr(t: torch.Tensor | None) -> int | None:
+    """Device pointer of a contiguous CUDA/HIP tensor (None passes a NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise VhError('tensor is not on a HIP device')
+    if not t.is_contiguous():
+        raise VhError('tensor must be contiguous')
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,201 @@
+// Embedding-sum + position add, LayerNorm / adaptive LayerNorm, greedy step.
+// All HBM-bound row kernels: one wave64 per row, float4 per lane, wave-shuffle reductions.
+#include "vh_common.h"
+
+struct TablePtrs {
+    const float* t[VH_MAX_TABLES];
+};
+
+// ---------------------------------------------------------------------------------------------
+// K1/K2  out[b, out_t0+t, :] = sum_j tables[j][ids[b,t,j], :] + pe[pos0+t, :]
+// grid: (ceil(T/4), B), block 256 = 4 waves, one wave per (b,t) row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_sum_pe_kernel(
+    const int64_t* __restrict__ ids, int64_t ids_bs, int64_t ids_ts, int64_t ids_js, TablePtrs tabs,
+    int n_tables, const float* __restrict__ pe, int pos0, const int32_t* __restrict__ lens,
+    float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    if (lens && t >= lens[b]) return;
+    const int64_t* idp = ids + b * ids_bs + t * ids_ts;
+    float* orow = out + b * out_bs + (int64_t)(out_t0 + t) * d;
+    const float* prow = pe ? pe + (int64_t)(pos0 + t) * d : nullptr;
+    for (int c = lane * 4; c < d; c += 256) {
+        f32x4 acc = prow ? ld4(prow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 e = ld4(tabs.t[0] + idp[0] * d + c);
+        // sum the codebooks first, then add the position row: same order as the reference
+        // (emb0 + emb1 + ... then + pe), so fp32 rounding matches op for op.
+        for (int j = 1; j < n_tables; ++j) e += ld4(tabs.t[j] + idp[j * ids_js] * d + c);
+        st4(orow + c, e + acc);
+    }
+}
+
+extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
+                               int64_t ids_jstride, const float* const* tables, int n_tables,
+                               const float* pe, int pos0, const int32_t* lens, float* out,
+                               int64_t out_bstride, int out_t0, int B, int T, int d, void* stream) {
+    VH_REQUIRE(ids && tables && out, VH_EINVAL, "vh_embed_sum_pe: null pointer");
+    VH_REQUIRE(n_tables >= 1 && n_tables <= VH_MAX_TABLES, VH_EINVAL,
+               "vh_embed_sum_pe: n_tables=%d not in 1..%d", n_tables, VH_MAX_TABLES);
+    VH_REQUIRE(B >= 0 && T >= 0 && d > 0 && d % 4 == 0, VH_EINVAL,
+               "vh_embed_sum_pe: bad dims B=%d T=%d d=%d (d must be a multiple of 4)", B, T, d);
+    VH_REQUIRE(vh_aligned16(out) && (!pe || vh_aligned16(pe)) && out_bstride % 4 == 0, VH_EALIGN,
+               "vh_embed_sum_pe: out/pe must be 16-byte aligned");
+    if (B == 0 || T == 0) return VH_OK;
+    TablePtrs tp{};
+    for (int j = 0; j < n_tables; ++j) {
+        VH_REQUIRE(tables[j] && vh_aligned16(tables[j]), VH_EALIGN,
+                   "vh_embed_sum_pe: table %d null or unaligned", j);
+        tp.t[j] = tables[j];
+    }
+    dim3 grid((T + 3) / 4, B);
+    hipLaunchKernelGGL(embed_sum_pe_kernel, grid, dim3(256), 0, (hipStream_t)stream, ids,
+                       ids_bstride, ids_tstride, ids_jstride, tp, n_tables, pe, pos0, lens, out,
+                       out_bstride, out_t0, T, d);
+    VH_CHECK_LAUNCH("vh_embed_sum_pe");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3/K4  LayerNorm (two-pass in registers: mean, then sum of squared deviations) + AdaLN affine
+// NV = float4 chunks per lane (d <= 256*NV).  grid: ceil(rows/4), block 256.
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ ada_scale, const float* __restrict__ ada_shift,
+    float* __restrict__ out, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (int64_t)row * d;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        v[i] = c < d ? ld4(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            f32x4 t = v[i] - mean;
+            ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    float* orow = out + (int64_t)row * d;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            f32x4 y = (v[i] - mean) * rstd * ld4(gamma + c) + ld4(beta + c);
+            if (ada_scale) y = ld4(ada_scale + c) * y + ld4(ada_shift + c);
+            st4(orow + c, y);
+        }
+    }
+}
+
+extern "C" int vh_layernorm(const float* x, const float* gamma, const float* beta,
+                            const float* ada_scale, const float* ada_shift, float* out, int rows,
+                            int d, float eps, void* stream) {
+    VH_REQUIRE(x && gamma && beta && out, VH_EINVAL, "vh_layernorm: null pointer");
+    VH_REQUIRE((ada_scale == nullptr) == (ada_shift == nullptr), VH_EINVAL,
+               "vh_layernorm: ada_scale and ada_shift must be given together");
+    VH_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0 && d <= 4096, VH_EINVAL,
+               "vh_layernorm: bad dims rows=%d d=%d (d multiple of 4, <= 4096)", rows, d);
+    VH_REQUIRE(vh_aligned16(x) && vh_aligned16(out) && vh_aligned16(gamma) && vh_aligned16(beta) &&
+                   vh_aligned16(ada_scale) && vh_aligned16(ada_shift),
+               VH_EALIGN, "vh_layernorm: pointers must be 16-byte aligned");
+    if (rows == 0) return VH_OK;
+    dim3 grid((rows + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LN_LAUNCH(NV)                                                                            \
+    hipLaunchKernelGGL(layernorm_kernel<NV>, grid, block, 0, s, x, gamma, beta, ada_scale,       \
+                       ada_shift, out, rows, d, eps)
+    if (d <= 256) LN_LAUNCH(1);
+    else if (d <= 512) LN_LAUNCH(2);
+    else if (d <= 1024) LN_LAUNCH(4);
+    else if (d <= 2048) LN_LAUNCH(8);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
+    VH_CHECK_LAUNCH("vh_layernorm");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K12/K13  greedy step: argmax (lowest index on ties, as torch.topk / multinomial over a one-hot),
+// EOS bookkeeping, token append, next-token embedding + position.  One 256-thread block per row.
+// The step index is derived from the row's own audio position, so the kernel carries no global
+// counter and a captured graph can be replayed as is.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_step_kernel(
+    const float* __restrict__ logits, int ldl, int V, int eos, int64_t* __restrict__ codes,
+    int64_t codes_stride, int32_t* __restrict__ eos_count, const int32_t* __restrict__ pos_base,
+    const float* __restrict__ audio_emb, const float* __restrict__ pe,
+    int32_t* __restrict__ audio_pos, int32_t* __restrict__ cache_len, float* __restrict__ x_next,
+    int d) {
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_tok;
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* lr = logits + (int64_t)b * ldl;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 256) {
+        const float v = lr[i];
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { s_val[w] = best; s_idx[w] = bi; }
+    __syncthreads();
+    const int pos = audio_pos[b];  // index of the token being produced in row b's audio stream
+    if (tid == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (s_val[k] > best || (s_val[k] == best && s_idx[k] < bi)) { best = s_val[k]; bi = s_idx[k]; }
+        int64_t* row = codes + (int64_t)b * codes_stride;
+        int tok = bi;
+        if (row[pos - 1] == (int64_t)eos) tok = eos;  // valle_ar.py:168: finished rows keep EOS
+        row[pos] = tok;                               // valle_ar.py:171
+        if (tok == eos) atomicAdd(&eos_count[pos - (pos_base ? pos_base[b] : 0)], 1);
+        s_tok = tok;
+    }
+    __syncthreads();
+    const int tok = s_tok;
+    const float* er = audio_emb + (int64_t)tok * d;   // valle_ar.py:143-144 for the next step,
+    const float* pr = pe + (int64_t)pos * d;          // only the new row (modules.py:337 keeps it)
+    for (int c = tid * 4; c < d; c += 1024) st4(x_next + (int64_t)b * d + c, ld4(er + c) + ld4(pr + c));
+    if (tid == 0) {
+        audio_pos[b] = pos + 1;
+        cache_len[b] += 1;
+    }
+}
+
+extern "C" int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
+                              int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
+                              const float* audio_emb, const float* pe, int32_t* audio_pos,
+                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next,
+               VH_EINVAL, "vh_greedy_step: null pointer");
+    VH_REQUIRE(B > 0 && V > 0 && ldl >= V && d > 0 && d % 4 == 0, VH_EINVAL,
+               "vh_greedy_step: bad dims B=%d V=%d ldl=%d d=%d", B, V, ldl, d);
+    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next), VH_EALIGN,
+               "vh_greedy_step: audio_emb/pe/x_next must be 16-byte aligned");
+    hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl,
+                       V, eos, codes, codes_stride, eos_count, pos_base, audio_emb, pe, audio_pos,
+                       cache_len, x_next, d);
+    VH_CHECK_LAUNCH("vh_greedy_step");
+    return VH_OK;
+}

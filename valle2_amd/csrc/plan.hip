@@ -1,0 +1,198 @@
+// Native composition of the primitives: one AR decode step (eager / hipGraph-captured) and the
+// full-sequence transformer forward.  Host code only — every launch goes through the C-ABI
+// primitives so that what the tests check piecewise is exactly what the composites run.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "vh_common.h"
+
+static thread_local char g_err[512] = "";
+
+void vh_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* vh_last_error(void) { return g_err; }
+extern "C" int vh_version(void) { return VH_VERSION; }
+
+#define TRY(call)                \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_ != VH_OK) return rc_; \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// AR decoder
+// ---------------------------------------------------------------------------------------------
+struct vh_ar_decoder {
+    vh_ar_decoder_desc d;
+    std::vector<vh_layer> layers;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int ldl = 0;
+};
+
+static int decoder_check(const vh_ar_decoder_desc* d) {
+    VH_REQUIRE(d, VH_EINVAL, "vh_ar_decoder: null desc");
+    VH_REQUIRE(d->B > 0 && d->B <= 64, VH_EUNSUPPORTED,
+               "vh_ar_decoder: B=%d (decode rows per GPU must be 1..64)", d->B);
+    VH_REQUIRE(d->n_layers > 0 && d->layers, VH_EINVAL, "vh_ar_decoder: no layers");
+    VH_REQUIRE(d->d_model == d->n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
+               "vh_ar_decoder: d_model=%d != n_heads=%d x 64", d->d_model, d->n_heads);
+    VH_REQUIRE(d->dff % 16 == 0 && d->V > 0 && d->S_max > 0 && d->n_split >= 1, VH_EINVAL,
+               "vh_ar_decoder: bad dff/V/S_max/n_split");
+    VH_REQUIRE(d->proj_w && d->audio_emb && d->audio_pe && d->x && d->q && d->attn && d->hidden &&
+                   d->logits && d->cache_len && d->audio_pos && d->eos_count && d->codes,
+               VH_EINVAL, "vh_ar_decoder: null buffer in desc");
+    VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
+    return VH_OK;
+}
+
+extern "C" vh_ar_decoder* vh_ar_decoder_create(const vh_ar_decoder_desc* desc) {
+    if (decoder_check(desc) != VH_OK) return nullptr;
+    auto* dec = new vh_ar_decoder();
+    dec->d = *desc;
+    dec->layers.assign(desc->layers, desc->layers + desc->n_layers);
+    dec->d.layers = dec->layers.data();
+    dec->ldl = (desc->V + 3) & ~3;
+    return dec;
+}
+
+extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
+    if (!dec) return;
+    if (dec->exec) (void)hipGraphExecDestroy(dec->exec);
+    if (dec->graph) (void)hipGraphDestroy(dec->graph);
+    delete dec;
+}
+
+// One decode step for every row: x (B,d) holds the new token's embedding on entry and the NEXT
+// token's embedding on exit.  `ev` (optional) brackets each decode-attention launch.
+static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEvent_t>* ev) {
+    const vh_ar_decoder_desc& d = dec->d;
+    const int B = d.B, D = d.d_model;
+    for (int i = 0; i < d.n_layers; ++i) {
+        const vh_layer& L = dec->layers[i];
+        // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
+        TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
+                          d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
+        if (ev) {
+            hipEvent_t e0, e1;
+            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+                vh_set_error("vh_ar_decoder: hipEventCreate failed");
+                return VH_ELAUNCH;
+            }
+            (void)hipEventRecord(e0, s);
+            TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
+                               d.S_max, d.n_split, d.attn_partial, s));
+            (void)hipEventRecord(e1, s);
+            ev->push_back(e0);
+            ev->push_back(e1);
+        } else {
+            TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
+                               d.S_max, d.n_split, d.attn_partial, s));
+        }
+        // out-proj + bias + residual (modules.py:171,277)
+        TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
+                      nullptr, nullptr, 0.f, s));
+        // LN2 fused + linear_1 + exact GELU (modules.py:221,278)
+        TRY(vh_linear(d.x, D, L.w1, L.b1, nullptr, 0, d.hidden, d.dff, B, d.dff, D, VH_ACT_GELU_ERF,
+                      L.ln2_g, L.ln2_b, nullptr, nullptr, d.ln_eps, s));
+        // linear_2 + bias + residual
+        TRY(vh_linear(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, nullptr,
+                      nullptr, nullptr, nullptr, 0.f, s));
+    }
+    // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
+    TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
+                  nullptr, nullptr, nullptr, nullptr, 0.f, s));
+    TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
+                       d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+    return VH_OK;
+}
+
+extern "C" int vh_ar_decoder_step(vh_ar_decoder* dec, void* stream) {
+    VH_REQUIRE(dec, VH_EINVAL, "vh_ar_decoder_step: null decoder");
+    return decoder_enqueue(dec, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int vh_ar_decoder_capture(vh_ar_decoder* dec, void* stream) {
+    VH_REQUIRE(dec, VH_EINVAL, "vh_ar_decoder_capture: null decoder");
+    VH_REQUIRE(stream, VH_EINVAL, "vh_ar_decoder_capture: capture needs a non-null stream");
+    hipStream_t s = (hipStream_t)stream;
+    if (dec->exec) { (void)hipGraphExecDestroy(dec->exec); dec->exec = nullptr; }
+    if (dec->graph) { (void)hipGraphDestroy(dec->graph); dec->graph = nullptr; }
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    const int rc = decoder_enqueue(dec, s, nullptr);
+    e = hipStreamEndCapture(s, &dec->graph);
+    if (rc != VH_OK) return rc;
+    VH_REQUIRE(e == hipSuccess && dec->graph, VH_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(&dec->exec, dec->graph, nullptr, nullptr, 0);
+    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
+extern "C" int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream) {
+    VH_REQUIRE(dec && dec->exec, VH_ESTATE, "vh_ar_decoder_replay: capture first");
+    VH_REQUIRE(n_steps >= 0, VH_EINVAL, "vh_ar_decoder_replay: n_steps=%d", n_steps);
+    for (int i = 0; i < n_steps; ++i) {
+        hipError_t e = hipGraphLaunch(dec->exec, (hipStream_t)stream);
+        VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+    }
+    return VH_OK;
+}
+
+extern "C" int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream,
+                                          float* mean_ms) {
+    VH_REQUIRE(dec && mean_ms && n_steps > 0, VH_EINVAL, "vh_ar_decoder_profile_attn: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev;
+    int rc = VH_OK;
+    for (int i = 0; i < n_steps && rc == VH_OK; ++i) rc = decoder_enqueue(dec, s, &ev);
+    (void)hipStreamSynchronize(s);
+    double total = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) { total += ms; ++n; }
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    *mean_ms = n ? (float)(total / n) : 0.f;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// full-sequence forward (prefill / NAR stage / training forward)
+// ---------------------------------------------------------------------------------------------
+extern "C" int vh_transformer_forward(const vh_forward_desc* f, void* stream) {
+    VH_REQUIRE(f && f->layers && f->x && f->xn && f->q && f->attn && f->hidden, VH_EINVAL,
+               "vh_transformer_forward: null pointer in desc");
+    VH_REQUIRE(f->B > 0 && f->T > 0 && f->n_layers > 0 && f->S_max >= f->T, VH_EINVAL,
+               "vh_transformer_forward: bad dims B=%d T=%d L=%d S_max=%d", f->B, f->T, f->n_layers,
+               f->S_max);
+    VH_REQUIRE(f->d_model == f->n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
+               "vh_transformer_forward: d_model=%d != n_heads=%d x 64", f->d_model, f->n_heads);
+    const int B = f->B, T = f->T, D = f->d_model, M = B * T;
+    for (int i = 0; i < f->n_layers; ++i) {
+        const vh_layer& L = f->layers[i];
+        const float* ada = f->ada ? f->ada + (int64_t)i * 4 * D : nullptr;
+        TRY(vh_layernorm(f->x, L.ln1_g, L.ln1_b, ada, ada ? ada + D : nullptr, f->xn, M, D, f->ln_eps,
+                         stream));
+        TRY(vh_linear_qkv(f->xn, D, L.wqkv, f->q, D, L.kcache, L.vcache, nullptr, B, T, D, f->n_heads,
+                          f->S_max, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
+        TRY(vh_attn_rows(f->q, D, L.kcache, L.vcache, f->attn, D, B, f->n_heads, T, T, f->S_max,
+                         f->mode, f->x_len, f->x_len_dev, f->kv_len, f->mask, f->pad, stream));
+        TRY(vh_linear(f->attn, D, L.wo, L.bo, f->x, D, f->x, D, M, D, D, VH_ACT_NONE, nullptr, nullptr,
+                      nullptr, nullptr, 0.f, stream));
+        TRY(vh_layernorm(f->x, L.ln2_g, L.ln2_b, ada ? ada + 2 * D : nullptr, ada ? ada + 3 * D : nullptr,
+                         f->xn, M, D, f->ln_eps, stream));
+        TRY(vh_linear(f->xn, D, L.w1, L.b1, nullptr, 0, f->hidden, f->dff, M, f->dff, D,
+                      VH_ACT_GELU_ERF, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
+        TRY(vh_linear(f->hidden, f->dff, L.w2, L.b2, f->x, D, f->x, D, M, D, f->dff, VH_ACT_NONE,
+                      nullptr, nullptr, nullptr, nullptr, 0.f, stream));
+    }
+    return VH_OK;
+}

@@ -1,0 +1,201 @@
+"""Device-side runtime of the path: KV cache, scratch buffers, the native forward composite and the
+hipGraph-replayed AR decoder.  Python here only wires pointers; all arithmetic runs in
+libvalle_hip.so (`_lib.lib()` raises without a HIP device — there is no CPU fallback).
+
+Data layout in HBM (all fp32):
+  residual stream x        (B*T, d) row-major, updated in place by the GEMM epilogues
+  KV cache per layer       K (B, h, S_max, 64), V (B, h, S_max, 64): one (b,head) stream is
+                           contiguous, so decode attention reads it as pure 16-B-per-lane bursts
+                           and a new token's K/V row is appended in place (no torch.cat regrow,
+                           valle/models/modules.py:151-157)
+  weights                  the nn.Linear / nn.LayerNorm parameters exactly as stored ((N,K)
+                           row-major): both GEMM operands are K-contiguous, no repacking
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib, kernels
+from ._lib import VhArDecoderDesc, VhForwardDesc, VhLayer, check, ptr, stream
+
+HEAD_DIM = kernels.HEAD_DIM
+
+
+class KVCache:
+    """(L, 2, B, h, S_max, 64) in one allocation; `length` rows are valid for every batch row
+    unless a per-row `cache_len` tensor says otherwise."""
+
+    def __init__(self, n_layers, batch, n_heads, s_max, device):
+        self.buf = torch.empty(n_layers, 2, batch, n_heads, s_max, HEAD_DIM, device=device,
+                               dtype=torch.float32)
+        self.n_layers, self.batch, self.n_heads, self.s_max = n_layers, batch, n_heads, s_max
+
+    def k(self, i):
+        return self.buf[i, 0]
+
+    def v(self, i):
+        return self.buf[i, 1]
+
+
+def _layer_params(layer):
+    """The 11 parameter tensors of one EncoderLayer in VhLayer order."""
+    at, ff = layer.self_attn, layer.ffn
+    n1 = layer.norm1.norm if hasattr(layer.norm1, 'project_layer') else layer.norm1
+    n2 = layer.norm2.norm if hasattr(layer.norm2, 'project_layer') else layer.norm2
+    return (n1.weight, n1.bias, at.qkv.weight, at.out.weight, at.out.bias, n2.weight, n2.bias,
+            ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias)
+
+
+def layer_table(transformer, cache: KVCache):
+    """ctypes array of VhLayer for `transformer.layers` bound to `cache`."""
+    layers = list(transformer.layers)
+    arr = (VhLayer * len(layers))()
+    for i, layer in enumerate(layers):
+        ps = _layer_params(layer)
+        for (name, _), t in zip(VhLayer._fields_[:11], ps):
+            if t.dtype != torch.float32:
+                raise _lib.VhError(f'parameter {name} of layer {i} is {t.dtype}; the path is fp32')
+            setattr(arr[i], name, ptr(t.detach()))
+        arr[i].kcache = ptr(cache.k(i))
+        arr[i].vcache = ptr(cache.v(i))
+    return arr
+
+
+def adaln_table(transformer, embedding):
+    """(L, 2, 2, d) [layer][norm1|norm2][scale|shift] = project_layer(embedding) for every
+    AdaptiveLayerNorm (valle/models/modules.py:94-98); one (1,d)x(d,2d) GEMV each."""
+    layers = list(transformer.layers)
+    d = embedding.shape[-1]
+    emb = embedding.reshape(1, d).contiguous()
+    out = torch.empty(len(layers), 2, 2 * d, device=emb.device, dtype=torch.float32)
+    for i, layer in enumerate(layers):
+        for j, norm in enumerate((layer.norm1, layer.norm2)):
+            kernels.linear(emb, norm.project_layer.weight.detach(), norm.project_layer.bias.detach(),
+                           out=out[i, j].view(1, 2 * d))
+    return out.view(len(layers), 2, 2, d)
+
+
+class ForwardScratch:
+    def __init__(self, rows, d, dff, device):
+        self.xn = torch.empty(rows, d, device=device, dtype=torch.float32)
+        self.q = torch.empty(rows, d, device=device, dtype=torch.float32)
+        self.attn = torch.empty(rows, d, device=device, dtype=torch.float32)
+        self.hidden = torch.empty(rows, dff, device=device, dtype=torch.float32)
+
+
+def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_dev=None,
+                        kv_len=None, mask=None, pad=None, embedding=None, scratch=None):
+    """Run all layers over x (B, T, d) IN PLACE (valle/models/modules.py:341-349), writing each
+    layer's K/V to `cache` rows 0..T-1.  Returns x."""
+    cfg = transformer.hparams
+    B, T, d = x.shape
+    if not x.is_contiguous():
+        raise _lib.VhError('x must be contiguous')
+    if cache.batch != B or cache.s_max < T or cache.n_layers != cfg.num_layers:
+        raise _lib.VhError('KV cache does not fit this forward')
+    scratch = scratch or ForwardScratch(B * T, d, cfg.dim_feedforward, x.device)
+    table = layer_table(transformer, cache)
+    ada = None
+    if cfg.norm != 'LayerNorm':
+        if embedding is None:
+            raise TypeError('AdaptiveLayerNorm needs `embedding` (reference: Linear(None) TypeError)')
+        ada = adaln_table(transformer, embedding)
+    desc = VhForwardDesc(
+        B=B, T=T, d_model=d, n_heads=cfg.n_heads, dff=cfg.dim_feedforward, n_layers=cfg.num_layers,
+        S_max=cache.s_max, mode=mode, x_len=int(x_len), ln_eps=1e-5, layers=table, ada=ptr(ada),
+        x_len_dev=ptr(x_len_dev), kv_len=ptr(kv_len), mask=ptr(mask), pad=ptr(pad),
+        x=ptr(x), xn=ptr(scratch.xn), q=ptr(scratch.q), attn=ptr(scratch.attn),
+        hidden=ptr(scratch.hidden))
+    check(_lib.lib().vh_transformer_forward(C.byref(desc), stream()), 'vh_transformer_forward')
+    return x
+
+
+def pick_n_split(rows_x_heads: int) -> int:
+    """Key-range splits of decode attention so that the grid covers the 256 CUs."""
+    if rows_x_heads >= 256:
+        return 1
+    return max(1, min(16, -(-256 // rows_x_heads)))
+
+
+class ArDecoder:
+    """The AR decode loop of valle/models/valle_ar.py:141-171 for B independent rows, one token
+    per row per step, the whole step enqueued natively and replayed as a hipGraph."""
+
+    def __init__(self, model, batch, s_max, codes, cache: KVCache, cache_len, audio_pos, pos_base,
+                 n_split=None, use_graph=True):
+        cfg = model.config
+        dev = cache.buf.device
+        d, dff, V = cfg.d_model, cfg.dim_feedforward, cfg.num_audio_tokens + 1
+        self.B, self.V, self.d = batch, V, d
+        self.ldl = (V + 3) // 4 * 4
+        self.n_split = n_split or pick_n_split(batch * cfg.n_heads)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.x = torch.empty(batch, d, **f32)
+        self.q = torch.empty(batch, d, **f32)
+        self.attn = torch.empty(batch, d, **f32)
+        self.hidden = torch.empty(batch, dff, **f32)
+        self.logits = torch.zeros(batch, self.ldl, **f32)
+        self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
+        self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
+        self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
+        self.pos_base = pos_base
+        self._table = layer_table(model.transformer, cache)
+        self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
+                      model.audio_position_emb.pe)
+        desc = VhArDecoderDesc(
+            B=batch, d_model=d, n_heads=cfg.n_heads, dff=dff, n_layers=cfg.num_layers, S_max=s_max,
+            V=V, eos=cfg.num_audio_tokens, n_split=self.n_split, ln_eps=1e-5, layers=self._table,
+            proj_w=ptr(self._keep[0]), audio_emb=ptr(self._keep[1]), audio_pe=ptr(self._keep[2]),
+            x=ptr(self.x), q=ptr(self.q), attn=ptr(self.attn), hidden=ptr(self.hidden),
+            logits=ptr(self.logits), attn_partial=ptr(self.partial), cache_len=ptr(cache_len),
+            audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
+            codes=ptr(codes), codes_stride=codes.stride(0))
+        self._desc = desc
+        self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
+        if not self._h:
+            msg = _lib.lib().vh_last_error()
+            raise _lib.VhError(f'vh_ar_decoder_create: {msg.decode() if msg else "failed"}')
+        self._captured = False
+        self.use_graph = use_graph
+
+    def close(self):
+        if getattr(self, '_h', None):
+            _lib.lib().vh_ar_decoder_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def sample_from(self, hidden_last):
+        """Head + greedy step on the last hidden row of a prefill (the tail of step 0)."""
+        m = self._keep
+        kernels.linear(hidden_last, m[0], out=self.logits[:, : self.V])
+        kernels.greedy_step(self.logits, self.V, self._desc.eos, self.codes, self.eos_count, m[1], m[2],
+                            self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
+
+    def run(self, n_steps):
+        """Enqueue n_steps decode steps on the current stream (graph replay when enabled)."""
+        if n_steps <= 0:
+            return
+        s = stream()
+        L = _lib.lib()
+        if self.use_graph:
+            if not self._captured:
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                check(L.vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
+                torch.cuda.current_stream().wait_stream(cap)
+                self._captured = True
+            check(L.vh_ar_decoder_replay(self._h, n_steps, s), 'vh_ar_decoder_replay')
+        else:
+            for _ in range(n_steps):
+                check(L.vh_ar_decoder_step(self._h, s), 'vh_ar_decoder_step')
+
+    def profile_attn(self, n_steps):
+        """Mean duration (ms) of the decode-attention launches over n_steps eager steps, measured
+        with HIP events on the launch stream (advances the decode state by n_steps)."""
+        ms = C.c_float(0)
+        check(_lib.lib().vh_ar_decoder_profile_attn(self._h, n_steps, stream(), C.byref(ms)),
+              'vh_ar_decoder_profile_attn')
+        return ms.value

@@ -1,0 +1,156 @@
+"""Tensor-level wrappers of the C-ABI primitives (include/valle_hip.h).
+
+Each function checks shapes on the host (a kernel that faults can reset every GPU of the box),
+passes raw device pointers + the current torch HIP stream, and raises on a non-zero status.
+Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream
+
+MASK_FULL, MASK_PREFIX, MASK_EXPLICIT = 0, 1, 2
+ACT_NONE, ACT_GELU = 0, 1
+HEAD_DIM = 64
+
+
+def _f32(t, name):
+    if t is not None and t.dtype != torch.float32:
+        raise _lib.VhError(f'{name} must be float32, got {t.dtype}')
+    return t
+
+
+def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None):
+    """out[b, out_t0+t] = sum_j tables[j][ids[b,t,j]] + pe[pos0+t].  ids (B,T) or (B,T,J) int64
+    (any strides); tables: list of (vocab,d); pe (P,1,d)|(P,d)|None; out (B,T_out,d)."""
+    if ids.dtype != torch.int64:
+        raise _lib.VhError('ids must be int64')
+    if ids.dim() == 2:
+        ids = ids.unsqueeze(-1)
+    B, T, J = ids.shape
+    n = len(tables)
+    if n > J and J != 1:
+        raise _lib.VhError(f'{n} tables but ids has {J} codebooks')
+    d = tables[0].shape[1]
+    if out.dim() != 3 or out.shape[0] != B or out.shape[2] != d or out_t0 + T > out.shape[1]:
+        raise _lib.VhError(f'out shape {tuple(out.shape)} does not fit B={B} T={T} d={d} t0={out_t0}')
+    if pe is not None and pos0 + T > pe.shape[0]:
+        raise _lib.VhError(f'position {pos0 + T} exceeds the table ({pe.shape[0]})')
+    arr = (C.c_void_p * n)(*[ptr(_f32(t, 'table')) for t in tables])
+    check(_lib.lib().vh_embed_sum_pe(
+        ids.data_ptr(), ids.stride(0), ids.stride(1), ids.stride(2), arr, n,
+        ptr(_f32(pe, 'pe')), pos0, ptr(lens), ptr(_f32(out, 'out')), out.stride(0), out_t0,
+        B, T, d, stream()), 'vh_embed_sum_pe')
+    return out
+
+
+def layernorm(x, gamma, beta, out=None, ada_scale=None, ada_shift=None, eps=1e-5):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().vh_layernorm(ptr(_f32(x, 'x')), ptr(gamma), ptr(beta), ptr(ada_scale),
+                                  ptr(ada_shift), ptr(out), rows, d, eps, stream()), 'vh_layernorm')
+    return out
+
+
+def _ln_args(ln):
+    if ln is None:
+        return None, None, None, None, 0.0
+    g, b, sc, sh, eps = ln
+    return ptr(g), ptr(b), ptr(sc), ptr(sh), float(eps)
+
+
+def linear(a, w, bias=None, residual=None, out=None, act=ACT_NONE, ln=None):
+    """out = act(LN?(a) @ w.T + bias) + residual.  a (M,K) (row stride lda), w (N,K)."""
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.VhError(f'linear: K mismatch {K} vs {K2}')
+    if a.stride(1) != 1 or not w.is_contiguous():
+        raise _lib.VhError('linear: operands must be row-major')
+    if out is None:
+        ldo = (N + 3) // 4 * 4
+        out = torch.empty(M, ldo, device=a.device, dtype=torch.float32)[:, :N]
+    if out.stride(1) != 1 or (residual is not None and residual.stride(1) != 1):
+        raise _lib.VhError('linear: out/residual must be row-major')
+    if bias is not None and bias.numel() != N:
+        raise _lib.VhError('linear: bias size')
+    if residual is not None and tuple(residual.shape) != (M, N):
+        raise _lib.VhError('linear: residual shape')
+    g, b, sc, sh, eps = _ln_args(ln)
+    check(_lib.lib().vh_linear(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+        residual.data_ptr() if residual is not None else None,
+        residual.stride(0) if residual is not None else 0,
+        _f32(out, 'out').data_ptr(), out.stride(0), M, N, K, act, g, b, sc, sh, eps, stream()),
+        'vh_linear')
+    return out
+
+
+def linear_qkv(a, wqkv, q_out, kcache, vcache, B, T, n_heads, cache_len=None, ln=None):
+    """QKV projection; Q → q_out (B*T, d); K,V rows appended to the caches (B,h,S_max,64)."""
+    M, d = a.shape
+    if M != B * T or tuple(wqkv.shape) != (3 * d, d) or d != n_heads * HEAD_DIM:
+        raise _lib.VhError(f'linear_qkv: shapes a={tuple(a.shape)} w={tuple(wqkv.shape)} B={B} T={T}')
+    S_max = kcache.shape[2]
+    if tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM) or kcache.shape != vcache.shape:
+        raise _lib.VhError(f'linear_qkv: cache shape {tuple(kcache.shape)}')
+    if cache_len is None and T > S_max:
+        raise _lib.VhError('linear_qkv: T > S_max')
+    g, b, sc, sh, eps = _ln_args(ln)
+    check(_lib.lib().vh_linear_qkv(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(wqkv), q_out.data_ptr(), q_out.stride(0),
+        ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max, g, b, sc, sh, eps,
+        stream()), 'vh_linear_qkv')
+    return q_out
+
+
+def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_dev=None,
+              kv_len=None, mask=None, pad=None):
+    S_max = kcache.shape[2]
+    if tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM) or Tk > S_max or Tq > Tk:
+        raise _lib.VhError(f'attn_rows: cache {tuple(kcache.shape)} Tq={Tq} Tk={Tk}')
+    if q.shape[0] != B * Tq or out.shape[0] != B * Tq:
+        raise _lib.VhError('attn_rows: q/out rows')
+    if mask is not None and (mask.dtype != torch.uint8 or tuple(mask.shape) != (Tq, Tk)):
+        raise _lib.VhError('attn_rows: mask must be uint8 (Tq,Tk)')
+    if pad is not None and (pad.dtype != torch.uint8 or tuple(pad.shape) != (B, Tk)):
+        raise _lib.VhError('attn_rows: pad must be uint8 (B,Tk)')
+    check(_lib.lib().vh_attn_rows(
+        q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0), B,
+        n_heads, Tq, Tk, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
+        stream()), 'vh_attn_rows')
+    return out
+
+
+def attn_decode_ws(B, n_heads, n_split, device):
+    n = _lib.lib().vh_attn_decode_ws_bytes(B, n_heads, n_split)
+    return torch.empty(max(n, 16) // 4, device=device, dtype=torch.float32) if n else None
+
+
+def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=None):
+    B, n_heads, S_max, hd = kcache.shape
+    if hd != HEAD_DIM or q.shape[0] != B or out.shape[0] != B:
+        raise _lib.VhError('attn_decode: shapes')
+    if cache_len.dtype != torch.int32 or cache_len.numel() != B:
+        raise _lib.VhError('attn_decode: cache_len must be int32 (B)')
+    check(_lib.lib().vh_attn_decode(
+        q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0),
+        ptr(cache_len), len_bias, B, n_heads, S_max, n_split, ptr(partial), stream()),
+        'vh_attn_decode')
+    return out
+
+
+def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next,
+                pos_base=None):
+    B = logits.shape[0]
+    d = x_next.shape[1]
+    check(_lib.lib().vh_greedy_step(
+        logits.data_ptr(), logits.stride(0), V, eos, ptr(codes), codes.stride(0), ptr(eos_count),
+        ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
+        stream()), 'vh_greedy_step')
