@@ -1,0 +1,350 @@
+"""Transformer building blocks with the reference's constructor/forward signatures and state_dict
+keys (valle/models/modules.py:11-352), computing on MI355X through libvalle_hip.so.
+
+These classes are parameter holders plus pointer plumbing: every forward runs HIP kernels on the
+current stream.  CPU tensors are rejected loudly (no CPU fallback; the CPU oracle lives in oracle/
+and is test-only).  Only `merge_masks` — bool/int mask plumbing the reference's own tests call on
+CPU tensors — is device-agnostic host logic.
+
+Attention masks: the API convention is the reference's (nonzero/True = masked,
+modules.py:160-164).  Masks produced by `valle2_amd.utils.build_attn_mask` carry their
+(x_len, y_len) as a tag, and padding masks from `build_pad_mask` carry their lengths, so the
+kernels evaluate them analytically; any other mask tensor takes the explicit u8-mask path.
+No (B,h,T,T) tensor is ever built on the compute path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from einops import rearrange, repeat
+
+from . import _lib, kernels
+from .engine import KVCache, transformer_forward
+from .synth import sinusoid_table
+
+HEAD_DIM = kernels.HEAD_DIM
+
+
+def _need_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.VhError(f'{what}: got a {t.device} tensor. valle2_amd computes on a HIP device only; '
+                           f'move the module and inputs to "cuda" (no CPU fallback exists).')
+
+
+def _drop(module: nn.Dropout, x):
+    # dropout is the identity in eval mode / p=0; in training mode it is torch's device RNG
+    return module(x) if (module.training and module.p > 0) else x
+
+
+class TokenEmbedding(nn.Module):
+    """valle/models/modules.py:11-37"""
+
+    def __init__(self, vocab_size: int, dim_model: int, dropout: float = 0.0):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.dim_model = dim_model
+        self.dropout = nn.Dropout(p=dropout)
+        self.word_embeddings = nn.Embedding(self.vocab_size, self.dim_model)
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.word_embeddings.weight
+
+    def embedding(self, index: int) -> torch.Tensor:
+        return self.word_embeddings.weight[index: index + 1]
+
+    def forward(self, x: torch.Tensor):
+        _need_device(x, 'TokenEmbedding')
+        ids = x.reshape(-1, x.shape[-1]) if x.dim() > 1 else x.reshape(1, -1)
+        out = torch.empty(*ids.shape, self.dim_model, device=x.device, dtype=torch.float32)
+        kernels.embed_sum_pe(ids, [self.weight.detach()], None, 0, out)
+        return _drop(self.dropout, out.view(*x.shape, self.dim_model))
+
+
+class PositionalEncoding(nn.Module):
+    """valle/models/modules.py:40-80 — absolute sinusoid table (buffer `pe`, in the state_dict)."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        self.register_buffer('pe', sinusoid_table(d_model, max_len))
+
+    def forward(self, x):
+        _need_device(x, 'PositionalEncoding')
+        b, t, c = x.shape
+        if t > self.pe.shape[0]:
+            raise _lib.VhError(f'sequence length {t} exceeds max_len {self.pe.shape[0]}')
+        out = x + self.pe[:t, 0]          # plumbing-level add; the fused kernel is embed_sum_pe
+        return _drop(self.dropout, out)
+
+
+class AdaptiveLayerNorm(nn.Module):
+    """valle/models/modules.py:83-99"""
+
+    def __init__(self, d_model) -> None:
+        super().__init__()
+        self.project_layer = nn.Linear(d_model, 2 * d_model)
+        self.norm = nn.LayerNorm(d_model)
+        self.d_model = d_model
+        self.eps = self.norm.eps
+
+    def scale_shift(self, embedding: torch.Tensor):
+        d = self.d_model
+        if embedding.numel() != d:
+            raise _lib.VhError('AdaptiveLayerNorm: one (1, d_model) stage embedding is supported')
+        wb = kernels.linear(embedding.reshape(1, d).contiguous(), self.project_layer.weight.detach(),
+                            self.project_layer.bias.detach())
+        wb = wb.contiguous().view(2, d)
+        return wb[0], wb[1]
+
+    def forward(self, x: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
+        _need_device(x, 'AdaptiveLayerNorm')
+        sc, sh = self.scale_shift(embedding)
+        return kernels.layernorm(x.contiguous(), self.norm.weight.detach(), self.norm.bias.detach(),
+                                 ada_scale=sc, ada_shift=sh, eps=self.eps)
+
+
+class _HipLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters (same state_dict keys), forward on the HIP kernel."""
+
+    def forward(self, x):
+        _need_device(x, 'LayerNorm')
+        return kernels.layernorm(x.contiguous(), self.weight.detach(), self.bias.detach(), eps=self.eps)
+
+
+class _CacheView:
+    """Bookkeeping attached to the (k, v) views a module returns, so the next call appends in
+    place instead of copying the whole cache (valle/models/modules.py:151-157 does a torch.cat)."""
+    __slots__ = ('kbuf', 'vbuf', 'length')
+
+    def __init__(self, kbuf, vbuf, length):
+        self.kbuf, self.vbuf, self.length = kbuf, vbuf, length
+
+
+def _tag(k, v, info):
+    k._vh_cache = info
+    v._vh_cache = info
+    return k, v
+
+
+def _mask_spec(attn_mask, padding_mask, tq, tk, device):
+    """Translate API masks into kernel arguments (dict for kernels.attn_rows)."""
+    if attn_mask is None:
+        # reference defect D6: key padding is dropped when no attn_mask is given
+        return dict(mode=kernels.MASK_FULL)
+    lens = getattr(padding_mask, '_vh_lens', None) if padding_mask is not None else None
+    tag = getattr(attn_mask, '_vh_prefix', None)
+    if tag is not None and tag[0] + tag[1] == tq == tk and (padding_mask is None or lens is not None):
+        return dict(mode=kernels.MASK_PREFIX, x_len=tag[0], kv_len=lens)
+    if attn_mask.dim() != 2:
+        raise _lib.VhError('3-D attention masks are not supported by the HIP path (2-D + key padding only)')
+    if tuple(attn_mask.shape) != (tq, tk):
+        raise _lib.VhError(f'attn_mask shape {tuple(attn_mask.shape)} != ({tq},{tk})')
+    m = (attn_mask != 0).to(device=device, dtype=torch.uint8).contiguous()
+    p = None
+    if padding_mask is not None:
+        p = (padding_mask != 0).to(device=device, dtype=torch.uint8).contiguous()
+    return dict(mode=kernels.MASK_EXPLICIT, mask=m, pad=p)
+
+
+class MultiHeadAttention(nn.Module):
+    """valle/models/modules.py:102-207"""
+
+    def __init__(self, d_model: int, n_heads: int) -> None:
+        super().__init__()
+        assert d_model % n_heads == 0, 'd_model should be divisible by n_heads'
+        self.d_model = d_model
+        self.n_heads = n_heads
+        self.head_dim = d_model // n_heads
+        self.qkv = nn.Linear(d_model, 3 * d_model, bias=False)
+        self.out = nn.Linear(d_model, d_model)
+
+    def forward(self, x, *, attn_mask=None, padding_mask=None, kv_cache=None, use_cache=False,
+                _ln=None, _residual=None):
+        """x (B, n, d) → (out (B, n, d), (k, v) | None) with k, v of shape (B, h, S, hd).
+        `_ln` / `_residual` are internal fusion hooks used by EncoderLayer."""
+        _need_device(x, 'MultiHeadAttention')
+        if self.head_dim != HEAD_DIM:
+            raise _lib.VhError(f'head_dim {self.head_dim} unsupported: the kernels are built for 64')
+        b, n, d = x.shape
+        h = self.n_heads
+        x2 = x.reshape(b * n, d)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        past = 0
+        info = None
+        if use_cache and kv_cache is not None:
+            past = kv_cache[0].shape[-2]
+            info = getattr(kv_cache[0], '_vh_cache', None)
+            if info is None or info.length != past or info.kbuf.shape[2] < past + n:
+                # foreign (or full) cache: adopt it into a buffer with room to grow
+                cap = max(2 * (past + n), past + n + 64)
+                kbuf = torch.empty(b, h, cap, HEAD_DIM, device=x.device, dtype=torch.float32)
+                vbuf = torch.empty_like(kbuf)
+                kbuf[:, :, :past] = kv_cache[0]
+                vbuf[:, :, :past] = kv_cache[1]
+                info = _CacheView(kbuf, vbuf, past)
+        if info is None:
+            cap = n + (64 if use_cache else 0)
+            info = _CacheView(torch.empty(b, h, cap, HEAD_DIM, device=x.device, dtype=torch.float32),
+                              torch.empty(b, h, cap, HEAD_DIM, device=x.device, dtype=torch.float32), 0)
+        total = past + n
+        q = torch.empty(b * n, d, device=x.device, dtype=torch.float32)
+        cache_len = None
+        if past:
+            cache_len = torch.full((b,), past, device=x.device, dtype=torch.int32)
+        ln = _ln if (_ln is not None and b * n <= 64) else None
+        a_in = x2 if (ln is not None or _ln is None) else kernels.layernorm(x2, *_ln[:2], ada_scale=_ln[2],
+                                                                            ada_shift=_ln[3], eps=_ln[4])
+        kernels.linear_qkv(a_in, self.qkv.weight.detach(), q, info.kbuf, info.vbuf, b, n, h,
+                           cache_len=cache_len, ln=ln)
+        attn = torch.empty(b * n, d, device=x.device, dtype=torch.float32)
+        if n == 1 and attn_mask is None:
+            cl = cache_len if cache_len is not None else torch.zeros(b, device=x.device, dtype=torch.int32)
+            kernels.attn_decode(q, info.kbuf, info.vbuf, attn, cl, 1)
+        else:
+            spec = _mask_spec(attn_mask, padding_mask, n, total, x.device)
+            kernels.attn_rows(q, info.kbuf, info.vbuf, attn, b, h, n, total, **spec)
+        res2 = None
+        if _residual is not None:
+            res2 = _residual.reshape(b * n, d)
+        out = kernels.linear(attn, self.out.weight.detach(), self.out.bias.detach(), residual=res2,
+                             out=torch.empty(b * n, d, device=x.device, dtype=torch.float32))
+        kv = None
+        if use_cache:
+            new = _CacheView(info.kbuf, info.vbuf, total)
+            kv = _tag(info.kbuf[:, :, :total], info.vbuf[:, :, :total], new)
+        return out.view(b, n, d), kv
+
+    def merge_masks(self, batch_size, attn_mask, key_padding_mask):
+        """valle/models/modules.py:175-207 — returns the SUM tensor (B,h,T,T) (or (B,1,T,T) for a
+        3-D mask); host-side mask plumbing, never used on the compute path."""
+        if attn_mask is None:
+            return None
+        if attn_mask.dim() == 3:
+            merged = rearrange(attn_mask, 'b t s -> b 1 t s')
+        else:
+            merged = repeat(attn_mask, 't s -> b n t s', b=batch_size, n=self.n_heads)
+        if key_padding_mask is not None:
+            merged = merged + repeat(key_padding_mask, 'b s -> b n t s', n=self.n_heads, t=1)
+        return merged
+
+
+class FeedForward(nn.Module):
+    """valle/models/modules.py:210-221 — Linear → exact-erf GELU → dropout → Linear."""
+
+    def __init__(self, d_model: int, d_ff: int, dropout: float = 0.1) -> None:
+        super().__init__()
+        self.linear_1 = nn.Linear(d_model, d_ff)
+        self.activation = nn.GELU()
+        self.dropout = nn.Dropout(dropout)
+        self.linear_2 = nn.Linear(d_ff, d_model)
+
+    def forward(self, x, _ln=None, _residual=None):
+        _need_device(x, 'FeedForward')
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        ln = _ln if (_ln is not None and x2.shape[0] <= 64) else None
+        if _ln is not None and ln is None:
+            x2 = kernels.layernorm(x2, *_ln[:2], ada_scale=_ln[2], ada_shift=_ln[3], eps=_ln[4])
+        hid = kernels.linear(x2, self.linear_1.weight.detach(), self.linear_1.bias.detach(),
+                             act=kernels.ACT_GELU, ln=ln,
+                             out=torch.empty(x2.shape[0], self.linear_1.out_features, device=x.device,
+                                             dtype=torch.float32))
+        hid = _drop(self.dropout, hid)
+        res2 = _residual.reshape(-1, shape[-1]) if _residual is not None else None
+        out = kernels.linear(hid, self.linear_2.weight.detach(), self.linear_2.bias.detach(),
+                             residual=res2,
+                             out=torch.empty(x2.shape[0], shape[-1], device=x.device, dtype=torch.float32))
+        return out.view(shape)
+
+
+class EncoderLayer(nn.Module):
+    """valle/models/modules.py:224-294 — pre-norm residual block."""
+
+    def __init__(self, config) -> None:
+        super().__init__()
+        self.config = config
+        self.self_attn = MultiHeadAttention(config.d_model, config.n_heads)
+        self.ffn = FeedForward(config.d_model, config.dim_feedforward, dropout=config.dropout)
+        self.norm1 = self._get_norm()(config.d_model)
+        self.norm2 = self._get_norm()(config.d_model)
+        self.dropout1 = nn.Dropout(config.dropout)
+        self.dropout2 = nn.Dropout(config.dropout)
+        self.activation = self._get_activation()()   # built but never called (reference D8)
+
+    def _ln_args(self, norm, embedding):
+        if self.config.norm == 'LayerNorm':
+            return (norm.weight.detach(), norm.bias.detach(), None, None, norm.eps)
+        if embedding is None:
+            raise TypeError('AdaptiveLayerNorm needs `embedding` (the reference raises '
+                            'TypeError in Linear(None), valle/models/modules.py:95)')
+        sc, sh = norm.scale_shift(embedding)
+        return (norm.norm.weight.detach(), norm.norm.bias.detach(), sc, sh, norm.eps)
+
+    def forward(self, x, *, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
+                use_cache=False):
+        _need_device(x, 'EncoderLayer')
+        fuse1 = not (self.dropout1.training and self.dropout1.p > 0)
+        fuse2 = not (self.dropout2.training and self.dropout2.p > 0)
+        x_attn, next_kv = self.self_attn(x, attn_mask=attn_mask, padding_mask=padding_mask,
+                                         kv_cache=kv_cache, use_cache=use_cache,
+                                         _ln=self._ln_args(self.norm1, embedding),
+                                         _residual=x if fuse1 else None)
+        x = x_attn if fuse1 else x + self.dropout1(x_attn)
+        y = self.ffn(x, _ln=self._ln_args(self.norm2, embedding), _residual=x if fuse2 else None)
+        x = y if fuse2 else x + self.dropout2(y)
+        return x, next_kv
+
+    def _get_norm(self):
+        return {'LayerNorm': _HipLayerNorm, 'AdaptiveLayerNorm': AdaptiveLayerNorm}[self.config.norm]
+
+    def _get_activation(self):
+        return {'relu': nn.ReLU, 'gelu': nn.GELU}[self.config.activation]
+
+
+class Transformer(nn.Module):
+    """valle/models/modules.py:297-352"""
+
+    def __init__(self, hparams) -> None:
+        super().__init__()
+        self.hparams = hparams
+        self.layers = nn.ModuleList([EncoderLayer(hparams) for _ in range(hparams.num_layers)])
+
+    def _any_dropout(self):
+        return self.training and self.hparams.dropout > 0
+
+    def forward(self, x, *, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
+                use_cache=False):
+        _need_device(x, 'Transformer')
+        new_kv: tuple = ()
+        if use_cache and kv_cache is not None:
+            x = x[:, -1:]
+            attn_mask = None
+        else:
+            kv_cache = tuple([None] * self.hparams.num_layers)
+            if not self._any_dropout() and x.shape[0] * x.shape[1] > 64:
+                return self._forward_native(x, padding_mask, attn_mask, embedding, use_cache)
+        for layer, past_kv in zip(self.layers, kv_cache):
+            x, next_kv = layer(x, padding_mask=padding_mask, attn_mask=attn_mask,
+                               embedding=embedding, kv_cache=past_kv, use_cache=use_cache)
+            if use_cache:
+                new_kv = new_kv + (next_kv,)
+        return x, new_kv
+
+    def _forward_native(self, x, padding_mask, attn_mask, embedding, use_cache):
+        """Whole stack through the native composite (one C call, no per-layer Python)."""
+        b, t, d = x.shape
+        cfg = self.hparams
+        cache = KVCache(cfg.num_layers, b, cfg.n_heads, t + (64 if use_cache else 0), x.device)
+        spec = _mask_spec(attn_mask, padding_mask, t, t, x.device)
+        y = x.contiguous().clone()
+        transformer_forward(self, y, cache, embedding=embedding, **spec)
+        new_kv: tuple = ()
+        if use_cache:
+            for i in range(cfg.num_layers):
+                info = _CacheView(cache.k(i), cache.v(i), t)
+                new_kv = new_kv + (_tag(cache.k(i)[:, :, :t], cache.v(i)[:, :, :t], info),)
+        return y, new_kv

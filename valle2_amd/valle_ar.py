@@ -1,0 +1,194 @@
+"""ValleAR with the reference's constructor / training_step / generate / configure_optimizers
+signatures and state_dict keys (valle/models/valle_ar.py:14-194), running on MI355X.
+
+`generate()` does not walk the module tree per step as the reference does: the prompt is embedded
+and prefilled once by the native forward composite (analytic prefix-LM mask, K/V written straight
+into a preallocated cache) and every further token is one replay of a hipGraph holding the whole
+decode step (engine.ArDecoder).  EOS is polled every `EOS_POLL` steps instead of a host sync per
+step (valle_ar.py:169-170).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import optim
+
+from . import _lib, kernels
+from .engine import ArDecoder, ForwardScratch, KVCache, transformer_forward
+from .modules import PositionalEncoding, TokenEmbedding, Transformer
+from .utils import get_best_beam
+
+try:  # the reference subclasses lightning.LightningModule; lightning is optional here
+    import lightning as L
+    _Base = L.LightningModule
+except Exception:  # pragma: no cover - lightning is absent in this image
+    class _Base(nn.Module):
+        def log(self, *args, **kwargs):
+            return None
+
+EOS_POLL = 32
+
+
+class ValleAR(_Base):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.tokens_emb = TokenEmbedding(config.vocab_size, config.d_model)
+        self.audio_emb = TokenEmbedding(config.num_audio_tokens + 2, config.d_model)
+        self.tokens_position_emb = PositionalEncoding(config.d_model)
+        self.audio_position_emb = PositionalEncoding(config.d_model)
+        self.transformer = Transformer(config)
+        self.proj = nn.Linear(config.d_model, config.num_audio_tokens + 1, bias=False)
+        self.last_generate_stats: dict = {}
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def eos_token(self):
+        return self.config.num_audio_tokens
+
+    @property
+    def bos_token(self):
+        return self.config.num_audio_tokens + 1
+
+    # ------------------------------------------------------------------------------------
+    def _require_layernorm(self):
+        if self.config.norm != 'LayerNorm':
+            # reference defect D3: with AdaptiveLayerNorm the AR model passes embedding=None and
+            # dies in Linear(None) with a TypeError; keep the failure, say why.
+            raise TypeError("ValleAR needs norm='LayerNorm' (AdaptiveLayerNorm has no stage "
+                            'embedding in the AR model; the reference raises TypeError too)')
+
+    def _embed_rows(self, text_ids, codes_ids, x, x_t0=0):
+        """x[:, x_t0:x_t0+Tx] = tokens_emb + PE; x[:, x_t0+Tx:] = audio_emb + PE (positions restart
+        at 0 for the audio stream, valle_ar.py:61-66)."""
+        tx = text_ids.shape[1]
+        kernels.embed_sum_pe(text_ids, [self.tokens_emb.weight.detach()], self.tokens_position_emb.pe,
+                             0, x, out_t0=x_t0)
+        kernels.embed_sum_pe(codes_ids, [self.audio_emb.weight.detach()], self.audio_position_emb.pe,
+                             0, x, out_t0=x_t0 + tx)
+
+    def forward_logits(self, batch):
+        """Teacher-forced logits (B, Ty, V_a+1) of valle_ar.py:54-83 (row-major, before the
+        reference's rearrange to (B, V, Ty))."""
+        self._require_layernorm()
+        dev = self.device
+        if dev.type != 'cuda':
+            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
+        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        codes_lens = batch['codes_lens']
+        tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
+        b = tokens.shape[0]
+        d = self.config.d_model
+        x = torch.empty(b, tx + ty, d, device=dev, dtype=torch.float32)
+        self._embed_rows(tokens[:, :tx], codes[:, :ty], x)
+        # key padding covers audio only; text padding is NOT masked (valle_ar.py:69-73)
+        kv_len = (codes_lens.to(torch.int64) + tx).to(device=dev, dtype=torch.int32)
+        cache = KVCache(self.config.num_layers, b, self.config.n_heads, tx + ty, dev)
+        transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
+        out = x[:, tx:].reshape(b * ty, d)
+        logits = kernels.linear(out, self.proj.weight.detach())
+        return logits.reshape(b, ty, -1)
+
+    def training_step(self, batch, **kwargs):
+        """valle_ar.py:43-90.  Forward only for now: the loss is computed from HIP logits but
+        carries no autograd graph (backward kernels are a later row of SURVEY.md §8)."""
+        logits = self.forward_logits(batch)
+        target = batch['target'].to(logits.device)
+        loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), target)
+        self.log('train/loss', loss)
+        return loss
+
+    # ------------------------------------------------------------------------------------
+    @torch.inference_mode()
+    def generate(self, prompt_tokens, prompt_codes, target_tokens=None):
+        """valle_ar.py:92-180 — one utterance replicated over `num_beams` rows; returns the 1-D
+        int64 first-codebook tokens of the best beam with EOS stripped."""
+        assert prompt_tokens.dim() == 1, 'Prompt tokens should be 1D tensor.'
+        assert prompt_codes.dim() == 2, 'Prompt codes should be 2D tensor.'
+        if target_tokens is not None:
+            assert target_tokens.dim() == 1, 'Target tokens should be 1D tensor.'
+        beams = self.config.num_beams
+        text = prompt_tokens if target_tokens is None else torch.cat((prompt_tokens, target_tokens), dim=0)
+        rows = self.generate_batch([text] * beams, [prompt_codes[..., 0]] * beams)
+        # beams → one sequence (valle_ar.py:174-180); with top_k=1 every log-prob is exactly 0
+        dev = rows.device
+        sum_logprobs = torch.zeros(beams, device=dev)
+        prompt_len = prompt_codes.shape[0] + 1
+        best = get_best_beam(rows, sum_logprobs, self.eos_token, self.config.length_penalty)
+        best = best[prompt_len:]
+        return best[best != self.eos_token]
+
+    @torch.inference_mode()
+    def generate_batch(self, texts, first_codes, max_new=None, use_graph=True):
+        """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
+        texts[b]: 1-D int64 text ids; first_codes[b]: 1-D int64 first-codebook prompt (no BOS).
+        All rows must currently share their lengths.  Returns codes (B, prompt_len + n_new) int64
+        (BOS + prompt + generated, finished rows padded with EOS), on the device."""
+        self._require_layernorm()
+        cfg = self.config
+        if cfg.top_k != 1:
+            raise NotImplementedError('valle2_amd: only greedy decoding (top_k=1) runs on device yet')
+        if not cfg.use_kv_cache:
+            raise NotImplementedError('use_kv_cache=False is broken in the reference (D2); '
+                                      'the HIP path always uses its in-place cache')
+        dev = self.device
+        if dev.type != 'cuda':
+            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
+        B = len(texts)
+        tx, tc = int(texts[0].shape[0]), int(first_codes[0].shape[0])
+        if any(t.shape[0] != tx for t in texts) or any(c.shape[0] != tc for c in first_codes):
+            raise NotImplementedError('ragged rows are not supported yet')
+        max_new = cfg.max_audio_len if max_new is None else max_new
+        prompt_len = tc + 1
+        s0 = tx + prompt_len
+        s_max = s0 + max_new
+        if prompt_len + max_new > self.audio_position_emb.pe.shape[0]:
+            raise _lib.VhError('audio length exceeds the positional table (max_len 5000)')
+        text_ids = torch.stack([t.to(dev) for t in texts])
+        codes = torch.full((B, prompt_len + max_new), self.eos_token, device=dev, dtype=torch.int64)
+        codes[:, 0] = self.bos_token                                   # valle_ar.py:115-117
+        codes[:, 1:prompt_len] = torch.stack([c.to(dev) for c in first_codes])
+        d = cfg.d_model
+
+        # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None)
+        cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev)
+        x = torch.empty(B, s0, d, device=dev, dtype=torch.float32)
+        self._embed_rows(text_ids, codes[:, :prompt_len], x)
+        transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX, x_len=tx,
+                            scratch=ForwardScratch(B * s0, d, cfg.dim_feedforward, dev))
+        cache_len = torch.full((B,), s0 - 1, device=dev, dtype=torch.int32)   # +1 by the greedy step
+        audio_pos = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
+        pos_base = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
+        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph)
+        try:
+            dec.sample_from(x[:, -1].contiguous())
+            del x
+            # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
+            done, stop = 1, None
+            while done < max_new:
+                n = min(EOS_POLL, max_new - done)
+                dec.run(n)
+                done += n
+                full = (dec.eos_count[:done] == B).nonzero()
+                if full.numel():
+                    stop = int(full[0])
+                    break
+            if stop is None:
+                full = (dec.eos_count[:done] == B).nonzero()
+                stop = int(full[0]) if full.numel() else None
+            n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
+            self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split}
+            self._last_decoder = None
+            return codes[:, : prompt_len + n_new].clone()
+        finally:
+            dec.close()
+
+    def configure_optimizers(self):
+        """valle_ar.py:182-194"""
+        optimizer = optim.AdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
+                                weight_decay=self.config.weight_decay, fused=self.device.type == 'cuda')
+        scheduler = optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, self.config.lr_warmup)
+        return {'optimizer': optimizer, 'lr_scheduler': scheduler}
