@@ -1,0 +1,253 @@
+"""Headline benchmark: acoustic tokens/s of AR greedy decoding on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch = one full greedy `generate` of
+BASELINE.json configs[1] per GPU: 12-layer/512-dim AR decoder, 32 rows, 1024-token prompt
+(256 text + BOS + 767 codec tokens) → 512 new tokens, fp32, synthetic tokens and seeded
+random-init weights, inputs resident in HBM before the timed region.  value = new tokens of all
+ranks / wall time (prefill + 511 graph-replayed decode steps included).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the utterance batch shards across ranks (32 rows per GPU, weights replicated, no
+data-path collective: SURVEY.md §8e "inference: replicas only"); ranks meet at a barrier before and
+after the timed region and the slowest rank's time is used (RCCL all-reduce MAX).
+
+Extra objects on the same JSON line: `roofline` (decode-attention kernel, HIP-event timed, HBM
+bound), `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample; rank 0,
+N=1 only), `nar` (one NAR stage forward of configs[2], secondary metric).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # fp32 MFMA dense peak
+
+AR = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm='LayerNorm',
+          top_k=1, use_kv_cache=True)
+ROWS, TEXT, FRAMES, NEW = 32, 256, 767, 512
+NAR_B, NAR_TEXT, NAR_FRAMES = 64, 256, 768
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-nar', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--small', action='store_true', help='tiny shapes for a functional check')
+    return ap.parse_args()
+
+
+def log(msg):
+    print(f'[bench {time.strftime("%H:%M:%S")}] {msg}', file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU cores this process may really use: cgroup quota, else affinity (os.cpu_count() reports
+    the whole host on a shared box and oversubscribing torch's pool stalls for minutes)."""
+    n = len(os.sched_getaffinity(0))
+    for quota_f, period_f in (('/sys/fs/cgroup/cpu.max', None),
+                              ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us')):
+        try:
+            if period_f is None:
+                quota, period = Path(quota_f).read_text().split()
+            else:
+                quota, period = Path(quota_f).read_text().strip(), Path(period_f).read_text().strip()
+            if quota not in ('max', '-1'):
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    # a GPU box gives each GPU a 16-core share of the host (driver note); never oversubscribe it
+    try:
+        import torch
+        n = min(n, 16 * max(1, torch.cuda.device_count()))
+    except Exception:
+        pass
+    return n
+
+
+def attn_algorithmic_bytes(rows, d_model, s0, new):
+    """Mean algorithmic HBM bytes of one decode-attention launch over the decode steps 1..new-1:
+    every K and V element of the row's context read once + q read + out written (SURVEY.md §8d:
+    2*B*S*d elements per layer per step, e=4)."""
+    lens = [s0 + t for t in range(1, new)]          # keys attended at step t (incl. the new one)
+    mean_s = sum(lens) / len(lens)
+    return 4.0 * (2 * rows * mean_s * d_model + 2 * rows * d_model), mean_s
+
+
+def cpu_baseline(cfg_kw, sd, utt, rows, new):
+    """Oracle (CPU restatement, proven bit-identical to the reference on the golden fixtures) on
+    this host's cores: prefill once, then 16 decode steps; extrapolated to `new` tokens."""
+    import torch
+
+    from oracle import valle_oracle as O          # checker/baseline only (never the product path)
+    from valle2_amd import ConfigValle
+    torch.set_num_threads(host_cores())
+    times = {}
+    for n in (1, 17):
+        log(f'cpu_baseline: oracle generate with {n} step(s) on {torch.get_num_threads()} threads')
+        cfg = ConfigValle(**dict(cfg_kw, num_beams=rows, max_audio_len=n))
+        t0 = time.perf_counter()
+        O.ar_generate(sd, cfg, *utt)
+        times[n] = time.perf_counter() - t0
+    t_prefill, t_step = times[1], (times[17] - times[1]) / 16
+    total = t_prefill + (new - 1) * t_step
+    return {'value': rows * new / total, 'unit': 'tokens/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'oracle ar_generate, same shapes: 1 prefill ({t_prefill:.2f} s) + 16 decode steps '
+                      f'({t_step * 1e3:.1f} ms/step at S~{TEXT + FRAMES + 1}), extrapolated to {new} tokens'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    os.chdir(tempfile.mkdtemp(prefix='vh_bench_'))
+    import torch
+    import torch.distributed as dist
+
+    from valle2_amd import ConfigValle, get_model_class, synth
+
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+
+    rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
+    ar_kw = dict(AR)
+    if args.small:
+        rows, text, frames, new = 4, 32, 63, 24
+        ar_kw.update(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2)
+    cfg = ConfigValle(**ar_kw, num_beams=rows, max_audio_len=new)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=0, rich=False), cfg)
+    model = get_model_class('ValleAR')(cfg)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    # 32 DISTINCT utterances per rank (rows are never deduplicated), seeds per SURVEY.md §8d
+    utts = [synth.synth_utterance(cfg, text // 2, text - text // 2, frames, seed=1234 + rank * rows + r)
+            for r in range(rows)]
+    texts = [torch.cat([u[0], u[2]]).to(dev) for u in utts]
+    firsts = [u[1][:, 0].to(dev) for u in utts]
+
+    def step():
+        out = model.generate_batch(texts, firsts)
+        assert out.shape[1] == frames + 1 + new, 'EOS must not end a bench run early'
+        return out
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log(f'rank {rank}/{world}: model ready, warmup {args.warmup}')
+    for _ in range(args.warmup):
+        step()
+    log('timed region')
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert int((out[:, frames + 1:] == cfg.eos_token).sum()) == 0, 'EOS appeared in a bench run'
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    log(f'{ms_per_step:.1f} ms per generate')
+    value = world * rows * new * args.steps / elapsed
+
+    result = {
+        'metric': 'acoustic tokens/sec (AR decode)', 'value': value, 'unit': 'tokens/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'configs[1]: 12-layer/512-dim AR decoder greedy generate, batch 32, '
+                               '1024-token prompt -> 512 new tokens, 1xMI355X per rank'
+                               if not args.small else 'SMALL functional check (not the metric)',
+                   'rows_per_gpu': rows, 'prompt_tokens': text + frames + 1, 'new_tokens': new,
+                   'layers': cfg.num_layers, 'd_model': cfg.d_model, 'sharding': f'utterance-batch x{world}',
+                   'timed_region': 'embed + prefill + (new-1) hipGraph-replayed decode steps'},
+    }
+
+    l_pl = 4 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.dim_feedforward   # matmul weights per layer
+    if rank == 0 and not args.no_roofline:
+        # dominant kernel: decode attention (KV streaming).  HIP events on the launch stream around
+        # every launch of an eager (non-graph) pass over the same 511 steps.
+        log('roofline: event-timed eager pass')
+        model.generate_batch(texts, firsts, profile_attn=True)
+        torch.cuda.synchronize()
+        st = model.last_generate_stats
+        bytes_per_launch, mean_s = attn_algorithmic_bytes(rows, cfg.d_model, st['s0'], new)
+        dur_s = st['attn_mean_ms'] * 1e-3
+        achieved = bytes_per_launch / dur_s / 1e9
+        result['roofline'] = {
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'kernel': 'attn_decode_kernel', 'launches': (new - 1) * cfg.num_layers,
+            'avg_launch_us': dur_s * 1e6, 'algorithmic_bytes_per_launch': bytes_per_launch,
+            'mean_context': mean_s,
+            'note': 'traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by separate rocprofv3 --pmc '
+                    'passes; see profiles/'}
+        # whole-step view of the same roofline: all algorithmic bytes of the decode steps
+        step_elems = [cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
+                      + 2 * cfg.num_layers * rows * (st['s0'] + t) * cfg.d_model
+                      + 2 * cfg.num_layers * rows * cfg.d_model for t in range(1, new)]
+        result['roofline']['decode_algorithmic_bytes_total'] = 4.0 * sum(step_elems)
+
+    if rank == 0 and world == 1 and not args.no_nar and not args.small:
+        log('nar: one stage forward of configs[2]')
+        ncfg = ConfigValle(**dict(AR, norm='AdaptiveLayerNorm'))
+        nsd = synth.make_state_dict(ncfg, 'ValleNAR', seed=0, rich=True)
+        nar = get_model_class('ValleNAR')(ncfg)
+        nar.load_state_dict(nsd)
+        nar = nar.to(dev).eval()
+        nb = synth.synth_nar_batch(ncfg, NAR_B, NAR_TEXT, NAR_FRAMES, seed=1234)
+        nb = {k: v.to(dev) for k, v in nb.items()}
+        nar.stage_logits(nb, 3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for i in range(reps):
+            nar.stage_logits(nb, 1 + i)
+        torch.cuda.synchronize()
+        t_stage = (time.perf_counter() - t0) / reps
+        s = NAR_TEXT + NAR_FRAMES
+        flop = (2 * 12 * l_pl * NAR_B * s + 4 * 512 * s * s * 12 * NAR_B
+                + 2 * 512 * 1024 * NAR_B * (NAR_FRAMES - 150))
+        result['nar'] = {'metric': 'NAR fwd tokens/sec (one stage, configs[2])',
+                         'value': NAR_B * s / t_stage, 'unit': 'tokens/s', 'ms_per_stage': t_stage * 1e3,
+                         'tflops': flop / t_stage / 1e12, 'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
+                         'frac_of_mfma_peak': flop / t_stage / 1e12 / MFMA_F32_PEAK_TF}
+        del nar, nb
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # same model, same first utterance, all `rows` beams, on the host cores of this box
+        result['cpu_baseline'] = cpu_baseline(ar_kw, sd, utts[0], rows, new)
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,167 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol the header declares, the
+host-side mirror keeps the reference's contracts (config, registry, mask builders, state_dict
+keys), and the product refuses to compute without a HIP device (no silent CPU fallback)."""
+import json
+import re
+from pathlib import Path
+
+import pytest
+import torch
+
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    from valle2_amd import _lib
+    lib = _lib.load_library()
+    header = (REPO / 'include' / 'valle_hip.h').read_text()
+    declared = set(re.findall(r'\b(vh_[a-z0-9_]+)\s*\(', header)) - {'vh_ar_decoder'}
+    assert declared, 'no declarations parsed'
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in include/valle_hip.h but not exported'
+    assert lib.vh_version() == 100
+    assert int(re.search(r'#define VH_VERSION (\d+)', header).group(1)) == lib.vh_version()
+
+
+def test_no_cpu_fallback_anywhere():
+    from valle2_amd import _lib
+    from valle2_amd.modules import FeedForward, MultiHeadAttention, TokenEmbedding, Transformer
+    from valle2_amd.config import ConfigValle
+    if torch.cuda.is_available():
+        pytest.skip('box has a GPU')
+    with pytest.raises(_lib.VhError):
+        _lib.lib()
+    x = torch.randn(2, 5, 128)
+    for mod, arg in ((MultiHeadAttention(128, 2), x), (FeedForward(128, 256), x),
+                     (TokenEmbedding(10, 128), torch.zeros(2, 3, dtype=torch.int64)),
+                     (Transformer(ConfigValle(d_model=128, n_heads=2, num_layers=1)), x)):
+        with pytest.raises(_lib.VhError):
+            mod(arg)
+
+
+def test_product_never_imports_the_oracle():
+    for path in list((REPO / 'valle2_amd').rglob('*.py')) + list((REPO / 'valle').rglob('*.py')):
+        text = path.read_text()
+        assert not re.search(r'^\s*(from|import)\s+oracle\b', text, re.M), f'{path} imports oracle/'
+        assert 'valle_oracle' not in text, f'{path} mentions the oracle module'
+
+
+def test_config_contract():
+    from valle2_amd.config import ConfigValle
+    c = ConfigValle()
+    assert (c.vocab_size, c.num_audio_tokens, c.num_quantizers, c.d_model, c.n_heads) == (256, 1024, 8, 256, 4)
+    assert (c.dim_feedforward, c.num_layers, c.norm, c.activation) == (1024, 8, 'AdaptiveLayerNorm', 'relu')
+    assert (c.max_audio_len, c.num_beams, c.use_kv_cache, c.top_k, c.tok_p) == (1024, 4, True, 50, 1.0)
+    assert c.betas == (0.9, 0.98) and c.lr == 1e-4 and c.weight_decay == 0.1 and c.lr_warmup == 1000
+    assert c.quantization_factor == 50 and c.eos_token == 1024 and c.bos_token == 1025
+    assert Path('models/checkpoints').is_dir() and Path('models/logs').is_dir()   # reference side effect
+    for bad in (dict(norm='RMSNorm'), dict(activation='swish'), dict(dataset=None)):
+        with pytest.raises(ValueError):
+            ConfigValle(**bad)
+    Path('hp.json').write_text(json.dumps({'d_model': 128, 'n_heads': 2, 'norm': 'LayerNorm'}))
+    assert ConfigValle.from_json('hp.json').d_model == 128
+    assert ConfigValle.from_dict({'num_layers': 3}).num_layers == 3
+    with pytest.raises(TypeError):
+        ConfigValle(no_such_field=1)
+
+
+def test_reference_import_paths_and_registry():
+    import valle.config
+    import valle.models
+    import valle.models.modules as mods
+    import valle.models.utils as utils
+    from valle.models import MODEL_DICT, get_model_class
+    assert get_model_class('ValleAR').__name__ == 'ValleAR'
+    assert get_model_class('ValleNAR').__name__ == 'ValleNAR'
+    assert set(MODEL_DICT.keys()) == {'EncodecPip', 'ValleAR', 'ValleNAR'}
+    with pytest.raises(ImportError):
+        get_model_class('EncodecPip')
+    for name in ('TokenEmbedding', 'PositionalEncoding', 'AdaptiveLayerNorm', 'MultiHeadAttention',
+                 'FeedForward', 'EncoderLayer', 'Transformer'):
+        assert hasattr(mods, name)
+    for name in ('build_pad_mask', 'build_attn_mask', 'topk_sampling', 'get_best_beam'):
+        assert hasattr(utils, name)
+
+
+# ---- the reference's own CPU tests on mask plumbing (tests/test_models_utils.py:7-59,
+# ---- tests/test_modules.py:33-79), same literals
+def test_build_attn_mask_literal():
+    from valle.models.utils import build_attn_mask
+    expected = torch.tensor(
+        [[0, 0, 0, 0, 0, 1, 1, 1, 1, 1]] * 5 +
+        [[0, 0, 0, 0, 0, 0, 1, 1, 1, 1], [0, 0, 0, 0, 0, 0, 0, 1, 1, 1], [0, 0, 0, 0, 0, 0, 0, 0, 1, 1],
+         [0, 0, 0, 0, 0, 0, 0, 0, 0, 1], [0, 0, 0, 0, 0, 0, 0, 0, 0, 0]], dtype=torch.bool)
+    mask = build_attn_mask(5, 5, device='cpu')
+    assert mask.shape == expected.shape and torch.equal(mask, expected)
+
+
+@pytest.mark.parametrize('lens,expected', [
+    (torch.tensor([5, 5, 5, 5]), torch.zeros(4, 5, dtype=torch.bool)),
+    (torch.tensor([5, 4, 3, 2]), torch.tensor([[0, 0, 0, 0, 0], [0, 0, 0, 0, 1], [0, 0, 0, 1, 1],
+                                               [0, 0, 1, 1, 1]], dtype=torch.bool))])
+def test_build_pad_mask_literal(lens, expected):
+    from valle.models.utils import build_pad_mask
+    mask = build_pad_mask(lens, device='cpu')
+    assert mask.shape == expected.shape and torch.equal(mask, expected)
+
+
+@pytest.mark.parametrize('d_model,n_heads,batch_size,seq_len,expected', [
+    (512, 8, 4, 5, [120, 112, 96, 72]),
+    (256, 4, 8, 10, [220, 216, 208, 196, 180, 160, 136, 108])])
+def test_merge_masks_zero_counts(d_model, n_heads, batch_size, seq_len, expected):
+    from valle.models.modules import MultiHeadAttention
+    attention = MultiHeadAttention(d_model=d_model, n_heads=n_heads)
+    pad = (torch.arange(seq_len)[None, :] >= (seq_len - torch.arange(batch_size))[:, None]).long()
+    attn_mask = torch.triu(torch.ones(seq_len, seq_len), diagonal=1)
+    mask = attention.merge_masks(batch_size, attn_mask, pad)
+    assert isinstance(mask, torch.Tensor) and mask.shape == (batch_size, n_heads, seq_len, seq_len)
+    assert [(mask[i] == 0.0).sum().item() for i in range(batch_size)] == expected
+    assert attention.merge_masks(batch_size, None, pad) is None
+
+
+def test_masks_match_golden_and_oracle():
+    from tests.oracle_runners import load_golden
+    from valle2_amd.utils import build_attn_mask, build_pad_mask
+    gold = load_golden('masks')
+    assert torch.equal(build_attn_mask(5, 5, 'cpu'), gold['attn_5_5'])
+    assert torch.equal(build_attn_mask(3, 7, 'cpu'), gold['attn_3_7'])
+    assert torch.equal(build_pad_mask(torch.tensor([5, 4, 3, 2]), 'cpu'), gold['pad_b'])
+    assert build_attn_mask(3, 7, 'cpu')._vh_prefix == (3, 7)
+
+
+def test_state_dict_keys_match_reference_layout():
+    from valle2_amd import get_model_class, synth
+    from valle2_amd.config import ConfigValle
+    for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm'), ('ValleNAR', 'LayerNorm')):
+        cfg = ConfigValle(d_model=128, n_heads=2, dim_feedforward=256, num_layers=2, norm=norm)
+        model = get_model_class(name)(cfg)
+        sd = model.state_dict()
+        shapes = synth.state_dict_shapes(cfg, name)
+        assert set(sd) == set(shapes), set(sd) ^ set(shapes)
+        for k, shp in shapes.items():
+            assert tuple(sd[k].shape) == tuple(shp), k
+        model.load_state_dict(synth.make_state_dict(cfg, name, seed=0))    # strict load
+    n_ar = sum(p.numel() for p in get_model_class('ValleAR')(
+        ConfigValle(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, norm='LayerNorm')).parameters())
+    assert n_ar == 691072          # verified against the reference
+
+
+def test_get_best_beam_and_sampling_contract():
+    from tests.oracle_runners import load_golden
+    from valle2_amd.utils import get_best_beam, topk_sampling
+    from tests.golden.cases import sampling_inputs
+    gold = load_golden('sampling')
+    _, x, lp = sampling_inputs()
+    assert torch.equal(get_best_beam(x, lp, 1024, 1.0), gold['best_beam_1'])
+    assert torch.equal(get_best_beam(x, lp, 1024, 0.0), gold['best_beam_2'])
+    from valle2_amd import _lib
+    with pytest.raises(_lib.VhError):
+        topk_sampling(torch.randn(2, 10), top_k=1)          # CPU logits: no fallback
+
+
+def test_bench_byte_accounting():
+    import bench
+    b, mean_s = bench.attn_algorithmic_bytes(32, 512, 1024, 512)
+    assert abs(mean_s - (1024 + 256)) < 1e-9
+    assert b == 4.0 * (2 * 32 * 1280 * 512 + 2 * 32 * 512)

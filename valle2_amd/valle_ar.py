@@ -122,11 +122,13 @@ class ValleAR(_Base):
         return best[best != self.eos_token]
 
     @torch.inference_mode()
-    def generate_batch(self, texts, first_codes, max_new=None, use_graph=True):
+    def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False):
         """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
         texts[b]: 1-D int64 text ids; first_codes[b]: 1-D int64 first-codebook prompt (no BOS).
         All rows must currently share their lengths.  Returns codes (B, prompt_len + n_new) int64
-        (BOS + prompt + generated, finished rows padded with EOS), on the device."""
+        (BOS + prompt + generated, finished rows padded with EOS), on the device.
+        profile_attn=True runs the steps eagerly with HIP events around every decode-attention
+        launch and leaves their mean duration in `last_generate_stats` (measurement only)."""
         self._require_layernorm()
         cfg = self.config
         if cfg.top_k != 1:
@@ -168,6 +170,10 @@ class ValleAR(_Base):
             del x
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
             done, stop = 1, None
+            attn_ms = None
+            if profile_attn and max_new > 1:
+                attn_ms = dec.profile_attn(max_new - 1)
+                done = max_new
             while done < max_new:
                 n = min(EOS_POLL, max_new - done)
                 dec.run(n)
@@ -180,8 +186,8 @@ class ValleAR(_Base):
                 full = (dec.eos_count[:done] == B).nonzero()
                 stop = int(full[0]) if full.numel() else None
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
-            self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split}
-            self._last_decoder = None
+            self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
+                                        'attn_mean_ms': attn_ms, 's0': s0}
             return codes[:, : prompt_len + n_new].clone()
         finally:
             dec.close()
