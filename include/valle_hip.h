@@ -51,6 +51,13 @@ enum {
 int vh_version(void);
 const char* vh_last_error(void);
 
+/* Kernel-selection knobs for benchmarking A/B runs in one process (0 = built-in default).
+ * Results are identical up to fp32 summation order whatever the setting. */
+enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16-key pipelined */
+       VH_TUNE_DECODE_WAVES = 1,    /* waves per decode-attention workgroup: 4, 8 or 16 */
+       VH_TUNE_COUNT = 8 };
+int vh_set_tuning(int knob, int value);
+
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------
  * replaces TokenEmbedding.forward + PositionalEncoding.forward (valle/models/modules.py:33-37,
  * 78-80) and the 8-codebook sum of ValleNAR._prepare_audio_codes (valle/models/valle_nar.py:
@@ -82,6 +89,16 @@ int vh_linear(const float* A, int lda, const float* W, const float* bias, const 
               int ldr, float* out, int ldo, int M, int N, int K, int act, const float* ln_gamma,
               const float* ln_beta, const float* ada_scale, const float* ada_shift, float ln_eps,
               void* stream);
+
+/* Same contract as vh_linear without the fused LayerNorm, plus a caller-owned workspace of
+ * vh_linear_ws_bytes(M,N,K) bytes: for M <= 64 and K > 1024 (linear_2, K = dim_feedforward) the K
+ * range is split over ~256 workgroups whose partial sums meet in the workspace and are added in a
+ * fixed order by a second small kernel (bitwise reproducible; no atomics).  Falls back to
+ * vh_linear when the shape does not split or workspace == NULL. */
+size_t vh_linear_ws_bytes(int M, int N, int K);
+int vh_linear_ws(const float* A, int lda, const float* W, const float* bias, const float* residual,
+                 int ldr, float* out, int ldo, int M, int N, int K, int act, void* workspace,
+                 size_t workspace_bytes, void* stream);
 
 /* ---- K5+K6: QKV projection with the K/V rows appended in place to the cache -----------------
  * replaces qkv Linear + chunk + rearrange + torch.cat cache growth (valle/models/modules.py:
@@ -152,6 +169,8 @@ typedef struct {
     float *x;                         /* (B,d) residual stream, holds the current token's embedding */
     float *q, *attn, *hidden, *logits;/* (B,d) (B,d) (B,dff) (B,ldl) scratch; ldl = round_up(V,4) */
     void *attn_partial;               /* vh_attn_decode_ws_bytes() or NULL when n_split == 1 */
+    void *gemm_ws;                    /* vh_linear_ws_bytes(B, d_model, dff) bytes or NULL */
+    size_t gemm_ws_bytes;
     int32_t *cache_len, *audio_pos, *eos_count;
     const int32_t *pos_base;          /* (B) or NULL */
     int64_t *codes;                   /* (B, codes_stride) growing code sequence */

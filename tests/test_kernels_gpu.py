@@ -50,6 +50,26 @@ def test_linear_tile_integer_exact(K, M, N, K_):
     assert torch.equal(out.cpu(), a @ w.T)
 
 
+@pytest.mark.parametrize('M,N,K_', [(32, 512, 2048), (16, 512, 2048), (4, 1024, 4096), (33, 100, 1280),
+                                    (32, 512, 512), (8, 48, 3072)])
+def test_linear_splitk_workspace_path(K, M, N, K_):
+    # wide-K split-K + fixed-order reduce: integer data exact; random data with the full epilogue
+    a = torch.randint(-3, 4, (M, K_), generator=g(80)).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g(81)).float()
+    w[:, 2] += torch.arange(N).float() % 5
+    assert torch.equal(K.linear_ws(a.to(DEV), w.to(DEV)).cpu(), a @ w.T)
+    a = torch.randn(M, K_, generator=g(82))
+    w = 0.05 * torch.randn(N, K_, generator=g(83))
+    bias, res = torch.randn(N, generator=g(84)), torch.randn(M, N, generator=g(85))
+    resd = res.to(DEV)
+    out = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV), resd, out=resd, act=1)
+    close(out, F.gelu(F.linear(a, w, bias)) + res, atol=5e-5)
+    # bitwise reproducible (fixed-order reduction, no atomics)
+    o1 = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV))
+    o2 = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV))
+    assert torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize('M', [7, 32, 200])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_epilogues(K, M, act):

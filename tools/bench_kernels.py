@@ -1,0 +1,152 @@
+"""Kernel-level A/B timings in ONE process (interleaved rounds, median), for tuning only.
+usage: python tools/bench_kernels.py [attn] [gemm] [rows]"""
+import statistics
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from valle2_amd import _lib, kernels as K  # noqa: E402
+
+DEV = 'cuda'
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3   # us
+
+
+def flush_cache(buf):
+    buf.add_(1.0)    # touch 1 GiB so L2 / Infinity Cache hold none of the operands
+
+
+def bench_attn():
+    B, h, S_max = 32, 8, 1536
+    q = torch.randn(B, 512, device=DEV)
+    out = torch.empty(B, 512, device=DEV)
+    # 12 layers of cache so successive launches stream different memory, as in the decode step
+    caches = [(torch.randn(B, h, S_max, 64, device=DEV), torch.randn(B, h, S_max, 64, device=DEV))
+              for _ in range(12)]
+    lib = _lib.lib()
+    for S in (1024, 1280, 1536):
+        cl = torch.full((B,), S - 1, device=DEV, dtype=torch.int32)
+        bytes_ = 2 * B * S * 512 * 4
+        res = {}
+        for rnd in range(3):
+            for variant in (1, 2):
+                for waves in (4, 8, 16):
+                    for ns in (1, 2, 4):
+                        if waves == 16 and ns > 1 or waves == 4 and ns == 1:
+                            continue
+                        lib.vh_set_tuning(0, variant)
+                        lib.vh_set_tuning(1, waves)
+                        ws = K.attn_decode_ws(B, h, ns, DEV)
+                        i = [0]
+
+                        def fn():
+                            kc, vc = caches[i[0] % 12]
+                            i[0] += 1
+                            K.attn_decode(q, kc, vc, out, cl, 1, ns, ws)
+                        res.setdefault((variant, waves, ns), []).append(timeit(fn, iters=48))
+        for k, v in sorted(res.items(), key=lambda kv: statistics.median(kv[1])):
+            us = statistics.median(v)
+            print(f'attn S={S} variant={k[0]} waves={k[1]} n_split={k[2]}: {us:7.2f} us  '
+                  f'{bytes_ / us / 1e3:7.1f} GB/s', flush=True)
+    lib.vh_set_tuning(0, 0)
+    lib.vh_set_tuning(1, 0)
+
+
+def bench_gemm():
+    B, d, dff = 32, 512, 2048
+    x = torch.randn(B, d, device=DEV)
+    hid = torch.randn(B, dff, device=DEV)
+    g, b = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    L = 12
+    wqkv = [0.02 * torch.randn(3 * d, d, device=DEV) for _ in range(L)]
+    wo = [0.02 * torch.randn(d, d, device=DEV) for _ in range(L)]
+    w1 = [0.02 * torch.randn(dff, d, device=DEV) for _ in range(L)]
+    w2 = [0.02 * torch.randn(d, dff, device=DEV) for _ in range(L)]
+    bo, b1 = torch.zeros(d, device=DEV), torch.zeros(dff, device=DEV)
+    kc = torch.zeros(B, 8, 64, 64, device=DEV)
+    vc = torch.zeros_like(kc)
+    q = torch.empty(B, d, device=DEV)
+    o1 = torch.empty(B, d, device=DEV)
+    o2 = torch.empty(B, dff, device=DEV)
+    cl = torch.zeros(B, device=DEV, dtype=torch.int32)
+    big = torch.zeros(256 * 1024 * 1024 // 4, device=DEV)
+    ln = (g, b, None, None, 1e-5)
+    ws2 = torch.empty(_lib.lib().vh_linear_ws_bytes(B, d, dff) // 4, device=DEV)
+    i = [0]
+
+    def nxt():
+        i[0] += 1
+        return i[0] % L
+    cases = {
+        'qkv+ln   (N=1536,K=512)': lambda: K.linear_qkv(x, wqkv[nxt()], q, kc, vc, B, 1, 8, cache_len=cl, ln=ln),
+        'out-proj (N=512,K=512)': lambda: K.linear(x, wo[nxt()], bo, o1, out=o1),
+        'ffn1+ln  (N=2048,K=512)': lambda: K.linear(x, w1[nxt()], b1, out=o2, act=1, ln=ln),
+        'ffn2     (N=512,K=2048)': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
+        'ffn2-splitk (N=512,K=2048)': lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2),
+    }
+    # graph-captured so the Python/ctypes launch cost is out of the picture
+    for name, fn in cases.items():
+        fn()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for _ in range(L):
+                fn()
+        res = {}
+        for mode in ('cold', 'warm'):
+            ts = []
+            for rnd in range(7):
+                if mode == 'cold':
+                    flush_cache(big)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                graph.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / L * 1e3)
+            res[mode] = statistics.median(ts)
+        print(f'gemm {name}: cold {res["cold"]:6.2f} us  warm {res["warm"]:6.2f} us (per launch, 12 weight sets)',
+              flush=True)
+
+
+def bench_rows():
+    B, T, d, dff, h = 32, 1024, 512, 2048, 8
+    M = B * T
+    x = torch.randn(M, d, device=DEV)
+    for name, N, Kk in (('qkv', 1536, 512), ('out', 512, 512), ('ffn1', 2048, 512), ('ffn2', 512, 2048)):
+        a = torch.randn(M, Kk, device=DEV)
+        w = 0.02 * torch.randn(N, Kk, device=DEV)
+        o = torch.empty(M, N, device=DEV)
+        us = timeit(lambda: K.linear(a, w, out=o), iters=10, warm=2)
+        print(f'tile gemm {name} M={M} N={N} K={Kk}: {us:8.1f} us  {2 * M * N * Kk / us / 1e6:6.1f} TFLOP/s', flush=True)
+    q = torch.randn(M, d, device=DEV)
+    kc = torch.randn(B, h, T, 64, device=DEV)
+    vc = torch.randn(B, h, T, 64, device=DEV)
+    o = torch.empty(M, d, device=DEV)
+    for mode, xl in ((K.MASK_PREFIX, 256), (K.MASK_FULL, 0)):
+        us = timeit(lambda: K.attn_rows(q, kc, vc, o, B, h, T, T, mode=mode, x_len=xl), iters=10, warm=2)
+        pairs = (xl * xl + (T - xl) * xl + (T - xl) * (T - xl + 1) // 2) if mode == K.MASK_PREFIX else T * T
+        print(f'attn_rows mode={mode}: {us:8.1f} us  {4 * 64 * pairs * B * h / us / 1e6:6.1f} TFLOP/s (visible pairs)',
+              flush=True)
+
+
+if __name__ == '__main__':
+    what = sys.argv[1:] or ['attn', 'gemm', 'rows']
+    if 'gemm' in what:
+        bench_gemm()
+    if 'attn' in what:
+        bench_attn()
+    if 'rows' in what:
+        bench_rows()

@@ -38,7 +38,8 @@ class VhArDecoderDesc(C.Structure):
         ('layers', C.POINTER(VhLayer)),
         ('proj_w', C.c_void_p), ('audio_emb', C.c_void_p), ('audio_pe', C.c_void_p),
         ('x', C.c_void_p), ('q', C.c_void_p), ('attn', C.c_void_p), ('hidden', C.c_void_p),
-        ('logits', C.c_void_p), ('attn_partial', C.c_void_p),
+        ('logits', C.c_void_p), ('attn_partial', C.c_void_p), ('gemm_ws', C.c_void_p),
+        ('gemm_ws_bytes', C.c_size_t),
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
     ]
@@ -60,6 +61,7 @@ class VhForwardDesc(C.Structure):
 SIGNATURES = {
     'vh_version': (C.c_int, []),
     'vh_last_error': (C.c_char_p, []),
+    'vh_set_tuning': (C.c_int, [C.c_int, C.c_int]),
     'vh_embed_sum_pe': (C.c_int, [c_i64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
                                   C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -68,6 +70,9 @@ SIGNATURES = {
     'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
                             C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                             C.c_float, C.c_void_p]),
+    'vh_linear_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_linear_ws': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'vh_linear_qkv': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_i32p,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                 c_f32p, C.c_float, C.c_void_p]),

@@ -113,6 +113,109 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     }
 }
 
+// Pipelined variant: 16-key chunks, two named register sets (A/B): the loads of chunk c+NW are in
+// flight while chunk c is reduced, so the wave never idles between a burst and its use.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ kc,
+    const float* __restrict__ vc, float* __restrict__ out, int ldo,
+    const int32_t* __restrict__ cache_len, int len_bias, int n_heads, int S_max, int n_split,
+    float* __restrict__ partial) {
+    __shared__ float s_m[NW], s_l[NW];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
+    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int len = cache_len[b] + len_bias;
+    const int nchunks = (len + 15) >> 4;
+    const int cps = (nchunks + n_split - 1) / n_split;
+    const int c_begin = split * cps;
+    const int c_end = min(nchunks, c_begin + cps);
+
+    const float qscale = 0.125f * LOG2E;
+    const f32x4 q4 = ld4(q + (int64_t)b * ldq + head * HD + 4 * c16) * qscale;
+    const float* kb = kc + (int64_t)bh * S_max * HD + 4 * c16;
+    const float* vb = vc + (int64_t)bh * S_max * HD + 4 * c16;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    float m = NEG_INF, l = 0.f;
+    f32x4 o = zero4;
+    f32x4 kA[4], vA[4], kB[4], vB[4];
+    auto load = [&](int c, f32x4 (&kf)[4], f32x4 (&vf)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = c * 16 + g + 4 * i;
+            const bool in = c < c_end && key < len;
+            kf[i] = in ? ld4(kb + (int64_t)key * HD) : zero4;
+            vf[i] = in ? ld4(vb + (int64_t)key * HD) : zero4;
+        }
+    };
+    auto reduce = [&](int c, const f32x4 (&kf)[4], const f32x4 (&vf)[4]) {
+        float s[4];
+        float cmax = NEG_INF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 t = kf[i] * q4;
+            const float d = row16_sum((t.x + t.y) + (t.z + t.w));
+            s[i] = (c * 16 + g + 4 * i < len) ? d : NEG_INF;
+            cmax = fmaxf(cmax, s[i]);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m, cmax);
+        const float alpha = exp2f(m - m_new);
+        o *= alpha;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float p = exp2f(s[i] - m_new);
+            l += p;
+            o += vf[i] * p;
+        }
+        m = m_new;
+    };
+    int c = c_begin + w;
+    load(c, kA, vA);
+    while (c < c_end) {
+        load(c + NW, kB, vB);
+        reduce(c, kA, vA);
+        c += NW;
+        if (c >= c_end) break;
+        load(c + NW, kA, vA);
+        reduce(c, kB, vB);
+        c += NW;
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        o.x += __shfl_xor(o.x, sh, 64); o.y += __shfl_xor(o.y, sh, 64);
+        o.z += __shfl_xor(o.z, sh, 64); o.w += __shfl_xor(o.w, sh, 64);
+        l += __shfl_xor(l, sh, 64);
+    }
+    if (lane < 16) st4(&s_o[w][4 * c16], o);
+    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
+    __syncthreads();
+    if (tid < HD) {
+        float M = s_m[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const float wgt = s_m[k] == NEG_INF ? 0.f : exp2f(s_m[k] - M);
+            L += s_l[k] * wgt;
+            O += s_o[k][tid] * wgt;
+        }
+        if (n_split == 1) {
+            out[(int64_t)b * ldo + head * HD + tid] = O / L;
+        } else {
+            float* pr = partial + ((int64_t)bh * n_split + split) * PART_LD;
+            pr[tid] = O;
+            if (tid == 0) { pr[HD] = M; pr[HD + 1] = L; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(
     const float* __restrict__ partial, float* __restrict__ out, int ldo, int n_heads, int n_split) {
     const int bh = blockIdx.x, b = bh / n_heads, head = bh - b * n_heads;
@@ -150,12 +253,21 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(n_split, B * n_heads);
     // few workgroups → 16 waves each (one (b,head) can own a whole CU); many → 4 waves each
-    if ((int64_t)B * n_heads * n_split >= 1024)
-        hipLaunchKernelGGL(attn_decode_kernel<4>, grid, dim3(256), 0, s, q, ldq, kcache, vcache, out,
-                           ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial);
-    else
-        hipLaunchKernelGGL(attn_decode_kernel<16>, grid, dim3(1024), 0, s, q, ldq, kcache, vcache,
-                           out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial);
+    const bool big = (int64_t)B * n_heads * n_split < 1024;
+#define AD(KERN, NW)                                                                               \
+    hipLaunchKernelGGL(KERN<NW>, grid, dim3(NW * 64), 0, s, q, ldq, kcache, vcache, out, ldo,      \
+                       cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
+    const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
+    const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
+    const int waves = nw ? nw : (big ? 16 : 4);
+    if (variant != 2) {
+        if (waves == 16) AD(attn_decode_kernel, 16); else if (waves == 8) AD(attn_decode_kernel, 8);
+        else AD(attn_decode_kernel, 4);
+    } else {
+        if (waves == 16) AD(attn_decode_pipe_kernel, 16); else if (waves == 8) AD(attn_decode_pipe_kernel, 8);
+        else AD(attn_decode_pipe_kernel, 4);
+    }
+#undef AD
     if (n_split > 1)
         hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(B * n_heads), dim3(64), 0, s,
                            (const float*)partial, out, ldo, n_heads, n_split);
@@ -177,6 +289,7 @@ struct RowsArgs {
     int n_heads, Tq, Tk, S_max, mode, x_len;
     const int32_t* x_len_dev; const int32_t* kv_len;
     const uint8_t* mask; const uint8_t* pad;
+    int n_qblocks;
 };
 
 __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
@@ -184,8 +297,13 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KLD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int bh = blockIdx.y, b = bh / a.n_heads, head = bh - b * a.n_heads;
-    const int q0 = blockIdx.x * QB;
+    // 1-D grid, heaviest query blocks first: under the causal/prefix mask the last query block of
+    // a head visits up to 4x the key tiles of the first, and with only ~4 workgroups per CU slot a
+    // heavy block dispatched late becomes the tail.  id % (B*h) is the (b,head), so workgroups that
+    // share an XCD (ids b, b+8, ...) still see every query block: no XCD gets only heavy ones.
+    const int n_bh = gridDim.x / a.n_qblocks;
+    const int bh = blockIdx.x % n_bh, b = bh / a.n_heads, head = bh - b * a.n_heads;
+    const int q0 = (a.n_qblocks - 1 - (int)(blockIdx.x / n_bh)) * QB;
     const int q_off = a.Tk - a.Tq;
     const int kvl = a.kv_len ? min(a.kv_len[b], a.Tk) : a.Tk;
     const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
@@ -353,9 +471,10 @@ extern "C" int vh_attn_rows(const float* q, int ldq, const float* kcache, const 
     VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(out),
                VH_EALIGN, "vh_attn_rows: pointers must be 16-byte aligned");
     if (B == 0 || Tq == 0) return VH_OK;
+    const int nqb = (Tq + QB - 1) / QB;
     RowsArgs a{q, ldq, kcache, vcache, out, ldo, n_heads, Tq, Tk, S_max, mode, x_len,
-               x_len_dev, kv_len, mask, pad};
-    dim3 grid((Tq + QB - 1) / QB, B * n_heads);
+               x_len_dev, kv_len, mask, pad, nqb};
+    dim3 grid(nqb * B * n_heads);
     hipLaunchKernelGGL(attn_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     VH_CHECK_LAUNCH("vh_attn_rows");
     return VH_OK;

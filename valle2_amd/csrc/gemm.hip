@@ -32,14 +32,32 @@ struct GemmArgs {
     float* vc;
     const int32_t* cache_len;
     int T, S_max, d_model, n_heads;
+    int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
+#ifdef VH_STAMPS
+    long long* dbg;  // diagnostic build only (tools/probe_skinny.hip): per-wave phase stamps
+#endif
 };
 
-enum { EPI_PLAIN = 0, EPI_QKV = 1 };
+#ifdef VH_STAMPS
+#define STAMP(k)                                                                         \
+    do {                                                                                 \
+        if (a.dbg && (threadIdx.x & 63) == 0)                                            \
+            a.dbg[((int64_t)blockIdx.x * 16 + (threadIdx.x >> 6)) * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2 };
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
 template <int EPI>
 __device__ __forceinline__ void store4(const GemmArgs& a, int m, int n, f32x4 v) {
     if (m >= a.M || n >= a.N) return;
+    if (EPI == EPI_PARTIAL) {  // raw partial sums of K-slice blockIdx.y → slab [split][M][ldo]
+        st4(a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + n, v);
+        return;
+    }
     if (EPI == EPI_QKV) {
         const int which = n / a.d_model, c = n - which * a.d_model;
         if (which == 0) {
@@ -191,78 +209,135 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 
 // =============================================================================================
 // Skinny kernel: M <= 16*MT rows.  Block = NW waves, owns 16 output columns n0..n0+15 over all K.
-// wave w takes k-steps of 16 (w, w+NW, ...).  lane: i = l&15 (W row / activation row), g = l>>4.
+// wave w owns a contiguous run of k-steps of 16; lane: i = l&15 (W row / activation row), g = l>>4.
+//
+// The kernel is latency-bound (a few KB per wave), so it is written around ONE memory round trip:
+//   1. issue every operand load of the wave's first chunk (CH k-steps: W from HBM, x/gamma/beta
+//      from L2) before anything else;
+//   2. while those are in flight compute the LayerNorm row statistics from a register-resident
+//      copy of the rows (single read, two-pass mean / centred variance), publish through LDS;
+//   3. normalise the activation fragments in registers, run the MFMAs, reduce over waves in LDS
+//      (fixed order → bitwise reproducible), fused epilogue.
 // =============================================================================================
-template <int MT, int NW, int EPI>
+template <int MT, int NW, int EPI, int CH, bool LN>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse ln) {
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
-
-    if (ln.gamma) {  // row statistics of the M activation rows (two-pass, fp32)
-        for (int row = w; row < a.M; row += NW) {
-            const float* xr = a.A + (int64_t)row * a.lda;
-            float s = 0.f;
-            for (int c = lane * 4; c < a.K; c += 256) {
-                const f32x4 v = ld4(xr + c);
-                s += (v.x + v.y) + (v.z + v.w);
-            }
-            const float mean = wave_sum(s) / (float)a.K;
-            float ss = 0.f;
-            for (int c = lane * 4; c < a.K; c += 256) {
-                const f32x4 v = ld4(xr + c) - mean;
-                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-            }
-            const float var = wave_sum(ss) / (float)a.K;
-            if (lane == 0) { s_mean[row] = mean; s_rstd[row] = rsqrtf(var + ln.eps); }
-        }
-        __syncthreads();
-    }
-
-    f32x4 acc[MT];
-    float mean[MT], rstd[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int row = mt * 16 + i;
-        mean[mt] = (ln.gamma && row < a.M) ? s_mean[row] : 0.f;
-        rstd[mt] = (ln.gamma && row < a.M) ? s_rstd[row] : 0.f;
-    }
+    const int nks = a.K / 16;
+    const int per_wave = (nks + NW - 1) / NW;
+    const int ks0 = w * per_wave, ks1 = min(nks, ks0 + per_wave);
     const bool nin = n0 + i < a.N;
     const float* wrow = a.W + (int64_t)(n0 + i) * a.K + 4 * g;
-    const int nks = a.K / 16;
-    for (int ks = w; ks < nks; ks += NW) {
-        const int k = ks * 16;
-        const f32x4 wf = nin ? ld4(wrow + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 xf[MT];
+    const float* xrow[MT];
+    bool min_[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int row = mt * 16 + i;
-            xf[mt] = row < a.M ? ld4(a.A + (int64_t)row * a.lda + k + 4 * g)
-                               : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-        if (ln.gamma) {
-            const f32x4 gm = ld4(ln.gamma + k + 4 * g), bt = ld4(ln.beta + k + 4 * g);
+    for (int mt = 0; mt < MT; ++mt) {
+        min_[mt] = mt * 16 + i < a.M;
+        xrow[mt] = a.A + (int64_t)(mt * 16 + i) * a.lda + 4 * g;
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 wf[CH], xf[CH][MT], gm[CH], bt[CH];
+    auto issue = [&](int base) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                xf[mt] = (xf[mt] - mean[mt]) * rstd[mt] * gm + bt;
-                if (ln.ada_scale)
-                    xf[mt] = ld4(ln.ada_scale + k + 4 * g) * xf[mt] + ld4(ln.ada_shift + k + 4 * g);
-                if (mt * 16 + i >= a.M) xf[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < CH; ++c) {
+            const int ks = base + c;
+            const bool kin = ks < ks1;
+            const int k = ks * 16;
+            wf[c] = (kin && nin) ? ld4(wrow + k) : zero4;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = (kin && min_[mt]) ? ld4(xrow[mt] + k) : zero4;
+            if (LN) {
+                gm[c] = kin ? ld4(ln.gamma + k + 4 * g) : zero4;
+                bt[c] = kin ? ld4(ln.beta + k + 4 * g) : zero4;
             }
         }
+    };
+    STAMP(0);
+    issue(ks0);
+    STAMP(1);
+
+    float mean[MT], rstd[MT];
+    if (LN) {
+        // rows w, w+NW, ...: each row is held in registers (K <= 1024) so it is read once; rows
+        // are taken RG at a time so their loads overlap
+        constexpr int RPW = (16 * MT + NW - 1) / NW;
+        constexpr int RG = RPW < 4 ? RPW : 4;
+#pragma unroll 1
+        for (int r0 = 0; r0 < RPW; r0 += RG) {
+            f32x4 xr[RG][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int rr = 0; rr < RG; ++rr) {
+                const int row = w + (r0 + rr) * NW;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j], xf[mt][j], acc[mt], 0, 0, 0);
+                for (int c = 0; c < 4; ++c) {
+                    const int col = (lane + 64 * c) * 4;
+                    xr[rr][c] = (row < a.M && col < a.K) ? ld4(a.A + (int64_t)row * a.lda + col) : zero4;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < RG; ++rr) {
+                const int row = w + (r0 + rr) * NW;
+                float s = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += (xr[rr][c].x + xr[rr][c].y) + (xr[rr][c].z + xr[rr][c].w);
+                const float mu = wave_sum(s) / (float)a.K;
+                float ss = 0.f;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    if ((lane + 64 * c) * 4 < a.K) {
+                        const f32x4 t = xr[rr][c] - mu;
+                        ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+                    }
+                }
+                const float var = wave_sum(ss) / (float)a.K;
+                if (lane == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            mean[mt] = min_[mt] ? s_mean[mt * 16 + i] : 0.f;
+            rstd[mt] = min_[mt] ? s_rstd[mt * 16 + i] : 0.f;
+        }
+    }
+
+    STAMP(2);
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = zero4;
+    for (int base = ks0; base < ks1; base += CH) {
+        if (base != ks0) issue(base);
+        if (LN) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 y = (xf[c][mt] - mean[mt]) * rstd[mt] * gm[c] + bt[c];
+                    if (ln.ada_scale) {
+                        const int k = (base + c) * 16 + 4 * g;
+                        if (base + c < ks1) y = ld4(ln.ada_scale + k) * y + ld4(ln.ada_shift + k);
+                    }
+                    xf[c][mt] = (min_[mt] && base + c < ks1) ? y : zero4;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][j], xf[c][mt][j], acc[mt], 0, 0, 0);
     }
     // D[i=n][j=m]: lane holds m = mt*16 + (l&15), n = n0 + 4g + {0..3}
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st4(&red[w][mt][lane][0], acc[mt]);
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
     for (int o = tid; o < MT * 64; o += NW * 64) {
         const int mt = o >> 6, l = o & 63;
         f32x4 s = ld4(&red[0][mt][l][0]);
@@ -270,6 +345,213 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
         for (int ww = 1; ww < NW; ++ww) s += ld4(&red[ww][mt][l][0]);
         store4<EPI>(a, mt * 16 + (l & 15), n0 + 4 * (l >> 4), s);
     }
+    STAMP(5);
+}
+
+// =============================================================================================
+// Compact fast path of the skinny kernel for K = 16*NW*PW*passes (every real model shape).
+// Every launch starts with a cold instruction cache and these kernels do only a few KB of work per
+// wave, so executed code bytes are time: no predication (out-of-range rows are CLAMPED to a valid
+// row — their products only reach output rows/columns that are never stored), immediate-offset
+// loads, DPP reductions, LayerNorm statistics for 4 rows per wave at once (one DPP row per
+// activation row, NJ float4 per lane) and a single LDS reduction.
+// =============================================================================================
+template <int MT, int NW, int EPI, int PW, bool LN, int NJ>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
+    __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
+    __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int koff = blockIdx.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
+    const float* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
+    const float* xp[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = a.A + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
+    const float* gp = LN ? ln.gamma + koff : nullptr;
+    const float* bp = LN ? ln.beta + koff : nullptr;
+
+    f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
+    auto issue = [&](int kbase) {
+#pragma unroll
+        for (int c = 0; c < PW; ++c) {
+            wf[c] = ld4(wp + kbase + 16 * c);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
+            if (LN) {
+                gm[c] = ld4(gp + kbase + 16 * c);
+                bt[c] = ld4(bp + kbase + 16 * c);
+            }
+        }
+    };
+    // Issue order = return order for s_waitcnt: the LayerNorm rows (L2 hits) go first so their
+    // reduction overlaps the weight loads (HBM) issued right behind them; the sched_barrier keeps
+    // hipcc from sinking loads between the MFMAs (it would trade round trips for registers).
+    constexpr int ROUNDS = LN ? (16 * MT + 4 * NW - 1) / (4 * NW) : 0;
+    f32x4 v[NJ];
+    auto ln_load = [&](int r0) {
+        const int row = (r0 * NW + w) * 4 + g;
+        const float* xr = a.A + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
+    };
+    auto ln_reduce = [&](int r0) {
+        // DPP row g of the wave reduces activation row 4*w + g (two-pass mean / centred variance)
+        const int row = (r0 * NW + w) * 4 + g;
+        float sum = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) sum += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
+        const float mu = row16_sum(sum) / (float)a.K;
+        float ss = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const f32x4 t = v[jj] - mu;
+            ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        }
+        const float var = row16_sum(ss) / (float)a.K;
+        if (i == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
+    };
+    if (LN) ln_load(0);
+    issue(0);
+    // Epilogue operands (bias / residual / cache position) are fetched NOW by the lanes that will
+    // finalise (wave w finalises m-tile w): loaded in the epilogue they would add one more
+    // dependent memory round trip to a kernel that is nothing but round trips.
+    const int em = w * 16 + i, en = n0 + 4 * g;
+    const bool fin = w < MT && em < a.M && en + 3 < a.N;
+    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_res = {0.f, 0.f, 0.f, 0.f};
+    int e_pos = 0;
+    if (fin) {
+        if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
+        if (EPI == EPI_PLAIN && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
+        if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    float mean[MT], rstd[MT];
+    if (LN) {
+        ln_reduce(0);
+#pragma unroll 1
+        for (int r0 = 1; r0 < ROUNDS; ++r0) {
+            ln_load(r0);
+            ln_reduce(r0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = min(mt * 16 + i, a.M - 1);
+            mean[mt] = s_mean[row];
+            rstd[mt] = s_rstd[row];
+        }
+    }
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int pass_stride = NW * PW * 16;
+#pragma unroll 1
+    for (int kbase = 0;;) {
+        if (LN) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const f32x4 sc = gm[c] * rstd[mt];
+                    xf[c][mt] = xf[c][mt] * sc + (bt[c] - sc * mean[mt]);
+                    if (ln.ada_scale)
+                        xf[c][mt] = ld4(ln.ada_scale + koff + kbase + 16 * c) * xf[c][mt] +
+                                    ld4(ln.ada_shift + koff + kbase + 16 * c);
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][jj], xf[c][mt][jj], acc[mt], 0, 0, 0);
+        kbase += pass_stride;
+        if (kbase >= a.k_len) break;
+        issue(kbase);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) st4(&red[w][mt][lane][0], acc[mt]);
+    __syncthreads();
+    if (tid < MT * 64) {
+        const int mt = tid >> 6;
+        f32x4 sacc = ld4(&red[0][mt][lane][0]);
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) sacc += ld4(&red[ww][mt][lane][0]);
+        if (!fin || EPI == EPI_PARTIAL) {
+            store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
+        } else if (EPI == EPI_PLAIN) {
+            sacc += e_bias;
+            if (a.act == VH_ACT_GELU_ERF) {
+                sacc.x = gelu_erf(sacc.x); sacc.y = gelu_erf(sacc.y);
+                sacc.z = gelu_erf(sacc.z); sacc.w = gelu_erf(sacc.w);
+            }
+            st4(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
+        } else {  // EPI_QKV with the cache position already in a register
+            const int which = en / a.d_model, c = en - which * a.d_model;
+            if (which == 0) {
+                st4(a.out + (int64_t)em * a.ldo + c, sacc);
+            } else {
+                const int head = c / VH_HEAD_DIM, e = c - head * VH_HEAD_DIM;
+                const int b = em / a.T, t = em - b * a.T;
+                float* base = which == 1 ? a.kc : a.vc;
+                st4(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
+            }
+        }
+    }
+}
+
+// =============================================================================================
+// Split-K for the wide-K skinny GEMM (linear_2: K = dff).  One workgroup can pull only ~20-30 GB/s
+// through its L1, and with K = 2048 a 16-column workgroup needs the whole (M, K) activation block
+// (256 KB) plus 128 KB of weights: the launch is bound by per-CU fill rate, not by HBM.  So the K
+// range is cut into gridDim.y slices (≈256 workgroups in all, each W 16 KB + x 32 KB), the slices
+// leave raw partial sums in a workspace and a second tiny kernel adds them IN FIXED ORDER (bitwise
+// reproducible, no atomics) and applies the bias / activation / residual epilogue.
+// =============================================================================================
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int n_split,
+                                                            GemmArgs a, int lds_) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int ngroups = lds_ / 4;
+    const int m = idx / ngroups, n = (idx - m * ngroups) * 4;
+    if (m >= a.M || n >= a.N) return;
+    const float* p = slabs + (int64_t)m * lds_ + n;
+    const int64_t stride = (int64_t)a.M * lds_;
+    f32x4 part[16];                     // all slices in flight at once, summed in slice order
+#pragma unroll
+    for (int sidx = 0; sidx < 16; ++sidx)
+        part[sidx] = sidx < n_split ? ld4(p + sidx * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool full = n + 3 < a.N;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, res4 = {0.f, 0.f, 0.f, 0.f};
+    if (full && a.bias) bias4 = ld4(a.bias + n);
+    if (full && a.res) res4 = ld4(a.res + (int64_t)m * a.ldr + n);
+    f32x4 acc = part[0];
+#pragma unroll
+    for (int sidx = 1; sidx < 16; ++sidx) acc += part[sidx];
+    if (!full) { store4<EPI_PLAIN>(a, m, n, acc); return; }
+    acc += bias4;
+    if (a.act == VH_ACT_GELU_ERF) {
+        acc.x = gelu_erf(acc.x); acc.y = gelu_erf(acc.y); acc.z = gelu_erf(acc.z); acc.w = gelu_erf(acc.w);
+    }
+    st4(a.out + (int64_t)m * a.ldo + n, acc + res4);
+}
+
+static int splitk_plan(int M, int N, int K) {
+    // number of K slices (0 = do not split)
+    if (M > 64 || K <= 1024 || K % 256 != 0) return 0;
+    const int tiles = (N + 15) / 16;
+    int splits = min(16, 256 / tiles);
+    while (splits > 1 && (K % (splits * 256) != 0)) --splits;
+    return splits >= 2 ? splits : 0;
+}
+
+extern "C" size_t vh_linear_ws_bytes(int M, int N, int K) {
+    const int splits = splitk_plan(M, N, K);
+    return splits ? (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
 }
 
 // =============================================================================================
@@ -290,8 +572,9 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
     VH_REQUIRE((ln.ada_scale == nullptr) == (ln.ada_shift == nullptr), VH_EINVAL,
                "%s: ada_scale and ada_shift must be given together", name);
     VH_REQUIRE(!ln.ada_scale || ln.gamma, VH_EINVAL, "%s: ada_* needs ln_gamma/ln_beta", name);
-    VH_REQUIRE(!ln.gamma || a.M <= 64, VH_EUNSUPPORTED,
-               "%s: fused LayerNorm only for M <= 64 (M=%d); run vh_layernorm first", name, a.M);
+    VH_REQUIRE(!ln.gamma || (a.M <= 64 && a.K <= 1024), VH_EUNSUPPORTED,
+               "%s: fused LayerNorm only for M <= 64 and K <= 1024 (M=%d K=%d); run vh_layernorm first",
+               name, a.M, a.K);
     VH_REQUIRE(vh_aligned16(ln.gamma) && vh_aligned16(ln.beta) && vh_aligned16(ln.ada_scale) &&
                    vh_aligned16(ln.ada_shift),
                VH_EALIGN, "%s: LayerNorm vectors must be 16-byte aligned", name);
@@ -304,12 +587,48 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
     if (a.M <= 64) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
-        // K split over 8 waves up to K=1024, 16 waves beyond (e.g. linear_2: K = dff = 2048)
         const bool wide = a.K > 1024;
-#define SK(MT, NW) hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI>), grid, dim3(NW * 64), 0, s, a, ln)
-        if (mt == 1) { if (wide) SK(1, 16); else SK(1, 8); }
-        else if (mt == 2) { if (wide) SK(2, 16); else SK(2, 8); }
-        else { if (wide) SK(4, 16); else SK(4, 8); }
+        const bool has_ln = ln.gamma != nullptr;
+        // ---- compact fast path: K = 16*NW*PW*passes
+#define SF(MT, NW, PW, LN, NJ) \
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, a, ln)
+#define SF_MT(NW, PW, LN, NJ)                                                  \
+    do {                                                                       \
+        if (mt == 1) SF(1, NW, PW, LN, NJ);                                    \
+        else if (mt == 2) SF(2, NW, PW, LN, NJ);                               \
+        else SF(4, NW, PW, LN, NJ);                                            \
+        VH_CHECK_LAUNCH(name);                                                 \
+        return VH_OK;                                                          \
+    } while (0)
+        if (has_ln) {  // K <= 1024 (check_gemm); statistics need K = 64*NJ
+            if (a.K == 128) SF_MT(8, 1, true, 2);
+            if (a.K == 256) SF_MT(8, 2, true, 4);
+            if (a.K == 512) SF_MT(8, 4, true, 8);
+            if (a.K == 1024) SF_MT(8, 4, true, 16);
+        } else if (!wide) {
+            if (a.K % 512 == 0) SF_MT(8, 4, false, 1);
+            if (a.K % 256 == 0) SF_MT(8, 2, false, 1);
+            if (a.K % 128 == 0) SF_MT(8, 1, false, 1);
+        } else {
+            if (a.K % 2048 == 0 && mt <= 2) {
+                if (mt == 1) SF(1, 16, 8, false, 1); else SF(2, 16, 8, false, 1);
+                VH_CHECK_LAUNCH(name);
+                return VH_OK;
+            }
+            if (a.K % 1024 == 0) SF_MT(16, 4, false, 1);
+        }
+#undef SF_MT
+#undef SF
+        // ---- generic guarded kernel for every other K (multiple of 16)
+#define SK(MT, NW, CH, LN) \
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI, CH, LN>), grid, dim3(NW * 64), 0, s, a, ln)
+        if (has_ln) {
+            if (mt == 1) SK(1, 8, 4, true); else if (mt == 2) SK(2, 8, 4, true); else SK(4, 8, 4, true);
+        } else if (wide) {
+            if (mt == 1) SK(1, 16, 8, false); else if (mt == 2) SK(2, 16, 8, false); else SK(4, 16, 4, false);
+        } else {
+            if (mt == 1) SK(1, 8, 4, false); else if (mt == 2) SK(2, 8, 4, false); else SK(4, 8, 4, false);
+        }
 #undef SK
     } else {
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
@@ -326,7 +645,7 @@ extern "C" int vh_linear(const float* A, int lda, const float* W, const float* b
                          void* stream) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
-    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act;
+    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K;
     LnFuse ln{ln_gamma, ln_beta, ada_scale, ada_shift, ln_eps};
     VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF, VH_EINVAL, "vh_linear: act=%d", act);
     VH_REQUIRE(ldo >= N && (!residual || ldr >= N), VH_EINVAL, "vh_linear: ldo/ldr < N");
@@ -346,9 +665,48 @@ extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* 
     VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache), VH_EALIGN, "vh_linear_qkv: cache alignment");
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = Wqkv; a.out = q_out; a.ldo = ldq; a.M = B * T; a.N = 3 * d_model;
-    a.K = d_model; a.act = VH_ACT_NONE; a.kc = kcache; a.vc = vcache; a.cache_len = cache_len;
+    a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE; a.kc = kcache; a.vc = vcache; a.cache_len = cache_len;
     a.T = T > 0 ? T : 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
     LnFuse ln{ln_gamma, ln_beta, ada_scale, ada_shift, ln_eps};
     if (int rc = check_gemm("vh_linear_qkv", a, ln)) return rc;
     return launch_gemm<EPI_QKV>("vh_linear_qkv", a, ln, (hipStream_t)stream);
+}
+
+extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,
+                            const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
+                            int act, void* workspace, size_t workspace_bytes, void* stream) {
+    const int splits = splitk_plan(M, N, K);
+    if (!splits || !workspace)
+        return vh_linear(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, act, nullptr, nullptr,
+                         nullptr, nullptr, 0.f, stream);
+    VH_REQUIRE(workspace_bytes >= vh_linear_ws_bytes(M, N, K) && vh_aligned16(workspace), VH_EINVAL,
+               "vh_linear_ws: workspace too small or unaligned (%zu < %zu)", workspace_bytes,
+               vh_linear_ws_bytes(M, N, K));
+    VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF, VH_EINVAL, "vh_linear_ws: act=%d", act);
+    VH_REQUIRE(ldo >= N && (!residual || ldr >= N), VH_EINVAL, "vh_linear_ws: ldo/ldr < N");
+    if (M == 0) return VH_OK;
+    const int lds_ = (N + 3) / 4 * 4;
+    GemmArgs part{};
+    part.A = A; part.lda = lda; part.W = W; part.out = (float*)workspace; part.ldo = lds_; part.M = M;
+    part.N = N; part.K = K; part.act = VH_ACT_NONE; part.k_len = K / splits;
+    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    if (int rc = check_gemm("vh_linear_ws", part, none)) return rc;
+    GemmArgs fin{};
+    fin.bias = bias; fin.res = residual; fin.ldr = ldr; fin.out = out; fin.ldo = ldo; fin.M = M; fin.N = N;
+    fin.K = K; fin.act = act;
+    VH_REQUIRE(vh_aligned16(out) && vh_aligned16(bias) && vh_aligned16(residual) && ldo % 4 == 0 &&
+                   (!residual || ldr % 4 == 0),
+               VH_EALIGN, "vh_linear_ws: out/bias/residual alignment");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((N + 15) / 16, splits);
+    const int mt = (M + 15) / 16;
+    // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
+    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
+    else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
+    const int items = M * (lds_ / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, s,
+                       (const float*)workspace, splits, fin, lds_);
+    VH_CHECK_LAUNCH("vh_linear_ws");
+    return VH_OK;
 }

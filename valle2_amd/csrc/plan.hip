@@ -16,6 +16,14 @@ void vh_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+static int g_tuning[VH_TUNE_COUNT] = {0};
+int vh_tuning(int knob) { return (knob >= 0 && knob < VH_TUNE_COUNT) ? g_tuning[knob] : 0; }
+extern "C" int vh_set_tuning(int knob, int value) {
+    VH_REQUIRE(knob >= 0 && knob < VH_TUNE_COUNT, VH_EINVAL, "vh_set_tuning: knob=%d", knob);
+    g_tuning[knob] = value;
+    return VH_OK;
+}
+
 extern "C" const char* vh_last_error(void) { return g_err; }
 extern "C" int vh_version(void) { return VH_VERSION; }
 
@@ -102,8 +110,8 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         TRY(vh_linear(d.x, D, L.w1, L.b1, nullptr, 0, d.hidden, d.dff, B, d.dff, D, VH_ACT_GELU_ERF,
                       L.ln2_g, L.ln2_b, nullptr, nullptr, d.ln_eps, s));
         // linear_2 + bias + residual
-        TRY(vh_linear(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, nullptr,
-                      nullptr, nullptr, nullptr, 0.f, s));
+        TRY(vh_linear_ws(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, d.gemm_ws,
+                         d.gemm_ws_bytes, s));
     }
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
     TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,

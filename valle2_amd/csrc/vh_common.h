@@ -33,25 +33,48 @@ static inline bool vh_aligned16(const void* p) { return (reinterpret_cast<uintpt
         }                                                                          \
     } while (0)
 
+// tuning knobs (vh_set_tuning); 0 = built-in default
+int vh_tuning(int knob);
+
 // ---- device side -----------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Cross-lane reductions on DPP (data-parallel primitives): one VALU instruction per step and no
+// LDS crossbar traffic (ds_bpermute), which matters twice here: the decode kernels are latency
+// bound, and every launch starts with a cold instruction cache, so compact code is faster code.
+//   quad_perm(1,0,3,2)=0xB1  quad_perm(2,3,0,1)=0x4E  row_mirror=0x140  row_half_mirror=0x141
+//   row_bcast15=0x142 (lane 15 of each row → next row)  row_bcast31=0x143 (lane 31 → rows 2,3)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v, float identity) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL,
+                                                      ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// reduce over the 16 lanes of one DPP row (lanes 16g..16g+15); every lane gets the sum
+// sum over the 16 lanes of one DPP row (lanes 16g..16g+15); every lane of the row gets the sum
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_get<0xB1, 0xF>(v, 0.f);
+    v += dpp_get<0x4E, 0xF>(v, 0.f);
+    v += dpp_get<0x141, 0xF>(v, 0.f);
+    v += dpp_get<0x140, 0xF>(v, 0.f);
     return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_get<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_get<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_get<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_get<0x140, 0xF>(v, v));
+    return v;
+}
+// combine the 4 row values of a wave (each row already uniform): result uniform over the wave
+__device__ __forceinline__ float rows4_sum(float v) {
+    v += dpp_get<0x142, 0xA>(v, 0.f);
+    v += dpp_get<0x143, 0xC>(v, 0.f);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    v = fmaxf(v, dpp_get<0x142, 0xA>(v, v));
+    v = fmaxf(v, dpp_get<0x143, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 

@@ -138,6 +138,8 @@ class ArDecoder:
         self.hidden = torch.empty(batch, dff, **f32)
         self.logits = torch.zeros(batch, self.ldl, **f32)
         self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
+        ws_bytes = _lib.lib().vh_linear_ws_bytes(batch, d, dff)
+        self.gemm_ws = torch.empty(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
@@ -149,7 +151,8 @@ class ArDecoder:
             V=V, eos=cfg.num_audio_tokens, n_split=self.n_split, ln_eps=1e-5, layers=self._table,
             proj_w=ptr(self._keep[0]), audio_emb=ptr(self._keep[1]), audio_pe=ptr(self._keep[2]),
             x=ptr(self.x), q=ptr(self.q), attn=ptr(self.attn), hidden=ptr(self.hidden),
-            logits=ptr(self.logits), attn_partial=ptr(self.partial), cache_len=ptr(cache_len),
+            logits=ptr(self.logits), attn_partial=ptr(self.partial), gemm_ws=ptr(self.gemm_ws),
+            gemm_ws_bytes=ws_bytes, cache_len=ptr(cache_len),
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0))
         self._desc = desc

@@ -92,6 +92,24 @@ def linear(a, w, bias=None, residual=None, out=None, act=ACT_NONE, ln=None):
     return out
 
 
+def linear_ws(a, w, bias=None, residual=None, out=None, act=ACT_NONE, workspace=None):
+    """vh_linear_ws: split-K path for wide K (see include/valle_hip.h)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
+    need = _lib.lib().vh_linear_ws_bytes(M, N, K)
+    if workspace is None and need:
+        workspace = torch.empty(need // 4, device=a.device, dtype=torch.float32)
+    check(_lib.lib().vh_linear_ws(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+        residual.data_ptr() if residual is not None else None,
+        residual.stride(0) if residual is not None else 0,
+        out.data_ptr(), out.stride(0), M, N, K, act, ptr(workspace),
+        workspace.numel() * 4 if workspace is not None else 0, stream()), 'vh_linear_ws')
+    return out
+
+
 def linear_qkv(a, wqkv, q_out, kcache, vcache, B, T, n_heads, cache_len=None, ln=None):
     """QKV projection; Q → q_out (B*T, d); K,V rows appended to the caches (B,h,S_max,64)."""
     M, d = a.shape
