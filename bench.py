@@ -120,13 +120,11 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from valle2_amd import ConfigValle, get_model_class, synth
+    from valle2_amd import ConfigValle, dp, get_model_class, synth
 
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+    dp.init_distributed('nccl', dev)                         # "nccl" is RCCL on ROCm; no-op at N=1
 
     rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
     ar_kw = dict(AR)
@@ -138,9 +136,9 @@ def main():
     model = get_model_class('ValleAR')(cfg)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
-    # 32 DISTINCT utterances per rank (rows are never deduplicated), seeds per SURVEY.md §8d
-    utts = [synth.synth_utterance(cfg, text // 2, text - text // 2, frames, seed=1234 + rank * rows + r)
-            for r in range(rows)]
+    # weak scaling: world*rows DISTINCT utterances, sharded by utterance (rows never deduplicated)
+    utts = [synth.synth_utterance(cfg, text // 2, text - text // 2, frames, seed=1234 + u)
+            for u in dp.shard_range(world * rows, rank, world)]
     texts = [torch.cat([u[0], u[2]]).to(dev) for u in utts]
     firsts = [u[1][:, 0].to(dev) for u in utts]
 
@@ -166,10 +164,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert int((out[:, frames + 1:] == cfg.eos_token).sum()) == 0, 'EOS appeared in a bench run'
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = dp.max_over_ranks(elapsed, dev)
     ms_per_step = elapsed / args.steps * 1e3
     log(f'{ms_per_step:.1f} ms per generate')
     value = world * rows * new * args.steps / elapsed
@@ -200,12 +195,19 @@ def main():
         achieved = bytes_per_launch / dur_s / 1e9
         result['roofline'] = {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_unit': 'bytes/launch',
             'kernel': 'attn_decode_kernel', 'launches': (new - 1) * cfg.num_layers,
             'avg_launch_us': dur_s * 1e6, 'algorithmic_bytes_per_launch': bytes_per_launch,
             'mean_context': mean_s,
-            'note': 'traffic (PMC FETCH_SIZE/WRITE_SIZE) is collected by separate rocprofv3 --pmc '
-                    'passes; see profiles/'}
+            'note': 'duration = HIP events around each launch (includes ~3 us dispatch latency); '
+                    'traffic = PMC FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes of this '
+                    'workload, committed under profiles/ (null when absent)'}
+        pmc = REPO / 'profiles' / 'attn_decode_traffic.json'
+        if pmc.exists() and not args.small:
+            t = json.loads(pmc.read_text())
+            if t.get('rows') == rows and t.get('new_tokens') == new:
+                result['roofline']['traffic'] = t['bytes_per_launch']
+                result['roofline']['traffic_source'] = t['source']
         # whole-step view of the same roofline: all algorithmic bytes of the decode steps
         step_elems = [cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
                       + 2 * cfg.num_layers * rows * (st['s0'] + t) * cfg.d_model
