@@ -154,6 +154,29 @@ def test_ar_generate_golden(which, graph):
     tokens_match(out, gold['tokens'], gold['margin'])
 
 
+def test_generate_batch_distinct_rows_vs_oracle():
+    """Rows are independent utterances: each row of generate_batch must equal the oracle run on
+    that utterance alone (a kernel that mixed rows or read row 0 for everyone would pass the
+    identical-beam fixtures)."""
+    from oracle import valle_oracle as O
+    from valle2_amd import synth
+    kw = dict(d_model=256, n_heads=4, dim_feedforward=1024, num_layers=3, dropout=0.0,
+              norm='LayerNorm', num_beams=1, top_k=1, max_audio_len=24)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=17, rich=True, std=0.15), cfg)
+    utts = [synth.synth_utterance(cfg, 7, 9, 21, seed=900 + r) for r in range(5)]
+    m = build('ValleAR', kw, sd)
+    rows = m.generate_batch([torch.cat([u[0], u[2]]).to(DEV) for u in utts],
+                            [u[1][:, 0].to(DEV) for u in utts])
+    outs = set()
+    for r, u in enumerate(utts):
+        trace = {}
+        ref = O.ar_generate(sd, cfg, *u, trace=trace)
+        tokens_match(rows[r, 22:], ref, torch.tensor(trace['margin']))
+        outs.add(tuple(ref.tolist()))
+    assert len(outs) > 1, 'test inputs must lead to different continuations'
+
+
 def test_ar_generate_eos_golden():
     gold = load_golden('ar_generate_eos')
     kw, sd, utt = C.ar_eos_inputs(gold['eos_row'])

@@ -411,6 +411,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         const float var = row16_sum(ss) / (float)a.K;
         if (i == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
     };
+    STAMP(0);
     if (LN) ln_load(0);
     issue(0);
     // Epilogue operands (bias / residual / cache position) are fetched NOW by the lanes that will
@@ -426,6 +427,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(1);
 
     float mean[MT], rstd[MT];
     if (LN) {
@@ -444,6 +446,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         }
     }
 
+    STAMP(2);
     f32x4 acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -476,7 +479,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st4(&red[w][mt][lane][0], acc[mt]);
+    STAMP(3);
     __syncthreads();
+    STAMP(4);
     if (tid < MT * 64) {
         const int mt = tid >> 6;
         f32x4 sacc = ld4(&red[0][mt][lane][0]);
@@ -503,6 +508,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             }
         }
     }
+    STAMP(5);
 }
 
 // =============================================================================================
