@@ -190,6 +190,33 @@ int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream);
  * milliseconds of those launches via *mean_ms (synchronises the stream; measurement only). */
 int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream, float* mean_ms);
 
+/* ---- training path: backward of the row ops (loss.backward() of valle/models/valle_ar.py:86) -----
+ * The plain backward GEMMs (dX = dY.W, dW = dY^T.X and the five attention products) are library
+ * GEMMs issued by the host; these entry points are the hand-written non-GEMM halves.  Gradient
+ * buffers marked "+=" are accumulated with fp32 atomics: the caller zeroes them first. */
+/* LayerNorm / AdaptiveLayerNorm backward (modules.py:284, :93-99).  y = s*(gamma*xhat+beta)+t:
+ * dx written; dgamma += , dbeta += , and when ada_scale != NULL dscale += , dshift += (all (d)). */
+int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta, const float* ada_scale,
+                     const float* dy, float* dx, float* dgamma, float* dbeta, float* dscale,
+                     float* dshift, int rows, int d, float eps, void* stream);
+/* exact-erf GELU on a saved pre-activation: dh == NULL → out = gelu(pre); else out = dh*gelu'(pre) */
+int vh_gelu(const float* pre, const float* dh, float* out, int64_t n, void* stream);
+/* P = softmax(S*scale + mask) in place over rows of (B,h,Tq,Tk); same mask semantics as vh_attn_rows */
+int vh_softmax_rows(float* S, int B, int n_heads, int Tq, int Tk, float scale, int mode, int x_len,
+                    const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+                    const uint8_t* pad, void* stream);
+/* dS = scale * P o (dP - rowsum(dP o P)), in place on dP */
+int vh_softmax_bwd(const float* P, float* dP, int64_t rows, int Tk, float scale, void* stream);
+/* mean cross entropy over `rows` rows of (rows, V) logits (F.cross_entropy, valle_ar.py:86):
+ * *loss = mean(lse - logit[target]); dlogits (may be NULL) = (softmax - onehot) / rows */
+int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
+                     float* dlogits, int ldd, int rows, void* stream);
+/* embedding backward: dtable[ids[b,t], :] += dout[b, out_t0 + t, :] */
+int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, const float* dout,
+                 int64_t dout_bstride, int out_t0, float* dtable, int B, int T, int d, void* stream);
+/* bias gradient: out[c] += sum_r x[r, c] */
+int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
+
 /* ---- composite: full-sequence transformer forward (prefill / NAR stage / training forward) --
  * valle/models/modules.py:305-352 without cache input: x (B*T, d) in/out in place, every
  * layer's K/V written to its cache at positions 0..T-1.  scratch: xn (B*T,d), q (B*T,d),

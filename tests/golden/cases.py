@@ -246,7 +246,20 @@ def _ref_sampling(ref):
             'best_beam_2': ref['utils'].get_best_beam(x, lp, 1024, 0.0)}
 
 
+def collate_inputs():
+    g = torch.Generator().manual_seed(61)
+    return [{'codes': torch.randint(0, 1024, (8, t), generator=g), 'tokens': torch.randint(0, 256, (n,), generator=g)}
+            for t, n in ((12, 5), (9, 3), (20, 11))]
+
+
+def _ref_collate(ref):
+    import valle.collate as rcollate            # the reference's module (imported by gen_golden's harness)
+    cfg = cfg_of(AR_TINY, ref['config'].ConfigValle)
+    return dict(rcollate.ValleARCollate(cfg)(collate_inputs()))
+
+
 REFERENCE_RUNNERS = {
+    'collate': _ref_collate,
     'masks': _ref_masks,
     'mha': _ref_mha,
     'transformer': _ref_transformer,

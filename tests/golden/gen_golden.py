@@ -74,6 +74,7 @@ def import_reference():
         import valle.models.utils as rutils
         import valle.models.valle_ar as rar
         import valle.models.valle_nar as rnar
+        import valle.collate  # noqa: F401  (kept in sys.modules for the collate case)
     finally:
         sys.path.remove(str(REF))
     assert str(REF) in rmodules.__file__, rmodules.__file__
@@ -95,7 +96,10 @@ def main():
     torch.set_grad_enabled(False)
     ref = import_reference()
     out = {}
+    only = set(sys.argv[1:])
     for name, fn in cases.REFERENCE_RUNNERS.items():
+        if only and name not in only:
+            continue
         res = fn(ref)
         out[name] = res
         path = HERE / f'{name}.npz'

@@ -165,3 +165,27 @@ def test_bench_byte_accounting():
     b, mean_s = bench.attn_algorithmic_bytes(32, 512, 1024, 512)
     assert abs(mean_s - (1024 + 256)) < 1e-9
     assert b == 4.0 * (2 * 32 * 1280 * 512 + 2 * 32 * 512)
+
+
+def test_collate_matches_reference_golden():
+    """valle/collate.py:19-44 wire format (BOS-prepend / EOS-append / zero pad / lens), pinned by a
+    fixture produced by the reference's own ValleARCollate; NAR layout fixed per defect D7."""
+    from tests.golden import cases as C
+    from tests.oracle_runners import load_golden
+    from valle.collate import ValleARCollate, ValleNARCollate, collate_list, get_collate
+    gold = load_golden('collate')
+    cfg = C.cfg_of(C.AR_TINY)
+    items = C.collate_inputs()
+    out = ValleARCollate(cfg)(items)
+    assert set(out) == set(gold)
+    for k in gold:
+        assert out[k].dtype == torch.int64 and torch.equal(out[k], gold[k]), k
+    nar = ValleNARCollate(cfg)(items)
+    assert nar['codes'].shape == (3, 20, 8) and nar['codes_lens'].tolist() == [12, 9, 20]
+    assert torch.equal(nar['codes'][1, :9], items[1]['codes'].T) and nar['codes'][1, 9:].sum() == 0
+    assert get_collate('ValleAR') is ValleARCollate
+    x, lens = collate_list([torch.ones(2), torch.ones(5)])
+    assert x.shape == (2, 5) and lens.tolist() == [2, 5]
+    with pytest.raises(AssertionError):       # codes must be longer than tokens (collate.py:37)
+        ValleARCollate(cfg)([{'codes': torch.zeros(8, 3, dtype=torch.int64),
+                              'tokens': torch.zeros(9, dtype=torch.int64)}])

@@ -1,0 +1,243 @@
+"""Autograd wrappers: the training path (`training_step` → `loss.backward()`, valle_ar.py:43-90).
+
+Forward passes run the same HIP kernels as inference.  Backward passes pair hand-written HIP
+kernels for every non-GEMM op (LayerNorm/AdaLN, GELU, softmax, cross entropy, embedding scatter,
+bias column sums — csrc/train.hip) with library GEMMs for the plain matrix products
+(`torch.matmul` → rocBLAS/hipBLASLt: dX = dY·W, dW = dYᵀ·X and the attention products on
+recomputed probabilities).  Nothing here runs on the CPU.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib, kernels
+from ._lib import check, ptr, stream
+
+HEAD_DIM = kernels.HEAD_DIM
+
+
+def _zeros_like(t):
+    return torch.zeros_like(t, memory_format=torch.contiguous_format)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W.T + b (+ residual).  x (M,K), W (N,K)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual):
+        x = x.contiguous()
+        n = w.shape[0]
+        out = torch.empty(x.shape[0], (n + 3) // 4 * 4, device=x.device, dtype=torch.float32)[:, :n]
+        kernels.linear(x, w.detach(), None if b is None else b.detach(), residual=residual, out=out)
+        if n % 4:
+            out = out.contiguous()        # ragged head (N = 1025): hand autograd a dense tensor
+        ctx.save_for_backward(x, w)
+        ctx.has_b, ctx.has_res = b is not None, residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
+        dw = torch.matmul(dy.t(), x) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = torch.zeros(w.shape[0], device=dy.device, dtype=torch.float32)
+            check(_lib.lib().vh_colsum(ptr(dy), dy.stride(0), ptr(db), dy.shape[0], dy.shape[1], stream()),
+                  'vh_colsum')
+        return dx, dw, db, (dy if ctx.has_res else None)
+
+
+class GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pre):
+        pre = pre.contiguous()
+        out = torch.empty_like(pre)
+        check(_lib.lib().vh_gelu(ptr(pre), None, ptr(out), pre.numel(), stream()), 'vh_gelu')
+        ctx.save_for_backward(pre)
+        return out
+
+    @staticmethod
+    def backward(ctx, dh):
+        (pre,) = ctx.saved_tensors
+        dh = dh.contiguous()
+        out = torch.empty_like(pre)
+        check(_lib.lib().vh_gelu(ptr(pre), ptr(dh), ptr(out), pre.numel(), stream()), 'vh_gelu')
+        return out
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = s * (gamma * xhat + beta) + t   (s, t optional: AdaptiveLayerNorm, modules.py:93-99)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, s, t, eps):
+        x = x.contiguous()
+        out = kernels.layernorm(x, gamma.detach(), beta.detach(),
+                                ada_scale=None if s is None else s.detach().contiguous(),
+                                ada_shift=None if t is None else t.detach().contiguous(), eps=eps)
+        ctx.save_for_backward(x, gamma, beta, s)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, s = ctx.saved_tensors
+        dy = dy.contiguous()
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dg, db = _zeros_like(gamma), _zeros_like(beta)
+        ds = dt = None
+        if s is not None:
+            s = s.contiguous()
+            ds, dt = torch.zeros(d, device=x.device), torch.zeros(d, device=x.device)
+        check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy),
+                                          ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(dt), rows, d, ctx.eps,
+                                          stream()), 'vh_layernorm_bwd')
+        if ds is not None:
+            ds, dt = ds.view_as(s), dt.view_as(s)
+        return dx, dg, db, ds, dt, None
+
+
+class QkvAttentionFn(torch.autograd.Function):
+    """out (B*T, d) = SDPA(split_heads(x @ Wqkv.T)) with the analytic / explicit masks of
+    vh_attn_rows (modules.py:146-170).  Backward recomputes P from the saved q, k, v."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, B, T, n_heads, spec):
+        x = x.contiguous()
+        d = x.shape[1]
+        dev = x.device
+        q = torch.empty(B * T, d, device=dev, dtype=torch.float32)
+        k = torch.empty(B, n_heads, T, HEAD_DIM, device=dev, dtype=torch.float32)
+        v = torch.empty_like(k)
+        kernels.linear_qkv(x, wqkv.detach(), q, k, v, B, T, n_heads)
+        out = torch.empty(B * T, d, device=dev, dtype=torch.float32)
+        kernels.attn_rows(q, k, v, out, B, n_heads, T, T, **spec)
+        ctx.save_for_backward(x, wqkv, q, k, v)
+        ctx.dims, ctx.spec = (B, T, n_heads), spec
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wqkv, q, k, v = ctx.saved_tensors
+        B, T, h = ctx.dims
+        d = h * HEAD_DIM
+        spec = ctx.spec
+        scale = HEAD_DIM ** -0.5
+        qh = q.view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)               # (B,h,T,64) view
+        do = dout.contiguous().view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)
+        P = torch.matmul(qh, k.transpose(-1, -2)).contiguous()           # raw scores (B,h,T,T)
+        check(_lib.lib().vh_softmax_rows(ptr(P), B, h, T, T, scale, spec['mode'], spec.get('x_len', 0),
+                                         ptr(spec.get('x_len_dev')), ptr(spec.get('kv_len')),
+                                         ptr(spec.get('mask')), ptr(spec.get('pad')), stream()),
+              'vh_softmax_rows')
+        dv = torch.matmul(P.transpose(-1, -2), do)                       # (B,h,T,64)
+        dP = torch.matmul(do, v.transpose(-1, -2)).contiguous()          # (B,h,T,T)
+        check(_lib.lib().vh_softmax_bwd(ptr(P), ptr(dP), B * h * T, T, scale, stream()), 'vh_softmax_bwd')
+        dq = torch.matmul(dP, k)                                         # (B,h,T,64)
+        dk = torch.matmul(dP.transpose(-1, -2), qh)
+        dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
+        dview = dqkv.view(B, T, 3, h, HEAD_DIM)
+        dview[:, :, 0].copy_(dq.permute(0, 2, 1, 3))
+        dview[:, :, 1].copy_(dk.permute(0, 2, 1, 3))
+        dview[:, :, 2].copy_(dv.permute(0, 2, 1, 3))
+        dx = torch.matmul(dqkv, wqkv) if ctx.needs_input_grad[0] else None
+        dw = torch.matmul(dqkv.t(), x) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None, None
+
+
+class EmbedSumPeFn(torch.autograd.Function):
+    """x[:, t0:t0+T] = sum_j tables[j][ids[..., j]] + pe[pos0:pos0+T]  written into a fresh (B,T,d)."""
+
+    @staticmethod
+    def forward(ctx, ids, pe, pos0, *tables):
+        if ids.dim() == 2:
+            ids = ids.unsqueeze(-1)
+        B, T, _ = ids.shape
+        d = tables[0].shape[1]
+        out = torch.empty(B, T, d, device=ids.device, dtype=torch.float32)
+        kernels.embed_sum_pe(ids, [t.detach() for t in tables], pe, pos0, out)
+        ctx.ids, ctx.shapes = ids, [t.shape for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids = ctx.ids
+        dout = dout.contiguous()
+        B, T, d = dout.shape
+        grads = []
+        for j, shp in enumerate(ctx.shapes):
+            if not ctx.needs_input_grad[3 + j]:
+                grads.append(None)
+                continue
+            g = torch.zeros(shp, device=dout.device, dtype=torch.float32)
+            col = ids[..., j]
+            check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout),
+                                          dout.stride(0), 0, ptr(g), B, T, d, stream()), 'vh_embed_bwd')
+            grads.append(g)
+        return (None, None, None, *grads)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Mean cross entropy over every row of (R, V) logits against (R,) int64 targets."""
+
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = logits.contiguous() if logits.stride(1) != 1 else logits
+        R, V = logits.shape
+        loss = torch.empty((), device=logits.device, dtype=torch.float32)
+        dl = torch.empty(R, V, device=logits.device, dtype=torch.float32)
+        target = target.contiguous()
+        check(_lib.lib().vh_cross_entropy(logits.data_ptr(), logits.stride(0), V, ptr(target), ptr(loss),
+                                          ptr(dl), V, R, stream()), 'vh_cross_entropy')
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def linear(x, w, b=None, residual=None):
+    return LinearFn.apply(x, w, b, residual)
+
+
+def layer_norm(x, gamma, beta, s=None, t=None, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, s, t, eps)
+
+
+def encoder_layer_train(layer, x, B, T, spec, embedding=None):
+    """One pre-norm block on x (B*T, d) with a full autograd graph (modules.py:240-280).
+    Dropout (training mode, p > 0) uses torch's device RNG, as the reference does."""
+    cfg = layer.config
+    at, ff = layer.self_attn, layer.ffn
+
+    def norm(n, inp):
+        if cfg.norm == 'LayerNorm':
+            return layer_norm(inp, n.weight, n.bias, eps=n.eps)
+        wb = linear(embedding.reshape(1, -1), n.project_layer.weight, n.project_layer.bias).view(2, -1)
+        return layer_norm(inp, n.norm.weight, n.norm.bias, wb[0], wb[1], eps=n.eps)
+
+    a = QkvAttentionFn.apply(norm(layer.norm1, x), at.qkv.weight, B, T, at.n_heads, spec)
+    d1, d2 = layer.dropout1, layer.dropout2
+    if d1.training and d1.p > 0:
+        x = x + d1(linear(a, at.out.weight, at.out.bias))
+    else:
+        x = linear(a, at.out.weight, at.out.bias, residual=x)
+    hid = GeluFn.apply(linear(norm(layer.norm2, x), ff.linear_1.weight, ff.linear_1.bias))
+    if ff.dropout.training and ff.dropout.p > 0:
+        hid = ff.dropout(hid)
+    if d2.training and d2.p > 0:
+        x = x + d2(linear(hid, ff.linear_2.weight, ff.linear_2.bias))
+    else:
+        x = linear(hid, ff.linear_2.weight, ff.linear_2.bias, residual=x)
+    return x
+
+
+def transformer_train(transformer, x, B, T, spec, embedding=None):
+    for layer in transformer.layers:
+        x = encoder_layer_train(layer, x, B, T, spec, embedding)
+    return x

@@ -1,0 +1,338 @@
+// Backward / training-only kernels of the path (valle/models/valle_ar.py:43-90 + loss.backward()):
+// LayerNorm backward (with the adaptive scale/shift), exact-erf GELU forward/backward on a saved
+// pre-activation, row softmax forward/backward for the recomputed attention probabilities,
+// fused cross-entropy forward+backward, embedding scatter-add, column sums for bias gradients.
+// All HBM-bound row kernels: one wave64 per row, float4 per lane, DPP reductions.  The plain
+// backward GEMMs (dX = dY·W, dW = dYᵀ·X, the five attention products) are library GEMMs (rocBLAS
+// through torch.matmul) — unfused matrix products, as the build rules allow.
+// Column-sum style gradients use fp32 atomics (order not fixed: last-bit run-to-run variation).
+#include "vh_common.h"
+
+#define NEG_INF (-INFINITY)
+
+__device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.w); }
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward.  Forward: xhat=(x-mu)*rstd; u=gamma*xhat+beta; y = s*u + t (s,t optional).
+//   du = dy*s;  dgamma += sum_rows du*xhat;  dbeta += sum_rows du;  ds += sum_rows dy*u;  dt += sum_rows dy
+//   g = du*gamma;  dx = rstd*(g - mean(g) - xhat*mean(g*xhat))
+// Waves stride over rows and keep their column partial sums in registers; one atomicAdd per
+// column per wave at the end.
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ s, const float* __restrict__ dy, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ds,
+    float* __restrict__ dt, int rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 gm[NV], bt[NV], sc[NV], ag[NV], ab[NV], as[NV], at[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const bool in = c < d;
+        gm[i] = in ? ld4(gamma + c) : z;
+        bt[i] = (in && s) ? ld4(beta + c) : z;
+        sc[i] = (in && s) ? ld4(s + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+        ag[i] = ab[i] = as[i] = at[i] = z;
+    }
+    for (int row = wid; row < rows; row += nw) {
+        const float* xr = x + (int64_t)row * d;
+        const float* dyr = dy + (int64_t)row * d;
+        f32x4 v[NV], g[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            v[i] = c < d ? ld4(xr + c) : z;
+            g[i] = c < d ? ld4(dyr + c) : z;
+            sum += hsum4(v[i]);
+        }
+        const float mu = wave_sum(sum) / (float)d;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if ((lane + 64 * i) * 4 < d) {
+                v[i] = v[i] - mu;
+                ss += hsum4(v[i] * v[i]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f32x4 xhat = v[i] * rstd;
+            const f32x4 dyv = g[i];
+            const f32x4 du = dyv * sc[i];
+            if (s) {
+                as[i] += dyv * (gm[i] * xhat + bt[i]);
+                at[i] += dyv;
+            }
+            ag[i] += du * xhat;
+            ab[i] += du;
+            g[i] = du * gm[i];
+            v[i] = xhat;
+            m1 += hsum4(g[i]);
+            m2 += hsum4(g[i] * xhat);
+        }
+        m1 = wave_sum(m1) / (float)d;
+        m2 = wave_sum(m2) / (float)d;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) st4(dx + (int64_t)row * d + c, (g[i] - m1 - v[i] * m2) * rstd);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(dgamma + c + j, ag[i][j]);
+                atomicAdd(dbeta + c + j, ab[i][j]);
+                if (s) {
+                    atomicAdd(ds + c + j, as[i][j]);
+                    atomicAdd(dt + c + j, at[i][j]);
+                }
+            }
+        }
+    }
+}
+
+extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta,
+                                const float* ada_scale, const float* dy, float* dx, float* dgamma,
+                                float* dbeta, float* dscale, float* dshift, int rows, int d, float eps,
+                                void* stream) {
+    VH_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, VH_EINVAL, "vh_layernorm_bwd: null pointer");
+    VH_REQUIRE(!ada_scale || (beta && dscale && dshift), VH_EINVAL,
+               "vh_layernorm_bwd: adaptive form needs beta, dscale, dshift");
+    VH_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0 && d <= 2048, VH_EINVAL,
+               "vh_layernorm_bwd: bad dims rows=%d d=%d (d multiple of 4, <= 2048)", rows, d);
+    VH_REQUIRE(vh_aligned16(x) && vh_aligned16(dy) && vh_aligned16(dx) && vh_aligned16(gamma) &&
+                   vh_aligned16(beta) && vh_aligned16(ada_scale),
+               VH_EALIGN, "vh_layernorm_bwd: pointers must be 16-byte aligned");
+    if (rows == 0) return VH_OK;
+    const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+    hipStream_t st = (hipStream_t)stream;
+#define LNB(NV)                                                                                    \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, gamma, beta,   \
+                       ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, rows, d, eps)
+    if (d <= 256) LNB(1);
+    else if (d <= 512) LNB(2);
+    else if (d <= 1024) LNB(4);
+    else LNB(8);
+#undef LNB
+    VH_CHECK_LAUNCH("vh_layernorm_bwd");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GELU (exact erf) forward on a saved pre-activation, and its backward.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ pre,
+                                                   const float* __restrict__ dh,
+                                                   float* __restrict__ out, int64_t n4) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 x = ld4(pre + 4 * i);
+        f32x4 r;
+        if (dh) {
+            const f32x4 g = ld4(dh + 4 * i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float cdf = 0.5f * (1.0f + erff(x[j] * 0.70710678118654752440f));
+                const float pdf = 0.39894228040143267794f * expf(-0.5f * x[j] * x[j]);
+                r[j] = g[j] * (cdf + x[j] * pdf);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = gelu_erf(x[j]);
+        }
+        st4(out + 4 * i, r);
+    }
+}
+
+extern "C" int vh_gelu(const float* pre, const float* dh, float* out, int64_t n, void* stream) {
+    VH_REQUIRE(pre && out && n >= 0 && n % 4 == 0, VH_EINVAL, "vh_gelu: n=%lld must be a multiple of 4",
+               (long long)n);
+    VH_REQUIRE(vh_aligned16(pre) && vh_aligned16(dh) && vh_aligned16(out), VH_EALIGN, "vh_gelu: alignment");
+    if (n == 0) return VH_OK;
+    const int64_t n4 = n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(gelu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, pre, dh, out, n4);
+    VH_CHECK_LAUNCH("vh_gelu");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax over materialised scores (training backward recomputes P = softmax(S*scale + mask)),
+// in place, with the same analytic masks as vh_attn_rows; and its backward
+// dS = scale * P o (dP - rowsum(dP o P)), in place on dP.   rows = B*h*Tq, one wave per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_rows_kernel(
+    float* __restrict__ S, int n_heads, int Tq, int Tk, float scale, int mode, int x_len,
+    const int32_t* __restrict__ x_len_dev, const int32_t* __restrict__ kv_len,
+    const uint8_t* __restrict__ mask, const uint8_t* __restrict__ pad, int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int i = (int)(row % Tq);
+    const int b = (int)(row / ((int64_t)Tq * n_heads));
+    const int kvl = kv_len ? min(kv_len[b], Tk) : Tk;
+    const int xl = x_len_dev ? x_len_dev[b] : x_len;
+    const int qpos = Tk - Tq + i;
+    float* sr = S + row * Tk;
+    auto visible = [&](int j) {
+        if (mode == VH_MASK_EXPLICIT) return !mask[(int64_t)i * Tk + j] && !(pad && pad[(int64_t)b * Tk + j]);
+        bool v = j < kvl;
+        if (mode == VH_MASK_PREFIX) v = v && (j < xl || (qpos >= xl && j <= qpos));
+        return v;
+    };
+    float m = NEG_INF;
+    for (int j = lane; j < Tk; j += 64) {
+        const float v = visible(j) ? sr[j] * scale : NEG_INF;
+        m = fmaxf(m, v);
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < Tk; j += 64) {
+        const float v = visible(j) ? expf(sr[j] * scale - m) : 0.f;
+        sr[j] = v;
+        l += v;
+    }
+    const float inv = 1.0f / wave_sum(l);
+    for (int j = lane; j < Tk; j += 64) sr[j] *= inv;
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P,
+                                                          float* __restrict__ dP, int Tk, float scale,
+                                                          int64_t rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = P + row * Tk;
+    float* dr = dP + row * Tk;
+    float acc = 0.f;
+    for (int j = lane; j < Tk; j += 64) acc += pr[j] * dr[j];
+    acc = wave_sum(acc);
+    for (int j = lane; j < Tk; j += 64) dr[j] = scale * pr[j] * (dr[j] - acc);
+}
+
+extern "C" int vh_softmax_rows(float* S, int B, int n_heads, int Tq, int Tk, float scale, int mode,
+                               int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
+                               const uint8_t* mask, const uint8_t* pad, void* stream) {
+    VH_REQUIRE(S && B >= 0 && n_heads > 0 && Tq >= 0 && Tk >= Tq, VH_EINVAL, "vh_softmax_rows: bad args");
+    VH_REQUIRE(mode == VH_MASK_FULL || mode == VH_MASK_PREFIX || (mode == VH_MASK_EXPLICIT && mask),
+               VH_EINVAL, "vh_softmax_rows: mode=%d", mode);
+    const int64_t rows = (int64_t)B * n_heads * Tq;
+    if (rows == 0) return VH_OK;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, S, n_heads, Tq, Tk, scale, mode, x_len, x_len_dev, kv_len,
+                       mask, pad, rows);
+    VH_CHECK_LAUNCH("vh_softmax_rows");
+    return VH_OK;
+}
+
+extern "C" int vh_softmax_bwd(const float* P, float* dP, int64_t rows, int Tk, float scale, void* stream) {
+    VH_REQUIRE(P && dP && rows >= 0 && Tk > 0, VH_EINVAL, "vh_softmax_bwd: bad args");
+    if (rows == 0) return VH_OK;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, P, dP, Tk, scale, rows);
+    VH_CHECK_LAUNCH("vh_softmax_bwd");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross entropy (F.cross_entropy with mean reduction over ALL rows, valle_ar.py:86), fused with its
+// gradient: loss += (lse - logit[target]) / R ;  dlogits = (softmax - onehot) * grad_scale.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_entropy_kernel(
+    const float* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
+    float* __restrict__ loss, float* __restrict__ dlogits, int ldd, float inv_rows, int rows) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* lr = logits + (int64_t)row * ld;
+    float m = NEG_INF;
+    for (int j = lane; j < V; j += 64) m = fmaxf(m, lr[j]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < V; j += 64) l += expf(lr[j] - m);
+    l = wave_sum(l);
+    const float lse = m + logf(l);
+    const int tgt = (int)target[row];
+    if (lane == 0) atomicAdd(loss, (lse - lr[tgt]) * inv_rows);
+    if (dlogits) {
+        float* dr = dlogits + (int64_t)row * ldd;
+        for (int j = lane; j < V; j += 64) dr[j] = (expf(lr[j] - lse) - (j == tgt ? 1.f : 0.f)) * inv_rows;
+    }
+}
+
+extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
+                                float* dlogits, int ldd, int rows, void* stream) {
+    VH_REQUIRE(logits && target && loss && rows > 0 && V > 0 && ld >= V && (!dlogits || ldd >= V),
+               VH_EINVAL, "vh_cross_entropy: bad args rows=%d V=%d ld=%d", rows, V, ld);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) {
+        vh_set_error("vh_cross_entropy: hipMemsetAsync failed");
+        return VH_ELAUNCH;
+    }
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, ld, V, target,
+                       loss, dlogits, ldd, 1.0f / (float)rows, rows);
+    VH_CHECK_LAUNCH("vh_cross_entropy");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding backward: dtable[ids[b,t]] += dout[b, t0+t, :]   (scatter-add, fp32 atomics)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t ids_bs,
+                                                        int64_t ids_ts, const float* __restrict__ dout,
+                                                        int64_t dout_bs, int t0, float* __restrict__ dtable,
+                                                        int T, int d) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    if (t >= T) return;
+    const int64_t id = ids[b * ids_bs + t * ids_ts];
+    const float* src = dout + b * dout_bs + (int64_t)(t0 + t) * d;
+    float* dst = dtable + id * d;
+    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c]);
+}
+
+extern "C" int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
+                            const float* dout, int64_t dout_bstride, int out_t0, float* dtable, int B,
+                            int T, int d, void* stream) {
+    VH_REQUIRE(ids && dout && dtable && B >= 0 && T >= 0 && d > 0, VH_EINVAL, "vh_embed_bwd: bad args");
+    if (B == 0 || T == 0) return VH_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, ids,
+                       ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, T, d);
+    VH_CHECK_LAUNCH("vh_embed_bwd");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Column sums (bias gradients): out[c] += sum_r x[r, c].   Thread per column, row slabs per block.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, int ld,
+                                                     float* __restrict__ out, int rows, int cols,
+                                                     int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float acc = 0.f;
+    for (int r = r0; r < r1; ++r) acc += x[(int64_t)r * ld + c];
+    atomicAdd(out + c, acc);
+}
+
+extern "C" int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream) {
+    VH_REQUIRE(x && out && rows >= 0 && cols > 0 && ld >= cols, VH_EINVAL, "vh_colsum: bad args");
+    if (rows == 0) return VH_OK;
+    const int rpb = 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0,
+                       (hipStream_t)stream, x, ld, out, rows, cols, rpb);
+    VH_CHECK_LAUNCH("vh_colsum");
+    return VH_OK;
+}

@@ -1,0 +1,75 @@
+"""`train(hparams_fp, model_name)` with the reference's signature (valle/train_model.py:13-35), as a
+plain data-parallel loop: one process per GPU (torch.distributed, RCCL over xGMI), per-rank
+micro-batches, one bucketed mean all-reduce of fp32 gradients per optimizer step (what Lightning's
+implicit DDP does for the reference), global-norm clipping (`gradient_clip_val`), gradient
+accumulation (`grad_accum`), AdamW + CosineAnnealingWarmRestarts from `configure_optimizers`.
+
+The reference's data pipeline (HF dataset + g2p + on-the-fly EnCodec, valle/data.py) is out of
+scope: pass any iterable of collated batches as `batches`, or none to train on seeded synthetic
+batches in the collate wire format.
+"""
+from __future__ import annotations
+
+import argparse
+import time
+from pathlib import Path
+
+import torch
+
+from . import dp, synth
+from .config import ConfigValle
+
+
+def synthetic_batches(model_name, config, rank, world, steps):
+    for i in range(steps):
+        seed = config.seed + 1000 * i + rank
+        if model_name == 'ValleAR':
+            yield synth.synth_ar_batch(config, config.batch_size, seed=seed)
+        else:
+            yield synth.synth_nar_batch(config, config.batch_size, n_tokens=80, n_frames=450, seed=seed)
+
+
+def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=print):
+    from . import get_model_class
+    config = ConfigValle.from_json(hparams_fp) if not isinstance(hparams_fp, ConfigValle) else hparams_fp
+    rank, local, _ = dp.env_world()
+    device = device or torch.device('cuda', local)
+    if device.type == 'cuda':
+        torch.cuda.set_device(device)
+    rank, world = dp.init_distributed(device=device if device.type == 'cuda' else None)
+    torch.manual_seed(config.seed)                       # identical initial weights on every rank
+    model = get_model_class(model_name)(config).to(device).train()
+    opt = model.configure_optimizers()
+    optimizer, scheduler = opt['optimizer'], opt['lr_scheduler']
+    params = [p for p in model.parameters() if p.requires_grad]
+    accum = max(1, config.grad_accum)
+    if batches is None:
+        batches = synthetic_batches(model_name, config, rank, world, config.max_steps * accum)
+    step, t0, losses = 0, time.perf_counter(), []
+    optimizer.zero_grad(set_to_none=True)
+    for i, batch in enumerate(batches):
+        loss = model.training_step(batch)
+        (loss / accum).backward()
+        losses.append(float(loss.detach()))
+        if (i + 1) % accum:
+            continue
+        dp.allreduce_mean_([p.grad for p in params if p.grad is not None])
+        torch.nn.utils.clip_grad_norm_(params, config.gradient_clip_val)
+        optimizer.step()
+        scheduler.step()
+        optimizer.zero_grad(set_to_none=True)
+        step += 1
+        if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
+            log(f'step {step}: train/loss {sum(losses[-accum:]) / accum:.4f} '
+                f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
+        if step >= config.max_steps:
+            break
+    return model, losses
+
+
+if __name__ == '__main__':
+    parser = argparse.ArgumentParser()
+    parser.add_argument('-c', '--config', type=Path, required=True)
+    parser.add_argument('-m', '--model', type=str, choices=['ValleAR', 'ValleNAR'], required=True)
+    args = parser.parse_args()
+    train(args.config, args.model)            # the reference reads args.hparams here and dies (D1)

@@ -92,12 +92,45 @@ class ValleAR(_Base):
         logits = kernels.linear(out, self.proj.weight.detach())
         return logits.reshape(b, ty, -1)
 
+    def _logits_with_graph(self, batch):
+        """The same forward as `forward_logits`, composed from autograd Functions so that
+        `loss.backward()` reaches every parameter (valle_ar.py:61-83)."""
+        from . import autograd as A
+        self._require_layernorm()
+        dev = self.device
+        if dev.type != 'cuda':
+            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
+        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        codes_lens = batch['codes_lens']
+        tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
+        b, d = tokens.shape[0], self.config.d_model
+        xt = A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)
+        xa = A.EmbedSumPeFn.apply(codes[:, :ty], self.audio_position_emb.pe, 0, self.audio_emb.weight)
+        for mod in (self.tokens_position_emb.dropout, ):      # PE dropout p=0.1 is live in train mode (D9)
+            if mod.training and mod.p > 0:
+                xt = mod(xt)
+        if self.audio_position_emb.dropout.training and self.audio_position_emb.dropout.p > 0:
+            xa = self.audio_position_emb.dropout(xa)
+        x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
+        kv_len = (codes_lens.to(torch.int64) + tx).to(device=dev, dtype=torch.int32)
+        spec = dict(mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
+        x = A.transformer_train(self.transformer, x, b, tx + ty, spec)
+        out = x.view(b, tx + ty, d)[:, tx:].reshape(b * ty, d)
+        return A.linear(out, self.proj.weight).reshape(b, ty, -1)
+
     def training_step(self, batch, **kwargs):
-        """valle_ar.py:43-90.  Forward only for now: the loss is computed from HIP logits but
-        carries no autograd graph (backward kernels are a later row of SURVEY.md §8)."""
-        logits = self.forward_logits(batch)
-        target = batch['target'].to(logits.device)
-        loss = torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), target)
+        """valle_ar.py:43-90: mean cross entropy over ALL (B, Ty) positions, pads included.  With
+        grad mode on the loss carries a full autograd graph (HIP forward kernels; backward = HIP
+        row kernels + library GEMMs, valle2_amd/autograd.py); under no_grad it takes the fused
+        inference kernels."""
+        from . import autograd as A
+        target = batch['target'].to(self.device)
+        if torch.is_grad_enabled():
+            logits = self._logits_with_graph(batch)
+        else:
+            logits = self.forward_logits(batch)
+        rows = logits.shape[0] * logits.shape[1]
+        loss = A.CrossEntropyFn.apply(logits.reshape(rows, -1), target[:, : logits.shape[1]].reshape(rows))
         self.log('train/loss', loss)
         return loss
 

@@ -96,13 +96,52 @@ class ValleNAR(_Base):
         logits = kernels.linear(z, self.proj_layers[stage - 1].weight.detach())
         return logits.reshape(b, t - p, -1), p
 
+    def _stage_logits_with_graph(self, batch, stage: int):
+        """`stage_logits` composed from autograd Functions (training path)."""
+        from . import autograd as A
+        dev = self._dev()
+        cfg = self.config
+        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        tx = int(batch['tokens_lens'].max())
+        b, t, q = codes.shape
+        d = cfg.d_model
+        p = self.prefix_len_of(t)
+        parts = [A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)]
+        tabs = [e.weight for e in self.codes_embs]
+        if p:
+            parts.append(A.EmbedSumPeFn.apply(codes[:, :p], self.audio_position_emb.pe, 0, *tabs))
+        if t > p:
+            parts.append(A.EmbedSumPeFn.apply(codes[:, p:], self.audio_position_emb.pe, p,
+                                              *tabs[: max(1, min(stage, q))]))
+        drops = [self.tokens_position_emb.dropout] + [self.audio_position_emb.dropout] * (len(parts) - 1)
+        parts = [dr(x) if (dr.training and dr.p > 0) else x for dr, x in zip(drops, parts)]
+        x = torch.cat(parts, dim=1).reshape(b * (tx + t), d)
+        x = A.transformer_train(self.transformer, x, b, tx + t, dict(mode=kernels.MASK_FULL),
+                                embedding=self.stage_embs[stage - 1].weight)
+        z = x.view(b, tx + t, d)[:, tx + p:].reshape(b * (t - p), d)
+        return A.linear(z, self.proj_layers[stage - 1].weight).reshape(b, t - p, -1), p
+
     def training_step(self, batch, **kwargs):
         """Intended loss: CE of the stage's logits against the raw ids codes[:, prefix:, stage]
-        (the reference slices the embedded tensor, valle_nar.py:81, and raises).  Forward only."""
+        (the reference slices the embedded tensor, valle_nar.py:81, and raises); mean over all
+        positions.  `stage=` pins the stage (the reference draws it with random.randint, :76)."""
+        from . import autograd as A
         stage = kwargs.get('stage') or random.randint(1, self.config.num_quantizers - 1)
-        logits, p = self.stage_logits(batch, stage)
+        if torch.is_grad_enabled():
+            logits, p = self._stage_logits_with_graph(batch, stage)
+        else:
+            logits, p = self.stage_logits(batch, stage)
         target = batch['codes'][:, p:, stage].to(logits.device)
-        return torch.nn.functional.cross_entropy(logits.permute(0, 2, 1), target)
+        rows = logits.shape[0] * logits.shape[1]
+        return A.CrossEntropyFn.apply(logits.reshape(rows, -1), target.reshape(rows))
+
+    def configure_optimizers(self):
+        """The reference's ValleNAR has no configure_optimizers; same recipe as AR."""
+        from torch import optim
+        optimizer = optim.AdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
+                                weight_decay=self.config.weight_decay, fused=self.device.type == 'cuda')
+        scheduler = optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, self.config.lr_warmup)
+        return {'optimizer': optimizer, 'lr_scheduler': scheduler}
 
     @torch.inference_mode()
     def generate(self, prompt_tokens, prompt_codes, target_tokens, target_codes_first_layer,
