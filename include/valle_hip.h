@@ -151,6 +151,20 @@ int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
                    float* x_next, int B, int d, void* stream);
 
+/* ---- K12 (stochastic): temperature / top-k / top-p sampling + the same state update ----------
+ * replaces topk_sampling (valle/models/utils.py:46-68) incl. the published semantics of
+ * transformers==4.38.2 top_k_top_p_filtering (top-k keeps ties of the k-th score, top_k <= 0 keeps
+ * all; top-p drops, from the smallest, entries whose cumulative probability is <= 1 - top_p and
+ * always keeps the largest), torch.multinomial and the log-prob gather; then the bookkeeping of
+ * vh_greedy_step plus sum_logprobs[b] += logprob while row b has not finished (valle_ar.py:167).
+ * Randomness is a counter-based generator keyed on (seed, row, audio_pos[b]) — replaying a captured
+ * graph draws fresh numbers; the stream is NOT torch's, so parity is distributional.  V <= 2048. */
+int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p,
+                   float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
+                   int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
+                   const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
+                   float* x_next, int B, int d, void* stream);
+
 /* ---- composite: one AR decode step / hipGraph replay ----------------------------------------
  * The ~5 launches per layer of one decode step (LN1+QKV+append, decode attention, out-proj+
  * residual, LN2+FFN1+GELU, FFN2+residual) plus head GEMM and vh_greedy_step, enqueued natively
@@ -175,6 +189,11 @@ typedef struct {
     const int32_t *pos_base;          /* (B) or NULL */
     int64_t *codes;                   /* (B, codes_stride) growing code sequence */
     int64_t codes_stride;
+    /* sampling (valle/config.py:48-51): top_k == 1 → vh_greedy_step, else vh_sample_step */
+    int top_k;
+    float top_p, temperature;
+    uint64_t seed;
+    float *sum_logprobs;              /* (B) or NULL */
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

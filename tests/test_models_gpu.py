@@ -188,7 +188,7 @@ def test_ar_generate_eos_golden():
 
 def test_ar_generate_rejects_what_the_reference_cannot_do():
     kw, sd, utt = C.ar_generate_inputs('tiny')
-    m = build('ValleAR', dict(kw, top_k=50), sd)
+    m = build('ValleAR', dict(kw, use_kv_cache=False), sd)       # raises in the reference too (D2)
     with pytest.raises(NotImplementedError):
         m.generate(*[u.to(DEV) for u in utt])
     with pytest.raises(AssertionError):

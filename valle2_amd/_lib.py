@@ -42,6 +42,8 @@ class VhArDecoderDesc(C.Structure):
         ('gemm_ws_bytes', C.c_size_t),
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
+        ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
+        ('sum_logprobs', C.c_void_p),
     ]
 
 
@@ -85,6 +87,9 @@ SIGNATURES = {
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
                                  c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int,
                                  C.c_void_p]),
+    'vh_sample_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
+                                 c_i64p, C.c_int64, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p,
+                                 c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_ar_decoder_create': (C.c_void_p, [C.POINTER(VhArDecoderDesc)]),
     'vh_ar_decoder_destroy': (None, [C.c_void_p]),
     'vh_ar_decoder_step': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -199,3 +199,134 @@ extern "C" int vh_greedy_step(const float* logits, int ldl, int V, int eos, int6
     VH_CHECK_LAUNCH("vh_greedy_step");
     return VH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// K12 (stochastic)  top-k / top-p / temperature sampling (valle/models/utils.py:46-68 with the
+// published transformers==4.38.2 top_k_top_p_filtering semantics), fused with the same decode-state
+// update as greedy_step_kernel.  One 256-thread block per row:
+//   1. scores = logits / temperature into LDS (padded to a power of two with -inf), bitonic sort
+//      descending (ties: lower index first);
+//   2. top-k: keep every score >= the k-th largest (ties kept; top_k <= 0 keeps all);
+//   3. top-p: walking from the smallest kept score, drop entries whose cumulative probability is
+//      <= 1 - top_p, always keeping the largest one;
+//   4. draw from the renormalised kept set with a counter-based RNG keyed on (seed, row, position)
+//      — a captured graph replays with fresh randomness because the position advances;
+//   5. logprob = log p(token) under the filtered distribution; sum_logprobs[b] += logprob while the
+//      row has not finished (valle_ar.py:167).
+// The RNG stream differs from torch.multinomial's (CPU mt19937 / Philox): parity with the reference
+// is distributional, not sample-exact (SURVEY.md §8c "parity unpinned" for top_k > 1).
+// ---------------------------------------------------------------------------------------------
+#define SAMPLE_MAXV 2048
+
+__device__ __forceinline__ float uniform01(uint64_t seed, uint32_t row, uint32_t pos) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (((uint64_t)row << 32) | (uint64_t)(pos + 1u));
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;     // splitmix64 finaliser
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f);   // 24 random bits → [0, 1)
+}
+
+__global__ __launch_bounds__(256) void sample_step_kernel(
+    const float* __restrict__ logits, int ldl, int V, int eos, int top_k, float top_p, float inv_temp,
+    uint64_t seed, int64_t* __restrict__ codes, int64_t codes_stride, int32_t* __restrict__ eos_count,
+    const int32_t* __restrict__ pos_base, float* __restrict__ sum_logprobs,
+    const float* __restrict__ audio_emb, const float* __restrict__ pe, int32_t* __restrict__ audio_pos,
+    int32_t* __restrict__ cache_len, float* __restrict__ x_next, int d, int npow2) {
+    __shared__ float s_val[SAMPLE_MAXV];
+    __shared__ int s_idx[SAMPLE_MAXV];
+    __shared__ int s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lr = logits + (int64_t)b * ldl;
+    for (int i = tid; i < npow2; i += 256) {
+        s_val[i] = i < V ? lr[i] * inv_temp : -INFINITY;
+        s_idx[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow2; i += 256) {
+                const int p = i ^ j;
+                if (p > i) {
+                    const bool desc = (i & k) == 0;
+                    const float a = s_val[i], c = s_val[p];
+                    const int ia = s_idx[i], ic = s_idx[p];
+                    const bool a_first = a > c || (a == c && ia < ic);   // a belongs before c
+                    if (desc ? !a_first : a_first) {
+                        s_val[i] = c; s_val[p] = a; s_idx[i] = ic; s_idx[p] = ia;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    const int pos = audio_pos[b];
+    if (tid == 0) {
+        int n_keep = V;
+        if (top_k > 0) {
+            const float kth = s_val[min(top_k, V) - 1];
+            n_keep = min(top_k, V);
+            while (n_keep < V && s_val[n_keep] >= kth) ++n_keep;         // ties kept
+        }
+        const float m = s_val[0];
+        float total = 0.f;
+        for (int i = 0; i < n_keep; ++i) total += expf(s_val[i] - m);
+        if (top_p >= 0.f && top_p <= 1.f) {                              // drop the low-probability tail
+            const float limit = (1.0f - top_p) * total;
+            float tail = 0.f;
+            int n2 = n_keep;
+            while (n2 > 1) {
+                tail += expf(s_val[n2 - 1] - m);
+                if (tail > limit) break;
+                --n2;
+            }
+            n_keep = n2;
+            total = 0.f;
+            for (int i = 0; i < n_keep; ++i) total += expf(s_val[i] - m);
+        }
+        const float u = uniform01(seed, (uint32_t)b, (uint32_t)pos) * total;
+        float acc = 0.f;
+        int pick = n_keep - 1;
+        for (int i = 0; i < n_keep; ++i) {
+            acc += expf(s_val[i] - m);
+            if (acc > u) { pick = i; break; }
+        }
+        const float logprob = (s_val[pick] - m) - logf(total);
+        int64_t* row = codes + (int64_t)b * codes_stride;
+        int tok = s_idx[pick];
+        const bool finished = row[pos - 1] == (int64_t)eos;
+        if (sum_logprobs && !finished) sum_logprobs[b] += logprob;       // valle_ar.py:167
+        if (finished) tok = eos;                                         // valle_ar.py:168
+        row[pos] = tok;
+        if (tok == eos) atomicAdd(&eos_count[pos - (pos_base ? pos_base[b] : 0)], 1);
+        s_tok = tok;
+    }
+    __syncthreads();
+    const int tok = s_tok;
+    const float* er = audio_emb + (int64_t)tok * d;
+    const float* pr = pe + (int64_t)pos * d;
+    for (int c = tid * 4; c < d; c += 1024) st4(x_next + (int64_t)b * d + c, ld4(er + c) + ld4(pr + c));
+    if (tid == 0) {
+        audio_pos[b] = pos + 1;
+        cache_len[b] += 1;
+    }
+}
+
+extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p,
+                              float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
+                              int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
+                              const float* audio_emb, const float* pe, int32_t* audio_pos,
+                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next,
+               VH_EINVAL, "vh_sample_step: null pointer");
+    VH_REQUIRE(B > 0 && V > 0 && V <= SAMPLE_MAXV && ldl >= V && d > 0 && d % 4 == 0, VH_EINVAL,
+               "vh_sample_step: bad dims B=%d V=%d (<= %d) ldl=%d d=%d", B, V, SAMPLE_MAXV, ldl, d);
+    VH_REQUIRE(temperature > 0.f, VH_EINVAL, "vh_sample_step: temperature must be positive");
+    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next), VH_EALIGN,
+               "vh_sample_step: audio_emb/pe/x_next must be 16-byte aligned");
+    int npow2 = 2;
+    while (npow2 < V) npow2 <<= 1;
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                       eos, top_k, top_p, 1.0f / temperature, seed, codes, codes_stride, eos_count,
+                       pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, d, npow2);
+    VH_CHECK_LAUNCH("vh_sample_step");
+    return VH_OK;
+}

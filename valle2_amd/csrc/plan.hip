@@ -57,6 +57,8 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                    d->logits && d->cache_len && d->audio_pos && d->eos_count && d->codes,
                VH_EINVAL, "vh_ar_decoder: null buffer in desc");
     VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
+    VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
+               "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
     return VH_OK;
 }
 
@@ -116,8 +118,13 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
     TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
                   nullptr, nullptr, nullptr, nullptr, 0.f, s));
-    TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
-                       d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+    if (d.top_k == 1)
+        TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
+                           d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+    else
+        TRY(vh_sample_step(d.logits, dec->ldl, d.V, d.eos, d.top_k, d.top_p, d.temperature, d.seed,
+                           d.codes, d.codes_stride, d.eos_count, d.pos_base, d.sum_logprobs, d.audio_emb,
+                           d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
     return VH_OK;
 }
 

@@ -124,7 +124,7 @@ class ArDecoder:
     per row per step, the whole step enqueued natively and replayed as a hipGraph."""
 
     def __init__(self, model, batch, s_max, codes, cache: KVCache, cache_len, audio_pos, pos_base,
-                 n_split=None, use_graph=True):
+                 n_split=None, use_graph=True, seed=0):
         cfg = model.config
         dev = cache.buf.device
         d, dff, V = cfg.d_model, cfg.dim_feedforward, cfg.num_audio_tokens + 1
@@ -141,6 +141,8 @@ class ArDecoder:
         ws_bytes = _lib.lib().vh_linear_ws_bytes(batch, d, dff)
         self.gemm_ws = torch.empty(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
+        self.sum_logprobs = torch.zeros(batch, **f32)
+        self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
         self._table = layer_table(model.transformer, cache)
@@ -154,7 +156,9 @@ class ArDecoder:
             logits=ptr(self.logits), attn_partial=ptr(self.partial), gemm_ws=ptr(self.gemm_ws),
             gemm_ws_bytes=ws_bytes, cache_len=ptr(cache_len),
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
-            codes=ptr(codes), codes_stride=codes.stride(0))
+            codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
+            temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
+            sum_logprobs=ptr(self.sum_logprobs))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:
@@ -174,8 +178,14 @@ class ArDecoder:
         """Head + greedy step on the last hidden row of a prefill (the tail of step 0)."""
         m = self._keep
         kernels.linear(hidden_last, m[0], out=self.logits[:, : self.V])
-        kernels.greedy_step(self.logits, self.V, self._desc.eos, self.codes, self.eos_count, m[1], m[2],
-                            self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
+        if self.sampling[0] == 1:
+            kernels.greedy_step(self.logits, self.V, self._desc.eos, self.codes, self.eos_count, m[1], m[2],
+                                self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
+        else:
+            top_k, top_p, temp, seed = self.sampling
+            kernels.sample_step(self.logits, self.V, self._desc.eos, top_k, top_p, temp, seed, self.codes,
+                                self.eos_count, self.sum_logprobs, m[1], m[2], self.audio_pos,
+                                self.cache_len, self.x, pos_base=self.pos_base)
 
     def run(self, n_steps):
         """Enqueue n_steps decode steps on the current stream (graph replay when enabled)."""

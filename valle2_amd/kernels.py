@@ -172,3 +172,14 @@ def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cach
         logits.data_ptr(), logits.stride(0), V, eos, ptr(codes), codes.stride(0), ptr(eos_count),
         ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
         stream()), 'vh_greedy_step')
+
+
+def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_count, sum_logprobs, audio_emb,
+                pe, audio_pos, cache_len, x_next, pos_base=None):
+    B = logits.shape[0]
+    d = x_next.shape[1]
+    check(_lib.lib().vh_sample_step(
+        logits.data_ptr(), logits.stride(0), V, eos, int(top_k), float(top_p), float(temperature),
+        int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
+        ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
+        stream()), 'vh_sample_step')

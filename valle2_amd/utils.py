@@ -40,20 +40,36 @@ def pad_lens_for_kernel(padding_mask, x_pad: int, device):
     return (lens + x_pad).to(device=device, dtype=torch.int32)
 
 
-def topk_sampling(logits: Tensor, top_k: int = 50, tok_p: float = 1.0, temperature: float | None = 1.0):
-    """valle/models/utils.py:46-68 → (token (B,1) int64, logprob (B,)).
-
-    On-device implementation of the greedy case only (top_k == 1: the filtered distribution is a
-    one-hot, so the sample is the arg-max with the lowest index on ties and its log-prob is 0).
-    Stochastic top-k/top-p sampling is a listed next row and raises."""
+def topk_sampling(logits: Tensor, top_k: int = 50, tok_p: float = 1.0, temperature: float | None = 1.0,
+                  seed: int | None = None):
+    """valle/models/utils.py:46-68 → (token (B,1) int64, logprob (B,)) on the device: temperature,
+    top-k (ties kept), top-p, multinomial draw and the log-prob of the draw in one kernel
+    (`vh_sample_step`; `top_k == 1` is the arg-max with the lowest index on ties, log-prob 0).
+    The random stream is the kernel's counter-based generator seeded from torch's RNG (or `seed`),
+    not torch.multinomial's, so agreement with the reference is distributional."""
+    from . import kernels
     if not logits.is_cuda:
         raise _lib.VhError('topk_sampling: logits must be on a HIP device (no CPU fallback)')
-    if top_k != 1:
-        raise NotImplementedError('valle2_amd: only greedy sampling (top_k=1) runs on device yet')
-    if temperature is not None and temperature <= 0:
-        raise ValueError('temperature must be positive')
-    token = torch.argmax(logits, dim=-1, keepdim=True)
-    return token, torch.zeros(logits.shape[0], device=logits.device, dtype=logits.dtype)
+    B, V = logits.shape
+    dev = logits.device
+    temperature = 1.0 if temperature is None else float(temperature)
+    lg = logits.float().contiguous()
+    codes = torch.zeros(B, 2, device=dev, dtype=torch.int64)
+    state = dict(eos_count=torch.zeros(4, device=dev, dtype=torch.int32),
+                 audio_pos=torch.ones(B, device=dev, dtype=torch.int32),
+                 cache_len=torch.zeros(B, device=dev, dtype=torch.int32))
+    emb, pe = torch.zeros(V + 1, 4, device=dev), torch.zeros(2, 4, device=dev)
+    x = torch.empty(B, 4, device=dev)
+    lp = torch.zeros(B, device=dev)
+    if top_k == 1:
+        kernels.greedy_step(lg, V, -1, codes, state['eos_count'], emb, pe, state['audio_pos'],
+                            state['cache_len'], x)
+    else:
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        kernels.sample_step(lg, V, -1, top_k, tok_p, temperature, seed, codes, state['eos_count'], lp, emb,
+                            pe, state['audio_pos'], state['cache_len'], x)
+    return codes[:, 1:2].clone(), lp.to(logits.dtype)
 
 
 def get_best_beam(x, sum_logprobs, stop_token, length_penalty=1.0):

@@ -147,8 +147,7 @@ class ValleAR(_Base):
         text = prompt_tokens if target_tokens is None else torch.cat((prompt_tokens, target_tokens), dim=0)
         rows = self.generate_batch([text] * beams, [prompt_codes[..., 0]] * beams)
         # beams → one sequence (valle_ar.py:174-180); with top_k=1 every log-prob is exactly 0
-        dev = rows.device
-        sum_logprobs = torch.zeros(beams, device=dev)
+        sum_logprobs = self.last_generate_stats['sum_logprobs']
         prompt_len = prompt_codes.shape[0] + 1
         best = get_best_beam(rows, sum_logprobs, self.eos_token, self.config.length_penalty)
         best = best[prompt_len:]
@@ -164,8 +163,6 @@ class ValleAR(_Base):
         launch and leaves their mean duration in `last_generate_stats` (measurement only)."""
         self._require_layernorm()
         cfg = self.config
-        if cfg.top_k != 1:
-            raise NotImplementedError('valle2_amd: only greedy decoding (top_k=1) runs on device yet')
         if not cfg.use_kv_cache:
             raise NotImplementedError('use_kv_cache=False is broken in the reference (D2); '
                                       'the HIP path always uses its in-place cache')
@@ -197,7 +194,10 @@ class ValleAR(_Base):
         cache_len = torch.full((B,), s0 - 1, device=dev, dtype=torch.int32)   # +1 by the greedy step
         audio_pos = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
         pos_base = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
-        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph)
+        # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
+        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph,
+                        seed=seed)
         try:
             dec.sample_from(x[:, -1].contiguous())
             del x
@@ -220,7 +220,8 @@ class ValleAR(_Base):
                 stop = int(full[0]) if full.numel() else None
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'attn_mean_ms': attn_ms, 's0': s0}
+                                        'attn_mean_ms': attn_ms, 's0': s0,
+                                        'sum_logprobs': dec.sum_logprobs.clone()}
             return codes[:, : prompt_len + n_new].clone()
         finally:
             dec.close()
