@@ -246,3 +246,25 @@ def test_module_level_errors_are_loud():
         FeedForward(128, 512).to(DEV)(torch.randn(1, 3, 128))       # CPU input
     with pytest.raises(_lib.VhError):
         MultiHeadAttention(128, 4).to(DEV)(torch.randn(1, 3, 128, device=DEV))   # head_dim 32
+
+
+def test_generate_batch_ragged_rows_vs_oracle():
+    """Rows of different text / prompt lengths in one batch (per-row prefix-LM mask, positions,
+    cache lengths): every row must equal the oracle run on that utterance alone."""
+    from oracle import valle_oracle as O
+    from valle2_amd import synth
+    kw = dict(d_model=256, n_heads=4, dim_feedforward=1024, num_layers=3, dropout=0.0,
+              norm='LayerNorm', num_beams=1, top_k=1, max_audio_len=20)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=23, rich=True, std=0.15), cfg)
+    shapes = [(5, 6, 40), (9, 3, 17), (2, 2, 140), (30, 20, 33)]       # (prompt text, target text, frames)
+    utts = [synth.synth_utterance(cfg, a, b, f, seed=700 + i) for i, (a, b, f) in enumerate(shapes)]
+    m = build('ValleAR', kw, sd)
+    rows = m.generate_batch([torch.cat([u[0], u[2]]).to(DEV) for u in utts], [u[1][:, 0].to(DEV) for u in utts])
+    starts = m.last_generate_stats['prompt_lens']
+    assert starts == [f + 1 for _, _, f in shapes] and rows.shape == (4, 141 + 20)
+    for r, u in enumerate(utts):
+        trace = {}
+        ref = O.ar_generate(sd, cfg, *u, trace=trace)
+        tokens_match(rows[r, starts[r]: starts[r] + 20], ref, torch.tensor(trace['margin']))
+        assert torch.equal(rows[r, 1:starts[r]].cpu(), u[1][:, 0]) and int(rows[r, 0]) == cfg.bos_token

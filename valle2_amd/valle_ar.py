@@ -157,8 +157,10 @@ class ValleAR(_Base):
     def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False):
         """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
         texts[b]: 1-D int64 text ids; first_codes[b]: 1-D int64 first-codebook prompt (no BOS).
-        All rows must currently share their lengths.  Returns codes (B, prompt_len + n_new) int64
-        (BOS + prompt + generated, finished rows padded with EOS), on the device.
+        Rows may differ in text and prompt length.  Returns codes (B, max_prompt_len + n_new) int64
+        on the device: row b holds BOS + prompt_b + its n_new generated tokens from index 0 (finished
+        rows and the tail of shorter rows are EOS-filled; `last_generate_stats['prompt_lens'][b]` is
+        where row b's generated tokens start).
         profile_attn=True runs the steps eagerly with HIP events around every decode-attention
         launch and leaves their mean duration in `last_generate_stats` (measurement only)."""
         self._require_layernorm()
@@ -170,37 +172,53 @@ class ValleAR(_Base):
         if dev.type != 'cuda':
             raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
         B = len(texts)
-        tx, tc = int(texts[0].shape[0]), int(first_codes[0].shape[0])
-        if any(t.shape[0] != tx for t in texts) or any(c.shape[0] != tc for c in first_codes):
-            raise NotImplementedError('ragged rows are not supported yet')
+        if B == 0 or len(first_codes) != B:
+            raise ValueError('generate_batch: texts and first_codes must be non-empty lists of equal length')
         max_new = cfg.max_audio_len if max_new is None else max_new
-        prompt_len = tc + 1
-        s0 = tx + prompt_len
+        txs = [int(t.shape[0]) for t in texts]
+        pls = [int(c.shape[0]) + 1 for c in first_codes]                  # BOS + prompt
+        ragged = len(set(txs)) > 1 or len(set(pls)) > 1
+        tx_max, pl_max = max(txs), max(pls)
+        s0 = max(t + p for t, p in zip(txs, pls))                           # longest row's context
         s_max = s0 + max_new
-        if prompt_len + max_new > self.audio_position_emb.pe.shape[0]:
-            raise _lib.VhError('audio length exceeds the positional table (max_len 5000)')
-        text_ids = torch.stack([t.to(dev) for t in texts])
-        codes = torch.full((B, prompt_len + max_new), self.eos_token, device=dev, dtype=torch.int64)
+        if pl_max + max_new > self.audio_position_emb.pe.shape[0] or tx_max > self.tokens_position_emb.pe.shape[0]:
+            raise _lib.VhError('sequence exceeds the positional table (max_len 5000)')
+        codes = torch.full((B, pl_max + max_new), self.eos_token, device=dev, dtype=torch.int64)
         codes[:, 0] = self.bos_token                                   # valle_ar.py:115-117
-        codes[:, 1:prompt_len] = torch.stack([c.to(dev) for c in first_codes])
         d = cfg.d_model
+        i32 = dict(device=dev, dtype=torch.int32)
 
-        # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None)
+        # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None).  Row b is laid
+        # out [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.
         cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev)
-        x = torch.empty(B, s0, d, device=dev, dtype=torch.float32)
-        self._embed_rows(text_ids, codes[:, :prompt_len], x)
-        transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX, x_len=tx,
-                            scratch=ForwardScratch(B * s0, d, cfg.dim_feedforward, dev))
-        cache_len = torch.full((B,), s0 - 1, device=dev, dtype=torch.int32)   # +1 by the greedy step
-        audio_pos = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
-        pos_base = torch.full((B,), prompt_len, device=dev, dtype=torch.int32)
+        if not ragged:
+            text_ids = torch.stack([t.to(dev) for t in texts])
+            codes[:, 1:pl_max] = torch.stack([c.to(dev) for c in first_codes])
+            x = torch.empty(B, s0, d, device=dev, dtype=torch.float32)
+            self._embed_rows(text_ids, codes[:, :pl_max], x)
+            fwd = dict(x_len=txs[0])
+            last = x[:, -1]
+        else:
+            x = torch.zeros(B, s0, d, device=dev, dtype=torch.float32)
+            for b in range(B):
+                codes[b, 1:pls[b]] = first_codes[b].to(dev)
+                self._embed_rows(texts[b].to(dev).unsqueeze(0), codes[b:b + 1, :pls[b]], x[b:b + 1])
+            lens = torch.tensor([t + p for t, p in zip(txs, pls)], **i32)
+            fwd = dict(x_len_dev=torch.tensor(txs, **i32), kv_len=lens)
+        transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
+                            scratch=ForwardScratch(B * s0, d, cfg.dim_feedforward, dev), **fwd)
+        if ragged:
+            last = x[torch.arange(B, device=dev), lens.long() - 1]
+        cache_len = torch.tensor([t + p - 1 for t, p in zip(txs, pls)], **i32)    # +1 by the sample step
+        audio_pos = torch.tensor(pls, **i32)
+        pos_base = audio_pos.clone()
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
         dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph,
                         seed=seed)
         try:
-            dec.sample_from(x[:, -1].contiguous())
-            del x
+            dec.sample_from(last.contiguous())
+            del x, last
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
             done, stop = 1, None
             attn_ms = None
@@ -220,9 +238,9 @@ class ValleAR(_Base):
                 stop = int(full[0]) if full.numel() else None
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'attn_mean_ms': attn_ms, 's0': s0,
+                                        'attn_mean_ms': attn_ms, 's0': s0, 'prompt_lens': pls,
                                         'sum_logprobs': dec.sum_logprobs.clone()}
-            return codes[:, : prompt_len + n_new].clone()
+            return codes[:, : pl_max + n_new].clone()
         finally:
             dec.close()
 
