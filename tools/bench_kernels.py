@@ -41,7 +41,7 @@ def bench_attn():
         bytes_ = 2 * B * S * 512 * 4
         res = {}
         for rnd in range(3):
-            for variant in (1, 2):
+            for variant in (1, 2, 3):
                 for waves in (4, 8, 16):
                     for ns in (1, 2, 4):
                         if waves == 16 and ns > 1 or waves == 4 and ns == 1:

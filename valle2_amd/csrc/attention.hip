@@ -24,7 +24,7 @@
 // =============================================================================================
 #define PART_LD 72  // floats per partial record: o[64], m, l, pad
 
-template <int NW>
+template <int NW, bool NT>
 __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ kc,
     const float* __restrict__ vc, float* __restrict__ out, int ldo,
@@ -56,8 +56,13 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
         for (int i = 0; i < 8; ++i) {
             const int key = key0 + 4 * i;
             const bool in = key < len;
-            kf[i] = in ? ld4(kb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
-            vf[i] = in ? ld4(vb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (NT) {
+                kf[i] = in ? ld4_stream(kb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+                vf[i] = in ? ld4_stream(vb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                kf[i] = in ? ld4(kb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+                vf[i] = in ? ld4(vb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         float s[8];
         float cmax = NEG_INF;
@@ -254,15 +259,18 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
     dim3 grid(n_split, B * n_heads);
     // few workgroups → 16 waves each (one (b,head) can own a whole CU); many → 4 waves each
     const bool big = (int64_t)B * n_heads * n_split < 1024;
-#define AD(KERN, NW)                                                                               \
-    hipLaunchKernelGGL(KERN<NW>, grid, dim3(NW * 64), 0, s, q, ldq, kcache, vcache, out, ldo,      \
+#define AD(KERN, ...)                                                                              \
+    hipLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, q, ldq, kcache, vcache, out, ldo, \
                        cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
     const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
     const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
     const int waves = nw ? nw : (big ? 16 : 4);
-    if (variant != 2) {
-        if (waves == 16) AD(attn_decode_kernel, 16); else if (waves == 8) AD(attn_decode_kernel, 8);
-        else AD(attn_decode_kernel, 4);
+    if (variant == 3) {          // burst kernel with plain (temporal) loads, for A/B runs
+        if (waves == 16) AD(attn_decode_kernel, 16, false); else if (waves == 8) AD(attn_decode_kernel, 8, false);
+        else AD(attn_decode_kernel, 4, false);
+    } else if (variant != 2) {   // default: burst kernel, non-temporal K/V loads
+        if (waves == 16) AD(attn_decode_kernel, 16, true); else if (waves == 8) AD(attn_decode_kernel, 8, true);
+        else AD(attn_decode_kernel, 4, true);
     } else {
         if (waves == 16) AD(attn_decode_pipe_kernel, 16); else if (waves == 8) AD(attn_decode_pipe_kernel, 8);
         else AD(attn_decode_pipe_kernel, 4);

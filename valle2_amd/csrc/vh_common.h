@@ -76,6 +76,11 @@ __device__ __forceinline__ float rows4_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }
 __device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+// streaming (read-once) load: non-temporal hint, so the KV stream does not evict the weights that
+// every decode step re-reads from L2 / Infinity Cache
+__device__ __forceinline__ f32x4 ld4_stream(const float* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+}
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 __device__ __forceinline__ float gelu_erf(float x) {
