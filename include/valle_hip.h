@@ -220,12 +220,13 @@ int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta, cons
                      float* dshift, int rows, int d, float eps, void* stream);
 /* exact-erf GELU on a saved pre-activation: dh == NULL → out = gelu(pre); else out = dh*gelu'(pre) */
 int vh_gelu(const float* pre, const float* dh, float* out, int64_t n, void* stream);
-/* P = softmax(S*scale + mask) in place over rows of (B,h,Tq,Tk); same mask semantics as vh_attn_rows */
-int vh_softmax_rows(float* S, int B, int n_heads, int Tq, int Tk, float scale, int mode, int x_len,
-                    const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+/* P = softmax(S*scale + mask) in place over rows of (B,h,Tq,Tk) with row stride ld >= Tk; same mask
+ * semantics as vh_attn_rows */
+int vh_softmax_rows(float* S, int ld, int B, int n_heads, int Tq, int Tk, float scale, int mode,
+                    int x_len, const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
                     const uint8_t* pad, void* stream);
-/* dS = scale * P o (dP - rowsum(dP o P)), in place on dP */
-int vh_softmax_bwd(const float* P, float* dP, int64_t rows, int Tk, float scale, void* stream);
+/* dS = scale * P o (dP - rowsum(dP o P)), in place on dP (both with row stride ld) */
+int vh_softmax_bwd(const float* P, float* dP, int ld, int64_t rows, int Tk, float scale, void* stream);
 /* mean cross entropy over `rows` rows of (rows, V) logits (F.cross_entropy, valle_ar.py:86):
  * *loss = mean(lse - logit[target]); dlogits (may be NULL) = (softmax - onehot) / rows */
 int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
@@ -235,6 +236,19 @@ int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, c
                  int64_t dout_bstride, int out_t0, float* dtable, int B, int T, int d, void* stream);
 /* bias gradient: out[c] += sum_r x[r, c] */
 int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
+
+/* General batched fp32 GEMM of the backward pass: C[b,h] = op(A[b,h]) . op(B[b,h]) on the fp32 matrix
+ * cores (128x128x32 tiles).  a_kmajor = 0: A stored (M,K) k contiguous; 1: stored (K,M) m contiguous.
+ * b_kmajor = 0: B stored (N,K) (an nn.Linear weight as stored); 1: stored (K,N).  C is (M,N) ldc.
+ * Two-level batch index (b < batch, h < H) with element strides, so attention operands are read in
+ * place from (B,T,h,64) / (B,h,T,64) / (B,h,T,T) tensors.  Leading dimensions and strides must be
+ * multiples of 4; ragged M/N/K are guarded (buffers padded to the leading dimension).
+ * k_splits > 1 cuts K into that many slices handled by separate workgroups whose partial tiles are
+ * ADDED to C with fp32 atomics (the caller zeroes C; summation order is not fixed) — for weight
+ * gradients, where the output is a few tiles and K is the whole token count. */
+int vh_gemm_batched(const float* A, int lda, int64_t sAb, int64_t sAh, int a_kmajor, const float* B,
+                    int ldb, int64_t sBb, int64_t sBh, int b_kmajor, float* C, int ldc, int64_t sCb,
+                    int64_t sCh, int M, int N, int K, int batch, int H, int k_splits, void* stream);
 
 /* ---- composite: full-sequence transformer forward (prefill / NAR stage / training forward) --
  * valle/models/modules.py:305-352 without cache input: x (B*T, d) in/out in place, every

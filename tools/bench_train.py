@@ -1,0 +1,62 @@
+"""Training-step timing at BASELINE.json configs[3]: 12L/512d AR and NAR forward+backward, per-GPU
+batch 16, LibriTTS-shaped synthetic batches (tokens 40..120, codes 225..900), fp32.  Developer tool
+(the graded bench is bench.py); under torch.distributed.run it averages gradients over RCCL.
+usage: python tools/bench_train.py [steps=5]"""
+import os
+import sys
+import tempfile
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from valle2_amd import ConfigValle, dp, get_model_class, synth  # noqa: E402
+
+
+def main(steps=5):
+    os.chdir(tempfile.mkdtemp())
+    rank, local, world = dp.env_world()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    dp.init_distributed('nccl', dev)
+    for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
+        cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm=norm,
+                          batch_size=16)
+        torch.manual_seed(0)
+        model = get_model_class(name)(cfg).to(dev).train()
+        opt = model.configure_optimizers()['optimizer']
+        params = [p for p in model.parameters() if p.requires_grad]
+        times, phases = [], []
+        for i in range(steps + 2):
+            if name == 'ValleAR':
+                batch = synth.synth_ar_batch(cfg, 16, seed=100 + i + 1000 * rank)
+            else:
+                batch = synth.synth_nar_batch(cfg, 16, n_tokens=80, n_frames=560, seed=100 + i + 1000 * rank)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = model.training_step(batch, **({'stage': 1 + i % 7} if name == 'ValleNAR' else {}))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            loss.backward()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            dp.allreduce_mean_([p.grad for p in params if p.grad is not None])
+            torch.nn.utils.clip_grad_norm_(params, cfg.gradient_clip_val)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            if i >= 2:
+                times.append(t3 - t0)
+                phases.append((t1 - t0, t2 - t1, t3 - t2))
+        if rank == 0:
+            f, b, o = (sum(p[k] for p in phases) / len(phases) * 1e3 for k in range(3))
+            rows = batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])
+            print(f'{name}: {sum(times) / len(times) * 1e3:.1f} ms/step (fwd {f:.1f}, bwd {b:.1f}, '
+                  f'allreduce+clip+AdamW {o:.1f}) world={world} last batch rows={rows} loss={float(loss):.3f} '
+                  f'peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
+
+
+if __name__ == '__main__':
+    main(*[int(a.split('=')[1]) for a in sys.argv[1:]])

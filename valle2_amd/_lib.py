@@ -100,14 +100,17 @@ SIGNATURES = {
     'vh_layernorm_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                    c_f32p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'vh_gelu': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
-    'vh_softmax_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int,
-                                  c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
-    'vh_softmax_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
+    'vh_softmax_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                  C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
+    'vh_softmax_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     'vh_cross_entropy': (C.c_int, [c_f32p, C.c_int, C.c_int, c_i64p, c_f32p, c_f32p, C.c_int, C.c_int,
                                    C.c_void_p]),
     'vh_embed_bwd': (C.c_int, [c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int,
                                C.c_int, C.c_int, C.c_void_p]),
     'vh_colsum': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    'vh_gemm_batched': (C.c_int, [c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64,
+                                  C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_transformer_forward': (C.c_int, [C.POINTER(VhForwardDesc), C.c_void_p]),
 }
 

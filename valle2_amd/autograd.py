@@ -2,9 +2,9 @@
 
 Forward passes run the same HIP kernels as inference.  Backward passes pair hand-written HIP
 kernels for every non-GEMM op (LayerNorm/AdaLN, GELU, softmax, cross entropy, embedding scatter,
-bias column sums — csrc/train.hip) with library GEMMs for the plain matrix products
-(`torch.matmul` → rocBLAS/hipBLASLt: dX = dY·W, dW = dYᵀ·X and the attention products on
-recomputed probabilities).  Nothing here runs on the CPU.
+bias column sums — csrc/train.hip) with the plain matrix products (dX = dY·W, dW = dYᵀ·X and the
+attention products on recomputed probabilities), which run either as library GEMMs or on the
+hand-written `vh_gemm_batched` (see BACKWARD_GEMM).  Nothing here runs on the CPU.
 """
 from __future__ import annotations
 
@@ -15,9 +15,38 @@ from ._lib import check, ptr, stream
 
 HEAD_DIM = kernels.HEAD_DIM
 
+# Engine of the PLAIN backward matrix products (dX = dY·W, dW = dYᵀ·X, the five attention products):
+#   'library' — rocBLAS / hipBLASLt through torch.matmul (default: these are unfused library GEMMs,
+#               measured 105-146 TFLOP/s fp32 on the training shapes);
+#   'hip'     — the hand-written vh_gemm_batched (92-124 TFLOP/s; reads the strided attention views
+#               in place and writes gradients straight into the (B*T, 3d) buffer).
+# Both pass the same gradient-parity tests; tools/bench_gemm_bwd.py holds the A/B.
+BACKWARD_GEMM = 'library'
+
+
+def _mm(a, b, out, a_kmajor=False, b_kmajor=False):
+    """out = op(a) @ op(b) with the operand-storage convention of kernels.gemm."""
+    if BACKWARD_GEMM == 'hip':
+        return kernels.gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
+    left = a.transpose(-1, -2) if a_kmajor else a
+    right = b if b_kmajor else b.transpose(-1, -2)
+    out.copy_(torch.matmul(left, right))
+    return out
+
 
 def _zeros_like(t):
     return torch.zeros_like(t, memory_format=torch.contiguous_format)
+
+
+def _ld4(t):
+    """A 2-D view of `t` whose row stride is a multiple of 4 floats (16-B loads in vh_gemm_batched);
+    copies into a padded buffer only for ragged widths such as the 1025-wide logits."""
+    if t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    rows, cols = t.shape
+    buf = torch.zeros(rows, (cols + 3) // 4 * 4, device=t.device, dtype=t.dtype)
+    buf[:, :cols] = t
+    return buf[:, :cols]
 
 
 class LinearFn(torch.autograd.Function):
@@ -38,9 +67,12 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = torch.matmul(dy, w) if ctx.needs_input_grad[0] else None
-        dw = torch.matmul(dy.t(), x) if ctx.needs_input_grad[1] else None
+        dy = _ld4(dy)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:      # dX = dY . W        (W stored (N,K) = (k_gemm, n_gemm): k-major B)
+            dx = _mm(dy, w, torch.empty_like(x), b_kmajor=True)
+        if ctx.needs_input_grad[1]:      # dW = dY^T . X      (both operands stored with the token index as rows)
+            dw = _mm(dy, x, torch.empty_like(w), a_kmajor=True, b_kmajor=True)
         db = None
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = torch.zeros(w.shape[0], device=dy.device, dtype=torch.float32)
@@ -126,25 +158,28 @@ class QkvAttentionFn(torch.autograd.Function):
         d = h * HEAD_DIM
         spec = ctx.spec
         scale = HEAD_DIM ** -0.5
-        qh = q.view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)               # (B,h,T,64) view
+        L = _lib.lib()
+        tp = (T + 3) // 4 * 4                                              # row stride of the (T,T) maps
+        qh = q.view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)               # (B,h,T,64) views, read in place
         do = dout.contiguous().view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)
-        P = torch.matmul(qh, k.transpose(-1, -2)).contiguous()           # raw scores (B,h,T,T)
-        check(_lib.lib().vh_softmax_rows(ptr(P), B, h, T, T, scale, spec['mode'], spec.get('x_len', 0),
-                                         ptr(spec.get('x_len_dev')), ptr(spec.get('kv_len')),
-                                         ptr(spec.get('mask')), ptr(spec.get('pad')), stream()),
-              'vh_softmax_rows')
-        dv = torch.matmul(P.transpose(-1, -2), do)                       # (B,h,T,64)
-        dP = torch.matmul(do, v.transpose(-1, -2)).contiguous()          # (B,h,T,T)
-        check(_lib.lib().vh_softmax_bwd(ptr(P), ptr(dP), B * h * T, T, scale, stream()), 'vh_softmax_bwd')
-        dq = torch.matmul(dP, k)                                         # (B,h,T,64)
-        dk = torch.matmul(dP.transpose(-1, -2), qh)
         dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
-        dview = dqkv.view(B, T, 3, h, HEAD_DIM)
-        dview[:, :, 0].copy_(dq.permute(0, 2, 1, 3))
-        dview[:, :, 1].copy_(dk.permute(0, 2, 1, 3))
-        dview[:, :, 2].copy_(dv.permute(0, 2, 1, 3))
-        dx = torch.matmul(dqkv, wqkv) if ctx.needs_input_grad[0] else None
-        dw = torch.matmul(dqkv.t(), x) if ctx.needs_input_grad[1] else None
+        dq, dk, dv = (dqkv.view(B, T, 3, h, HEAD_DIM)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        _mm(qh, k, P)                                                     # S = Q K^T (raw scores)
+        check(L.vh_softmax_rows(P.data_ptr(), tp, B, h, T, T, scale, spec['mode'], spec.get('x_len', 0),
+                                ptr(spec.get('x_len_dev')), ptr(spec.get('kv_len')), ptr(spec.get('mask')),
+                                ptr(spec.get('pad')), stream()), 'vh_softmax_rows')
+        _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                      # dV = P^T dO   → dqkv[:, 2d:]
+        _mm(do, v, dP)                                                    # dP = dO V^T
+        check(L.vh_softmax_bwd(P.data_ptr(), dP.data_ptr(), tp, B * h * T, T, scale, stream()), 'vh_softmax_bwd')
+        _mm(dP, k, dq, b_kmajor=True)                                     # dQ = dS K     → dqkv[:, :d]
+        _mm(dP, qh, dk, a_kmajor=True, b_kmajor=True)                     # dK = dS^T Q   → dqkv[:, d:2d]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _mm(dqkv, wqkv, torch.empty_like(x), b_kmajor=True)
+        if ctx.needs_input_grad[1]:
+            dw = _mm(dqkv, x, torch.empty_like(wqkv), a_kmajor=True, b_kmajor=True)
         return dx, dw, None, None, None, None
 
 

@@ -174,7 +174,7 @@ extern "C" int vh_gelu(const float* pre, const float* dh, float* out, int64_t n,
 __global__ __launch_bounds__(256) void softmax_rows_kernel(
     float* __restrict__ S, int n_heads, int Tq, int Tk, float scale, int mode, int x_len,
     const int32_t* __restrict__ x_len_dev, const int32_t* __restrict__ kv_len,
-    const uint8_t* __restrict__ mask, const uint8_t* __restrict__ pad, int64_t rows) {
+    const uint8_t* __restrict__ mask, const uint8_t* __restrict__ pad, int64_t rows, int ld) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(
     const int kvl = kv_len ? min(kv_len[b], Tk) : Tk;
     const int xl = x_len_dev ? x_len_dev[b] : x_len;
     const int qpos = Tk - Tq + i;
-    float* sr = S + row * Tk;
+    float* sr = S + row * ld;
     auto visible = [&](int j) {
         if (mode == VH_MASK_EXPLICIT) return !mask[(int64_t)i * Tk + j] && !(pad && pad[(int64_t)b * Tk + j]);
         bool v = j < kvl;
@@ -208,38 +208,40 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(
 
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P,
                                                           float* __restrict__ dP, int Tk, float scale,
-                                                          int64_t rows) {
+                                                          int64_t rows, int ld) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const float* pr = P + row * Tk;
-    float* dr = dP + row * Tk;
+    const float* pr = P + row * ld;
+    float* dr = dP + row * ld;
     float acc = 0.f;
     for (int j = lane; j < Tk; j += 64) acc += pr[j] * dr[j];
     acc = wave_sum(acc);
     for (int j = lane; j < Tk; j += 64) dr[j] = scale * pr[j] * (dr[j] - acc);
 }
 
-extern "C" int vh_softmax_rows(float* S, int B, int n_heads, int Tq, int Tk, float scale, int mode,
+extern "C" int vh_softmax_rows(float* S, int ld, int B, int n_heads, int Tq, int Tk, float scale, int mode,
                                int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
                                const uint8_t* mask, const uint8_t* pad, void* stream) {
-    VH_REQUIRE(S && B >= 0 && n_heads > 0 && Tq >= 0 && Tk >= Tq, VH_EINVAL, "vh_softmax_rows: bad args");
+    VH_REQUIRE(S && B >= 0 && n_heads > 0 && Tq >= 0 && Tk >= Tq && ld >= Tk, VH_EINVAL,
+               "vh_softmax_rows: bad args");
     VH_REQUIRE(mode == VH_MASK_FULL || mode == VH_MASK_PREFIX || (mode == VH_MASK_EXPLICIT && mask),
                VH_EINVAL, "vh_softmax_rows: mode=%d", mode);
     const int64_t rows = (int64_t)B * n_heads * Tq;
     if (rows == 0) return VH_OK;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, S, n_heads, Tq, Tk, scale, mode, x_len, x_len_dev, kv_len,
-                       mask, pad, rows);
+                       mask, pad, rows, ld);
     VH_CHECK_LAUNCH("vh_softmax_rows");
     return VH_OK;
 }
 
-extern "C" int vh_softmax_bwd(const float* P, float* dP, int64_t rows, int Tk, float scale, void* stream) {
-    VH_REQUIRE(P && dP && rows >= 0 && Tk > 0, VH_EINVAL, "vh_softmax_bwd: bad args");
+extern "C" int vh_softmax_bwd(const float* P, float* dP, int ld, int64_t rows, int Tk, float scale,
+                              void* stream) {
+    VH_REQUIRE(P && dP && rows >= 0 && Tk > 0 && ld >= Tk, VH_EINVAL, "vh_softmax_bwd: bad args");
     if (rows == 0) return VH_OK;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, P, dP, Tk, scale, rows);
+                       (hipStream_t)stream, P, dP, Tk, scale, rows, ld);
     VH_CHECK_LAUNCH("vh_softmax_bwd");
     return VH_OK;
 }

@@ -183,3 +183,39 @@ def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_coun
         int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
         ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
         stream()), 'vh_sample_step')
+
+
+def gemm(a, b, out, a_kmajor=False, b_kmajor=False):
+    """out = op(a) @ op(b) through vh_gemm_batched.  a, b, out are 2-D (rows, cols) or 4-D
+    (batch, heads, rows, cols) tensors / views with unit stride in the last dimension:
+      a_kmajor=False: a is (M, K);  True: a is stored (K, M)   (the left operand transposed)
+      b_kmajor=False: b is (N, K) as an nn.Linear weight;  True: b is stored (K, N)
+    out is (M, N).  Strides are taken from the tensors, so permuted views are read in place."""
+    def spec(t):
+        if t.dim() == 2:
+            return t.shape[0], t.shape[1], t.stride(0), 0, 0, 1, 1
+        if t.dim() == 4:
+            return t.shape[2], t.shape[3], t.stride(2), t.stride(0), t.stride(1), t.shape[0], t.shape[1]
+        raise _lib.VhError('gemm: operands must be 2-D or 4-D')
+    for t in (a, b, out):
+        if t.stride(-1) != 1 or t.dtype != torch.float32:
+            raise _lib.VhError('gemm: fp32 operands with unit stride in the last dimension required')
+    ar, ac, lda, sab, sah, nb, nh = spec(a)
+    br, bc, ldb, sbb, sbh, nb2, nh2 = spec(b)
+    cr, cc, ldc, scb, sch, nb3, nh3 = spec(out)
+    M, K = (ac, ar) if a_kmajor else (ar, ac)
+    N, K2 = (bc, br) if b_kmajor else (br, bc)
+    if K != K2 or (cr, cc) != (M, N) or (nb, nh) != (nb2, nh2) or (nb, nh) != (nb3, nh3):
+        raise _lib.VhError(f'gemm: shape mismatch a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)}')
+    # few output tiles but a long K (weight gradients: K = every token of the batch): split K over
+    # more workgroups; their partial tiles are summed into a zeroed `out` with fp32 atomics
+    tiles = -(-M // 128) * -(-N // 128) * nb * nh
+    splits = 1
+    if tiles < 256 and K >= 2048:
+        splits = max(1, min(32, 512 // tiles, K // 512))
+    if splits > 1:
+        out.zero_()
+    check(_lib.lib().vh_gemm_batched(a.data_ptr(), lda, sab, sah, int(a_kmajor), b.data_ptr(), ldb, sbb, sbh,
+                                     int(b_kmajor), out.data_ptr(), ldc, scb, sch, M, N, K, nb, nh, splits,
+                                     stream()), 'vh_gemm_batched')
+    return out
