@@ -112,6 +112,25 @@ int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int 
                   int S_max, const float* ln_gamma, const float* ln_beta, const float* ada_scale,
                   const float* ada_shift, float ln_eps, void* stream);
 
+/* ---- LayerNorm folded into the weights (decode path, M <= 64) -------------------------------
+ * The LayerNorm in front of a Linear (valle/models/modules.py:271 norm1 → qkv, :278 norm2 →
+ * linear_1) is rewritten so the products do not wait for the row statistics:
+ *   LN(x) W^T + b = rstd * (x Wf^T - mean * c1) + c2,
+ *   Wf = W * gamma (per input column), c1[n] = sum_k Wf[n,k], c2[n] = sum_k beta[k] W[n,k] + b[n].
+ * vh_ln_fold prepares Wf (N,K), c1 (N), c2 (N) once per weight set (bias may be NULL);
+ * vh_linear_folded / vh_linear_qkv_folded are vh_linear / vh_linear_qkv with (Wf, c1, c2) in
+ * place of (W, bias, ln_gamma, ln_beta): mean / rstd are computed beside the products and applied
+ * in the epilogue.  Supported: M <= 64, N % 16 == 0, K in {128, 256, 512, 1024}. */
+int vh_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias, float* Wf,
+               float* c1, float* c2, int N, int K, void* stream);
+int vh_linear_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                     const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
+                     int act, float ln_eps, void* stream);
+int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                         float* q_out, int ldq, float* kcache, float* vcache,
+                         const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
+                         float ln_eps, void* stream);
+
 /* ---- K7+K8a: multi-row attention (prefill / NAR / training forward) -------------------------
  * replaces merge_masks + F.scaled_dot_product_attention (valle/models/modules.py:160-167,
  * 175-207).  q (B,Tq,ldq) heads at columns head*64; K/V from the cache layout (B,h,S_max,64);
@@ -173,6 +192,9 @@ int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, floa
 typedef struct {
     const float *ln1_g, *ln1_b, *wqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
     float *kcache, *vcache;           /* this layer's (B,h,S_max,64) caches */
+    /* optional vh_ln_fold outputs for (ln1, wqkv) and (ln2, w1, b1); all NULL → LayerNorm applied in
+     * the operand load from ln*_g / ln*_b.  Used by the decode step only. */
+    const float *wqkv_f, *qkv_c1, *qkv_c2, *w1_f, *w1_c1, *w1_c2;
 } vh_layer;
 
 typedef struct {

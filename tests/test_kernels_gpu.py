@@ -154,6 +154,61 @@ def test_linear_fused_layernorm(K, M, ada):
     close(K.linear(a.to(DEV), w.to(DEV), ln=ln), ref, atol=5e-5)
 
 
+@pytest.mark.parametrize('M,N,K_,act', [(3, 96, 128, 0), (32, 2048, 512, 1), (32, 1536, 512, 0), (64, 64, 1024, 1),
+                                        (17, 512, 256, 0)])
+def test_linear_folded_layernorm(K, M, N, K_, act):
+    """LN(x) W^T + b rebuilt as rstd (x Wf^T - mean c1) + c2 (vh_ln_fold + vh_linear_folded)."""
+    a = 2.0 * torch.randn(M, K_, generator=g(9)) + 0.5
+    a[0] += 3.0                                            # a row whose mean exceeds its deviation
+    w = 0.1 * torch.randn(N, K_, generator=g(10))
+    gm, bt = 1 + 0.1 * torch.randn(K_, generator=g(11)), 0.1 * torch.randn(K_, generator=g(12))
+    bias, res = torch.randn(N, generator=g(13)), torch.randn(M, N, generator=g(14))
+    ref = F.linear(F.layer_norm(a.double(), (K_,), gm.double(), bt.double(), 1e-5), w.double(), bias.double())
+    ref = ((F.gelu(ref) if act else ref) + res.double()).float()
+    folded = K.ln_fold(w.to(DEV), gm.to(DEV), bt.to(DEV), bias.to(DEV))
+    torch.testing.assert_close(folded[0].cpu(), w * gm, atol=0, rtol=0)
+    torch.testing.assert_close(folded[1].cpu(), (w * gm).double().sum(1).float(), atol=1e-6, rtol=1e-6)
+    torch.testing.assert_close(folded[2].cpu(), (w.double() @ bt.double() + bias.double()).float(), atol=1e-6, rtol=1e-6)
+    resd = res.to(DEV)
+    out = K.linear_folded(a.to(DEV), folded, residual=resd, out=resd, act=act)
+    close(out, ref, atol=5e-5)
+    # and it agrees with the operand-load LayerNorm kernel to the same tolerance
+    ln = (gm.to(DEV), bt.to(DEV), None, None, 1e-5)
+    close(K.linear(a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV), act=act, ln=ln), ref, atol=5e-5)
+
+
+def test_linear_folded_rejects_unsupported_shapes(K):
+    from valle2_amd._lib import VhError
+    w = torch.randn(96, 384, device=DEV)
+    folded = K.ln_fold(w, torch.ones(384, device=DEV), torch.zeros(384, device=DEV))
+    with pytest.raises(VhError, match='folded LayerNorm'):
+        K.linear_folded(torch.randn(4, 384, device=DEV), folded)
+    w = torch.randn(96, 512, device=DEV)
+    folded = K.ln_fold(w, torch.ones(512, device=DEV), torch.zeros(512, device=DEV))
+    with pytest.raises(VhError, match='folded LayerNorm'):
+        K.linear_folded(torch.randn(65, 512, device=DEV), folded)
+
+
+def test_linear_qkv_folded_scatter(K):
+    B, h, S_max = 5, 4, 20
+    d = 64 * h
+    x = torch.randn(B, d, generator=g(62)) + 0.3
+    w = 0.1 * torch.randn(3 * d, d, generator=g(61))
+    gm, bt = 1 + 0.2 * torch.randn(d, generator=g(63)), 0.2 * torch.randn(d, generator=g(64))
+    ref1 = F.linear(F.layer_norm(x, (d,), gm, bt, 1e-5), w)
+    kc = torch.zeros(B, h, S_max, 64, device=DEV)
+    vc = torch.zeros_like(kc)
+    qo = torch.empty(B, d, device=DEV)
+    cl = torch.tensor([3, 11, 0, 19, 7], dtype=torch.int32)
+    folded = K.ln_fold(w.to(DEV), gm.to(DEV), bt.to(DEV))
+    K.linear_qkv_folded(x.to(DEV), folded, qo, kc, vc, B, 1, h, cache_len=cl.to(DEV))
+    close(qo, ref1[:, :d], atol=5e-5)
+    for b in range(B):
+        close(kc[b, :, int(cl[b])], ref1[b, d:2 * d].view(h, 64), atol=5e-5)
+        close(vc[b, :, int(cl[b])], ref1[b, 2 * d:].view(h, 64), atol=5e-5)
+    assert int((kc != 0).any(-1).sum()) == B * h       # exactly one row per (b, head) written
+
+
 @pytest.mark.parametrize('rows,d', [(1, 128), (37, 512), (5, 1024), (3, 2048), (9, 132)])
 def test_layernorm(K, rows, d):
     x = 3 * torch.randn(rows, d, generator=g(15)) + 1

@@ -31,7 +31,7 @@ int main() {
 
     const int M = 32;
     struct Case { const char* name; int N, K; bool ln; } cases[] = {
-        {"qkv+ln", 1536, 512, true}, {"out-proj", 512, 512, false}, {"ffn1+ln", 2048, 512, true}, {"ffn2", 512, 2048, false}};
+        {"qkv+ln", 1536, 512, true}, {"qkv-noln", 1536, 512, false}, {"ffn1-noln", 2048, 512, false}, {"out-proj", 512, 512, false}, {"ffn1+ln", 2048, 512, true}, {"ffn2", 512, 2048, false}};
     for (auto& c : cases) {
         float *A, *W, *O, *g, *b; long long* dbg;
         CK(hipMalloc(&A, M * c.K * 4)); CK(hipMalloc(&W, (size_t)c.N * c.K * 4)); CK(hipMalloc(&O, M * c.N * 4));

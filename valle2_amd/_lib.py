@@ -27,7 +27,7 @@ class VhError(RuntimeError):
 class VhLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'ln1_g', 'ln1_b', 'wqkv', 'wo', 'bo', 'ln2_g', 'ln2_b', 'w1', 'b1', 'w2', 'b2',
-        'kcache', 'vcache')]
+        'kcache', 'vcache', 'wqkv_f', 'qkv_c1', 'qkv_c2', 'w1_f', 'w1_c1', 'w1_c2')]
 
 
 class VhArDecoderDesc(C.Structure):
@@ -78,6 +78,13 @@ SIGNATURES = {
     'vh_linear_qkv': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, c_f32p, c_i32p,
                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p,
                                 c_f32p, C.c_float, C.c_void_p]),
+    'vh_ln_fold': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                             C.c_void_p]),
+    'vh_linear_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
+                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
+                                       c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_float, C.c_void_p]),
     'vh_attn_rows': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
                                c_u8p, C.c_void_p]),

@@ -563,7 +563,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 // loads, DPP reductions, LayerNorm statistics for 4 rows per wave at once (one DPP row per
 // activation row, NJ float4 per lane) and a single LDS reduction.
 // =============================================================================================
-template <int MT, int NW, int EPI, int PW, bool LN, int NJ>
+// LN: 0 = none; 1 = rows normalised in the operand load (statistics first, then the products);
+//     2 = folded (vh_ln_fold): the products run on the raw rows against W∘gamma while the statistics
+//         are computed beside them, and the epilogue applies rstd·(acc − mean·c1) + c2 — no
+//         statistics → normalise → MFMA dependency, one workgroup barrier instead of two.
+template <int MT, int NW, int EPI, int PW, int LN, int NJ>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
@@ -575,8 +579,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     const float* xp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xp[mt] = a.A + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
-    const float* gp = LN ? ln.gamma + koff : nullptr;
-    const float* bp = LN ? ln.beta + koff : nullptr;
+    const float* gp = LN == 1 ? ln.gamma + koff : nullptr;
+    const float* bp = LN == 1 ? ln.beta + koff : nullptr;
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
     auto issue = [&](int kbase) {
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             wf[c] = ld4(wp + kbase + 16 * c);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
-            if (LN) {
+            if (LN == 1) {
                 gm[c] = ld4(gp + kbase + 16 * c);
                 bt[c] = ld4(bp + kbase + 16 * c);
             }
@@ -626,10 +630,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     // dependent memory round trip to a kernel that is nothing but round trips.
     const int em = w * 16 + i, en = n0 + 4 * g;
     const bool fin = w < MT && em < a.M && en + 3 < a.N;
-    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_res = {0.f, 0.f, 0.f, 0.f};
+    f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_res = {0.f, 0.f, 0.f, 0.f}, e_c1 = {0.f, 0.f, 0.f, 0.f};
     int e_pos = 0;
     if (fin) {
-        if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
+        if (LN == 2) {                       // c2 carries the bias
+            e_c1 = ld4(ln.c1 + en);
+            e_bias = ld4(ln.c2 + en);
+        } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
         if (EPI == EPI_PLAIN && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
     }
@@ -644,6 +651,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             ln_load(r0);
             ln_reduce(r0);
         }
+    }
+    if (LN == 1) {
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -660,7 +669,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     const int pass_stride = NW * PW * 16;
 #pragma unroll 1
     for (int kbase = 0;;) {
-        if (LN) {
+        if (LN == 1) {
 #pragma unroll
             for (int c = 0; c < PW; ++c)
 #pragma unroll
@@ -694,6 +703,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         f32x4 sacc = ld4(&red[0][mt][lane][0]);
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) sacc += ld4(&red[ww][mt][lane][0]);
+        if (LN == 2 && fin) {                // statistics were published before the barrier above
+            const float mu = s_mean[em], rs = s_rstd[em];
+            sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
+            if (EPI == EPI_QKV) sacc += e_bias;
+        }
         if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
@@ -801,7 +815,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
         const bool wide = a.K > 1024;
-        const bool has_ln = ln.gamma != nullptr;
+        const bool has_ln = ln.gamma != nullptr || ln.c1 != nullptr;
+        const bool fold = ln.c1 != nullptr;
         // ---- compact fast path: K = 16*NW*PW*passes
 #define SF(MT, NW, PW, LN, NJ) \
     hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, a, ln)
@@ -814,21 +829,29 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         return VH_OK;                                                          \
     } while (0)
         if (has_ln) {  // K <= 1024 (check_gemm); statistics need K = 64*NJ
-            if (a.K == 128) SF_MT(8, 1, true, 2);
-            if (a.K == 256) SF_MT(8, 2, true, 4);
-            if (a.K == 512) SF_MT(8, 4, true, 8);
-            if (a.K == 1024) SF_MT(8, 4, true, 16);
+            if (fold) {
+                if (a.K == 128) SF_MT(8, 1, 2, 2);
+                if (a.K == 256) SF_MT(8, 2, 2, 4);
+                if (a.K == 512) SF_MT(8, 4, 2, 8);
+                if (a.K == 1024) SF_MT(8, 4, 2, 16);
+                vh_set_error("%s: folded LayerNorm needs K in {128,256,512,1024} (K=%d)", name, a.K);
+                return VH_EUNSUPPORTED;
+            }
+            if (a.K == 128) SF_MT(8, 1, 1, 2);
+            if (a.K == 256) SF_MT(8, 2, 1, 4);
+            if (a.K == 512) SF_MT(8, 4, 1, 8);
+            if (a.K == 1024) SF_MT(8, 4, 1, 16);
         } else if (!wide) {
-            if (a.K % 512 == 0) SF_MT(8, 4, false, 1);
-            if (a.K % 256 == 0) SF_MT(8, 2, false, 1);
-            if (a.K % 128 == 0) SF_MT(8, 1, false, 1);
+            if (a.K % 512 == 0) SF_MT(8, 4, 0, 1);
+            if (a.K % 256 == 0) SF_MT(8, 2, 0, 1);
+            if (a.K % 128 == 0) SF_MT(8, 1, 0, 1);
         } else {
             if (a.K % 2048 == 0 && mt <= 2) {
-                if (mt == 1) SF(1, 16, 8, false, 1); else SF(2, 16, 8, false, 1);
+                if (mt == 1) SF(1, 16, 8, 0, 1); else SF(2, 16, 8, 0, 1);
                 VH_CHECK_LAUNCH(name);
                 return VH_OK;
             }
-            if (a.K % 1024 == 0) SF_MT(16, 4, false, 1);
+            if (a.K % 1024 == 0) SF_MT(16, 4, 0, 1);
         }
 #undef SF_MT
 #undef SF
@@ -903,6 +926,89 @@ extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* 
     LnFuse ln{ln_gamma, ln_beta, ada_scale, ada_shift, ln_eps};
     if (int rc = check_gemm("vh_linear_qkv", a, ln)) return rc;
     return launch_gemm<EPI_QKV>("vh_linear_qkv", a, ln, (hipStream_t)stream);
+}
+
+// ---- LayerNorm folded into the weight operand (decode path) -----------------------------------
+// LN(x)·Wᵀ + b = rstd·(x·(W∘γ)ᵀ − mean·c1) + c2 with c1[n] = Σ_k γ_k W[n,k], c2[n] = Σ_k β_k W[n,k] + b[n].
+// One wave per output row n; the two sums in double (one-off preparation, rounded once).
+__global__ __launch_bounds__(256) void ln_fold_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const float* __restrict__ bias,
+                                                      float* __restrict__ Wf, float* __restrict__ c1,
+                                                      float* __restrict__ c2, int N, int K) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 4 * lane; k < K; k += 256) {
+        const f32x4 w = ld4(W + (int64_t)n * K + k), g = ld4(gamma + k), b = ld4(beta + k);
+        const f32x4 wf = w * g;
+        st4(Wf + (int64_t)n * K + k, wf);
+        s1 += ((double)wf.x + (double)wf.y) + ((double)wf.z + (double)wf.w);
+        s2 += ((double)w.x * b.x + (double)w.y * b.y) + ((double)w.z * b.z + (double)w.w * b.w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane == 0) {
+        c1[n] = (float)s1;
+        c2[n] = (float)(s2 + (bias ? (double)bias[n] : 0.0));
+    }
+}
+
+extern "C" int vh_ln_fold(const float* W, const float* gamma, const float* beta, const float* bias,
+                          float* Wf, float* c1, float* c2, int N, int K, void* stream) {
+    VH_REQUIRE(W && gamma && beta && Wf && c1 && c2, VH_EINVAL, "vh_ln_fold: null pointer");
+    VH_REQUIRE(N > 0 && K > 0 && K % 4 == 0, VH_EINVAL, "vh_ln_fold: N=%d K=%d (K must be a multiple of 4)", N, K);
+    VH_REQUIRE(vh_aligned16(W) && vh_aligned16(gamma) && vh_aligned16(beta) && vh_aligned16(Wf), VH_EALIGN,
+               "vh_ln_fold: pointers must be 16-byte aligned");
+    hipLaunchKernelGGL(ln_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, W, gamma, beta,
+                       bias, Wf, c1, c2, N, K);
+    VH_CHECK_LAUNCH("vh_ln_fold");
+    return VH_OK;
+}
+
+static int check_folded(const char* name, const GemmArgs& a, const LnFuse& ln) {
+    VH_REQUIRE(ln.c1 && ln.c2, VH_EINVAL, "%s: null c1/c2", name);
+    VH_REQUIRE(a.M <= 64 && a.N % 16 == 0 && (a.K == 128 || a.K == 256 || a.K == 512 || a.K == 1024),
+               VH_EUNSUPPORTED,
+               "%s: folded LayerNorm is the decode path: M <= 64, N %% 16 == 0, K in {128,256,512,1024} "
+               "(M=%d N=%d K=%d)", name, a.M, a.N, a.K);
+    VH_REQUIRE(vh_aligned16(ln.c1) && vh_aligned16(ln.c2), VH_EALIGN, "%s: c1/c2 must be 16-byte aligned", name);
+    return VH_OK;
+}
+
+extern "C" int vh_linear_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                                const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
+                                int act, float ln_eps, void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = Wf; a.res = residual; a.ldr = ldr; a.out = out;
+    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K;
+    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
+    VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF, VH_EINVAL, "vh_linear_folded: act=%d", act);
+    VH_REQUIRE(ldo >= N && (!residual || ldr >= N), VH_EINVAL, "vh_linear_folded: ldo/ldr < N");
+    if (int rc = check_gemm("vh_linear_folded", a, ln)) return rc;
+    if (int rc = check_folded("vh_linear_folded", a, ln)) return rc;
+    return launch_gemm<EPI_PLAIN>("vh_linear_folded", a, ln, (hipStream_t)stream);
+}
+
+extern "C" int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                                    float* q_out, int ldq, float* kcache, float* vcache,
+                                    const int32_t* cache_len, int B, int T, int d_model, int n_heads,
+                                    int S_max, float ln_eps, void* stream) {
+    VH_REQUIRE(kcache && vcache, VH_EINVAL, "vh_linear_qkv_folded: null cache");
+    VH_REQUIRE(B >= 0 && T >= 0 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
+               "vh_linear_qkv_folded: d_model=%d must equal n_heads=%d x %d", d_model, n_heads, VH_HEAD_DIM);
+    VH_REQUIRE(S_max >= T && ldq >= d_model, VH_EINVAL, "vh_linear_qkv_folded: S_max=%d < T=%d or ldq", S_max, T);
+    VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache), VH_EALIGN, "vh_linear_qkv_folded: cache alignment");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq; a.M = B * T; a.N = 3 * d_model;
+    a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE; a.kc = kcache; a.vc = vcache; a.cache_len = cache_len;
+    a.T = T > 0 ? T : 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
+    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
+    if (int rc = check_gemm("vh_linear_qkv_folded", a, ln)) return rc;
+    if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
+    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream);
 }
 
 extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,

@@ -87,8 +87,12 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
-        TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
-                          d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
+        if (L.wqkv_f)
+            TRY(vh_linear_qkv_folded(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
+                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
+        else
+            TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
+                              d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
         if (ev) {
             hipEvent_t e0, e1;
             if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
@@ -109,8 +113,12 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
                       nullptr, nullptr, 0.f, s));
         // LN2 fused + linear_1 + exact GELU (modules.py:221,278)
-        TRY(vh_linear(d.x, D, L.w1, L.b1, nullptr, 0, d.hidden, d.dff, B, d.dff, D, VH_ACT_GELU_ERF,
-                      L.ln2_g, L.ln2_b, nullptr, nullptr, d.ln_eps, s));
+        if (L.w1_f)
+            TRY(vh_linear_folded(d.x, D, L.w1_f, L.w1_c1, L.w1_c2, nullptr, 0, d.hidden, d.dff, B, d.dff, D,
+                                 VH_ACT_GELU_ERF, d.ln_eps, s));
+        else
+            TRY(vh_linear(d.x, D, L.w1, L.b1, nullptr, 0, d.hidden, d.dff, B, d.dff, D, VH_ACT_GELU_ERF,
+                          L.ln2_g, L.ln2_b, nullptr, nullptr, d.ln_eps, s));
         // linear_2 + bias + residual
         TRY(vh_linear_ws(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, d.gemm_ws,
                          d.gemm_ws_bytes, s));

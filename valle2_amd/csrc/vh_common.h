@@ -95,4 +95,8 @@ struct LnFuse {
     const float* ada_scale;  // (K) or nullptr
     const float* ada_shift;
     float eps;
+    // folded form (vh_ln_fold): the weight operand is W∘gamma and LN(x)·Wᵀ + bias is rebuilt in the
+    // epilogue as rstd·(x·Wfᵀ − mean·c1) + c2; gamma/beta are unused when c1 != nullptr
+    const float* c1;
+    const float* c2;
 };

@@ -48,7 +48,33 @@ def _layer_params(layer):
             ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias)
 
 
-def layer_table(transformer, cache: KVCache):
+FOLD_LAYERNORM = True   # decode step: LayerNorm folded into the QKV / linear_1 weights (vh_ln_fold)
+
+
+def folded_layer_norms(transformer):
+    """Per layer ((Wqkv∘γ1, c1, c2), (W1∘γ2, c1, c2)) for the decode step, or None when the shape is
+    outside the folded kernels (d_model not in {128,256,512,1024}) or the norms are adaptive.  Cached
+    on the module and rebuilt when any of the source parameters changed (optimizer step, load)."""
+    layers = list(transformer.layers)
+    d = transformer.hparams.d_model
+    if (not FOLD_LAYERNORM or d not in (128, 256, 512, 1024) or transformer.hparams.dim_feedforward % 16
+            or any(hasattr(l.norm1, 'project_layer') for l in layers)):
+        return None
+    srcs = [(l.norm1.weight, l.norm1.bias, l.self_attn.qkv.weight, l.norm2.weight, l.norm2.bias,
+             l.ffn.linear_1.weight, l.ffn.linear_1.bias) for l in layers]
+    key = tuple((t.data_ptr(), t._version) for ps in srcs for t in ps)
+    cached = getattr(transformer, '_vh_folded', None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.no_grad():
+        folded = [(kernels.ln_fold(wq.detach(), g1.detach(), b1.detach()),
+                   kernels.ln_fold(w1.detach(), g2.detach(), b2.detach(), bias1.detach()))
+                  for g1, b1, wq, g2, b2, w1, bias1 in srcs]
+    transformer._vh_folded = (key, folded)
+    return folded
+
+
+def layer_table(transformer, cache: KVCache, folded=None):
     """ctypes array of VhLayer for `transformer.layers` bound to `cache`."""
     layers = list(transformer.layers)
     arr = (VhLayer * len(layers))()
@@ -60,6 +86,9 @@ def layer_table(transformer, cache: KVCache):
             setattr(arr[i], name, ptr(t.detach()))
         arr[i].kcache = ptr(cache.k(i))
         arr[i].vcache = ptr(cache.v(i))
+        if folded is not None:
+            (arr[i].wqkv_f, arr[i].qkv_c1, arr[i].qkv_c2), (arr[i].w1_f, arr[i].w1_c1, arr[i].w1_c2) = (
+                tuple(ptr(t) for t in folded[i][0]), tuple(ptr(t) for t in folded[i][1]))
     return arr
 
 
@@ -145,7 +174,8 @@ class ArDecoder:
         self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
-        self._table = layer_table(model.transformer, cache)
+        self._folded = folded_layer_norms(model.transformer)   # kept alive: the table holds raw pointers
+        self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
         desc = VhArDecoderDesc(

@@ -128,6 +128,45 @@ def linear_qkv(a, wqkv, q_out, kcache, vcache, B, T, n_heads, cache_len=None, ln
     return q_out
 
 
+def ln_fold(w, gamma, beta, bias=None):
+    """(Wf, c1, c2) of vh_ln_fold: LN(x) @ w.T + bias == rstd * (x @ Wf.T - mean * c1) + c2."""
+    N, K = w.shape
+    if not w.is_contiguous() or gamma.numel() != K or beta.numel() != K:
+        raise _lib.VhError(f'ln_fold: w={tuple(w.shape)} gamma={tuple(gamma.shape)}')
+    wf = torch.empty_like(w)
+    c = torch.empty(2, (N + 3) // 4 * 4, device=w.device, dtype=torch.float32)
+    check(_lib.lib().vh_ln_fold(_f32(w, 'w').data_ptr(), ptr(gamma), ptr(beta), ptr(bias), ptr(wf),
+                                c[0].data_ptr(), c[1].data_ptr(), N, K, stream()), 'vh_ln_fold')
+    return wf, c[0, :N], c[1, :N]
+
+
+def linear_folded(a, folded, residual=None, out=None, act=ACT_NONE, eps=1e-5):
+    """act(LN(a) @ w.T + bias) + residual from the folded triple of ln_fold (decode rows, M <= 64)."""
+    wf, c1, c2 = folded
+    M, K = a.shape
+    N = wf.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.float32)
+    check(_lib.lib().vh_linear_folded(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(wf), ptr(c1), ptr(c2), ptr(residual),
+        residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0), M, N, K, act,
+        eps, stream()), 'vh_linear_folded')
+    return out
+
+
+def linear_qkv_folded(a, folded, q_out, kcache, vcache, B, T, n_heads, cache_len=None, eps=1e-5):
+    wf, c1, c2 = folded
+    M, d = a.shape
+    S_max = kcache.shape[2]
+    if M != B * T or tuple(wf.shape) != (3 * d, d) or tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM):
+        raise _lib.VhError(f'linear_qkv_folded: shapes a={tuple(a.shape)} w={tuple(wf.shape)}')
+    check(_lib.lib().vh_linear_qkv_folded(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(wf), ptr(c1), ptr(c2), q_out.data_ptr(),
+        q_out.stride(0), ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max, eps,
+        stream()), 'vh_linear_qkv_folded')
+    return q_out
+
+
 def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_dev=None,
               kv_len=None, mask=None, pad=None):
     S_max = kcache.shape[2]
