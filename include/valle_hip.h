@@ -126,10 +126,30 @@ int vh_ln_fold(const float* W, const float* gamma, const float* beta, const floa
 int vh_linear_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
                      const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
                      int act, float ln_eps, void* stream);
-int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
-                         float* q_out, int ldq, float* kcache, float* vcache,
+int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const float* Wf, const float* c1,
+                         const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
                          const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
                          float ln_eps, void* stream);
+
+/* ---- residual stream in fp64 accumulator form (decode path, M <= 64) -------------------------
+ * linear_2 at M <= 64 is split over K (one CU pulls ~25 GB/s, see vh_linear_ws).  Instead of slabs
+ * plus a reduce launch, vh_linear_acc64 lets every K slice add its partial sums onto an fp64 copy
+ * of the residual stream with hardware atomics:   acc[m,n] += sum_k A[m,k] W[n,k]  (+ bias[n] +
+ * residual[m,n], added once).  Every addend is first rounded to a multiple of 2^-32, so while
+ * |values| < 2^19 the fp64 sums are exact and the result is independent of arrival order:
+ * bitwise reproducible, and closer to the real sum than an fp32 reduction.  acc (M,N) ldacc doubles
+ * must hold zeros (or an earlier such sum) on entry.  N % 16 == 0, K % 128 == 0.
+ * Consumers of the fp64 rows:
+ *   vh_linear_qkv_folded(A = acc, a_f64 = 1, ...)                  LN1 + QKV of the next layer
+ *   vh_linear_x64(A = acc, a_f64 = 1, ..., residual64 = NULL, ...) plain Linear on the rows (head)
+ *   vh_linear_x64(A fp32, a_f64 = 0, ..., residual64 = acc, ...)   out = A W^T + bias + acc, and the
+ *       rows of acc are CLEARED as they are read (N % 16 == 0), ready for the next vh_linear_acc64
+ *   vh_greedy_step / vh_sample_step (x_next64)                     write the next embedding in this form
+ * (valle/models/modules.py:277-279 residual adds; valle_ar.py:143-158). */
+int vh_linear_acc64(const float* A, int lda, const float* W, const float* bias, const float* residual,
+                    int ldr, double* acc, int ldacc, int M, int N, int K, void* stream);
+int vh_linear_x64(const void* A, int a_f64, int lda, const float* W, const float* bias,
+                  double* residual64, int ldr, float* out, int ldo, int M, int N, int K, void* stream);
 
 /* ---- K7+K8a: multi-row attention (prefill / NAR / training forward) -------------------------
  * replaces merge_masks + F.scaled_dot_product_attention (valle/models/modules.py:160-167,
@@ -164,12 +184,13 @@ int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vc
  *   p = audio_pos[b]; tok = (codes[b][p-1]==eos) ? eos : argmax(logits[b,:V]); codes[b][p] = tok;
  *   if (tok==eos) eos_count[p - (pos_base?pos_base[b]:0)] += 1;
  *   x_next[b,:] = audio_emb[tok,:] + pe[p*d + :]; audio_pos[b] = p+1; cache_len[b] += 1.
+ * x_next (fp32) and x_next64 (the fp64 accumulator form, see vh_linear_acc64) may each be NULL, not both.
  * eos_count[s] == B means every row had finished at step s (the reference's break, :169-170);
  * the host polls it every few steps instead of synchronising every step. */
 int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
                    int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
-                   float* x_next, int B, int d, void* stream);
+                   float* x_next, double* x_next64, int B, int d, void* stream);
 
 /* ---- K12 (stochastic): temperature / top-k / top-p sampling + the same state update ----------
  * replaces topk_sampling (valle/models/utils.py:46-68) incl. the published semantics of
@@ -183,7 +204,7 @@ int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, floa
                    float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
                    int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
-                   float* x_next, int B, int d, void* stream);
+                   float* x_next, double* x_next64, int B, int d, void* stream);
 
 /* ---- composite: one AR decode step / hipGraph replay ----------------------------------------
  * The ~5 launches per layer of one decode step (LN1+QKV+append, decode attention, out-proj+
@@ -217,6 +238,11 @@ typedef struct {
     float top_p, temperature;
     uint64_t seed;
     float *sum_logprobs;              /* (B) or NULL */
+    /* optional: residual stream kept in fp64 accumulator form between layers (vh_linear_acc64): x64
+     * (B,d) doubles + xmid (B,d) floats; needs the folded weights in every layer.  NULL → fp32 x with
+     * the split-K workspace + reduce launch.  On entry of a step the token embedding is in x64 then. */
+    double *x64;
+    float *xmid;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

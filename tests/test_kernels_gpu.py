@@ -209,6 +209,92 @@ def test_linear_qkv_folded_scatter(K):
     assert int((kc != 0).any(-1).sum()) == B * h       # exactly one row per (b, head) written
 
 
+# ---- residual stream in fp64 accumulator form (vh_linear_acc64 and its consumers) --------------------
+@pytest.mark.parametrize('M,N,K_', [(32, 512, 2048), (5, 64, 512), (64, 128, 128), (17, 512, 4096), (32, 96, 1280)])
+def test_linear_acc64_exact_atomics(K, M, N, K_):
+    a = torch.randn(M, K_, generator=g(90))
+    w = 0.05 * torch.randn(N, K_, generator=g(91))
+    bias, res = torch.randn(N, generator=g(92)), torch.randn(M, N, generator=g(93))
+    ref = a.double() @ w.double().T + bias.double() + res.double()
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
+    runs = []
+    for _ in range(3):
+        acc = torch.zeros(M, N, device=DEV, dtype=torch.float64)
+        K.linear_acc64(ad, wd, acc, bd, rd)
+        runs.append(acc)
+    torch.testing.assert_close(runs[0].cpu(), ref, atol=3e-5, rtol=1e-6)
+    # exact sums of grid-rounded addends: independent of the arrival order of the K slices
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+    assert torch.equal(runs[0] * 2 ** 32, torch.round(runs[0] * 2 ** 32))      # multiples of 2^-32
+    # accumulates onto what is there (no bias / residual the second time)
+    K.linear_acc64(ad, wd, runs[0])
+    torch.testing.assert_close(runs[0].cpu(), ref + a.double() @ w.double().T, atol=6e-5, rtol=1e-6)
+    # integer data: exact
+    ai = torch.randint(-3, 4, (M, K_), generator=g(94)).float()
+    wi = torch.randint(-3, 4, (N, K_), generator=g(95)).float()
+    acc = torch.zeros(M, N, device=DEV, dtype=torch.float64)
+    K.linear_acc64(ai.to(DEV), wi.to(DEV), acc)
+    assert torch.equal(acc.cpu(), (ai.double() @ wi.double().T))
+
+
+@pytest.mark.parametrize('M,N,K_', [(32, 512, 512), (3, 64, 128), (64, 128, 256)])
+def test_linear_x64_consumes_and_clears_the_residual(K, M, N, K_):
+    a = torch.randn(M, K_, generator=g(96))
+    w = 0.05 * torch.randn(N, K_, generator=g(97))
+    bias = torch.randn(N, generator=g(98))
+    res64 = torch.randn(M, N, generator=g(99), dtype=torch.float64)
+    ref = (a.double() @ w.double().T + bias.double() + res64).float()
+    rd = res64.to(DEV)
+    out = K.linear_x64(a.to(DEV), w.to(DEV), bias.to(DEV), residual64=rd)
+    close(out, ref, atol=3e-5)
+    assert int(rd.count_nonzero()) == 0
+
+
+@pytest.mark.parametrize('M,N,K_', [(32, 1025, 512), (4, 100, 128), (33, 48, 1024)])
+def test_linear_x64_fp64_rows(K, M, N, K_):
+    a64 = torch.randn(M, K_, generator=g(100), dtype=torch.float64)
+    w = 0.05 * torch.randn(N, K_, generator=g(101))
+    out = K.linear_x64(a64.to(DEV), w.to(DEV))
+    close(out, (a64.float().double() @ w.double().T).float(), atol=3e-5)
+    ai = torch.randint(-3, 4, (M, K_), generator=g(102)).double()
+    wi = torch.randint(-3, 4, (N, K_), generator=g(103)).float()
+    assert torch.equal(K.linear_x64(ai.to(DEV), wi.to(DEV)).cpu(), (ai @ wi.double().T).float())
+
+
+def test_linear_x64_argument_checks(K):
+    from valle2_amd._lib import VhError
+    w = torch.randn(64, 128, device=DEV)
+    a = torch.randn(4, 128, device=DEV)
+    with pytest.raises(VhError, match='exactly one'):
+        K.linear_x64(a, w)                                   # neither operand in fp64 form
+    with pytest.raises(VhError, match='exactly one'):
+        K.linear_x64(a.double(), w, residual64=torch.zeros(4, 64, device=DEV, dtype=torch.float64))
+    with pytest.raises(VhError, match='decode path'):
+        K.linear_x64(torch.randn(65, 128, device=DEV).double(), w)
+    with pytest.raises(VhError, match='decode path'):
+        K.linear_acc64(torch.randn(4, 128, device=DEV), torch.randn(60, 128, device=DEV),
+                       torch.zeros(4, 60, device=DEV, dtype=torch.float64))
+
+
+def test_qkv_folded_from_fp64_rows_matches_fp32_rows(K):
+    B, h, S_max = 6, 2, 9
+    d = 64 * h
+    x = torch.randn(B, d, generator=g(104)) + 0.2
+    w = 0.1 * torch.randn(3 * d, d, generator=g(105))
+    gm, bt = 1 + 0.2 * torch.randn(d, generator=g(106)), 0.2 * torch.randn(d, generator=g(107))
+    folded = K.ln_fold(w.to(DEV), gm.to(DEV), bt.to(DEV))
+    cl = torch.tensor([3, 0, 8, 1, 5, 2], dtype=torch.int32, device=DEV)
+    outs = []
+    for xx in (x.to(DEV), x.double().to(DEV)):
+        kc = torch.zeros(B, h, S_max, 64, device=DEV)
+        vc = torch.zeros_like(kc)
+        qo = torch.empty(B, d, device=DEV)
+        K.linear_qkv_folded(xx, folded, qo, kc, vc, B, 1, h, cache_len=cl)
+        outs.append((qo, kc, vc))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)       # fp32 → fp64 → fp32 is exact: identical arithmetic
+
+
 @pytest.mark.parametrize('rows,d', [(1, 128), (37, 512), (5, 1024), (3, 2048), (9, 132)])
 def test_layernorm(K, rows, d):
     x = 3 * torch.randn(rows, d, generator=g(15)) + 1
@@ -391,3 +477,10 @@ def test_greedy_step(K):
     assert dv['apos'].cpu().tolist() == [5] * B and dv['clen'].cpu().tolist() == [11, 12, 13, 14, 15]
     assert dv['cnt'].cpu()[4].item() == 2 and dv['cnt'].cpu().sum().item() == 2
     assert torch.equal(x.cpu(), emb[exp] + pe[4, 0])
+    # the same step writing the fp64 accumulator form of the embedding
+    dv2 = {k: v.to(DEV) for k, v in dict(codes=codes, apos=apos, clen=clen, cnt=cnt).items()}
+    x64 = torch.empty(B, d, device=DEV, dtype=torch.float64)
+    K.greedy_step(dv['logits'], V, eos, dv2['codes'], dv2['cnt'], dv['emb'], dv['pe'], dv2['apos'],
+                  dv2['clen'], x64)
+    assert torch.equal(x64.cpu(), (emb[exp] + pe[4, 0]).double())
+    assert torch.equal(dv2['codes'], dv['codes'])

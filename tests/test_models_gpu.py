@@ -154,6 +154,25 @@ def test_ar_generate_golden(which, graph):
     tokens_match(out, gold['tokens'], gold['margin'])
 
 
+@pytest.mark.parametrize('fold,acc64', [(False, False), (True, False), (True, True)])
+def test_ar_generate_golden_every_decode_engine(fold, acc64):
+    """The decode step has three forms of its GEMM chain (LayerNorm in the operand load + split-K
+    reduce; folded LayerNorm; folded + fp64 accumulator residual stream).  Each must reproduce the
+    reference's greedy tokens."""
+    from valle2_amd import engine
+    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL
+    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL = fold, acc64
+    try:
+        for which in ('tiny', 'mid'):
+            gold = load_golden(f'ar_generate_{which}')
+            kw, sd, utt = C.ar_generate_inputs(which)
+            m = build('ValleAR', kw, sd)
+            out = m.generate(*[u.to(DEV) for u in utt])
+            tokens_match(out, gold['tokens'], gold['margin'])
+    finally:
+        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL = old
+
+
 def test_generate_batch_distinct_rows_vs_oracle():
     """Rows are independent utterances: each row of generate_batch must equal the oracle run on
     that utterance alone (a kernel that mixed rows or read row 0 for everyone would pass the

@@ -89,7 +89,29 @@ def bench_gemm():
     def nxt():
         i[0] += 1
         return i[0] % L
+    lib = _lib.lib()
+    fq = [K.ln_fold(wqkv[l], g, b) for l in range(L)]
+    f1 = [K.ln_fold(w1[l], g, b, b1) for l in range(L)]
+    x64 = torch.randn(B, d, device=DEV, dtype=torch.float64)
+    acc = torch.zeros(B, d, device=DEV, dtype=torch.float64)
+    xmid = torch.randn(B, d, device=DEV)
+    wh = 0.02 * torch.randn(1025, d, device=DEV)
+    logits = torch.empty(B, 1028, device=DEV)
+
+    def tuned(knob, val, fn):
+        def run():
+            lib.vh_set_tuning(knob, val)
+            fn()
+            lib.vh_set_tuning(knob, 0)
+        return run
     cases = {
+        'qkv fold': lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
+        'qkv fold f64 rows': lambda: K.linear_qkv_folded(x64, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
+        'ffn1 fold': lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1),
+        'out-proj, residual64 consumed': lambda: K.linear_x64(x, wo[nxt()], bo, residual64=acc, out=o1),
+        'ffn2 acc64 (N=512,K=2048)': lambda: K.linear_acc64(hid, w2[nxt()], acc, bo, xmid),
+        'head f64 rows (N=1025)': lambda: K.linear_x64(x64, wh, out=logits[:, :1025]),
+        'head f32 rows (N=1025)': lambda: K.linear(x, wh, out=logits[:, :1025]),
         'qkv+ln   (N=1536,K=512)': lambda: K.linear_qkv(x, wqkv[nxt()], q, kc, vc, B, 1, 8, cache_len=cl, ln=ln),
         'out-proj (N=512,K=512)': lambda: K.linear(x, wo[nxt()], bo, o1, out=o1),
         'ffn1+ln  (N=2048,K=512)': lambda: K.linear(x, w1[nxt()], b1, out=o2, act=1, ln=ln),

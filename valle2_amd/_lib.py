@@ -43,7 +43,7 @@ class VhArDecoderDesc(C.Structure):
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
-        ('sum_logprobs', C.c_void_p),
+        ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p),
     ]
 
 
@@ -82,9 +82,13 @@ SIGNATURES = {
                              C.c_void_p]),
     'vh_linear_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
-    'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
-                                       c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+    'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+                                       c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_void_p]),
+    'vh_linear_acc64': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_linear_x64': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
+                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_attn_rows': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
                                c_u8p, C.c_void_p]),
@@ -92,11 +96,11 @@ SIGNATURES = {
     'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
-                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int,
+                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                  C.c_void_p]),
     'vh_sample_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
                                  c_i64p, C.c_int64, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p,
-                                 c_f32p, C.c_int, C.c_int, C.c_void_p]),
+                                 c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_ar_decoder_create': (C.c_void_p, [C.POINTER(VhArDecoderDesc)]),
     'vh_ar_decoder_destroy': (None, [C.c_void_p]),
     'vh_ar_decoder_step': (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -15,6 +15,8 @@
 //   16x16x4 : A[i=l&15][k=l>>4], B[k=l>>4][j=l&15]; D reg r: row i=4(l>>4)+r,          col j=l&15
 // The k index of a product is only summed over, so each lane feeds 4 consecutive k (one float4)
 // per operand and the 4 MFMAs of a group consume element j of both operands: same k on both sides.
+#include <type_traits>
+
 #include "vh_common.h"
 
 struct GemmArgs {
@@ -48,7 +50,21 @@ struct GemmArgs {
 #define STAMP(k)
 #endif
 
-enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2 };
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2, EPI_ACC64 = 3 };
+
+// ---- accumulator form of the residual stream (decode step) ---------------------------------------
+// The split-K slices of linear_2 add their partial sums straight onto an fp64 copy of the residual
+// stream with hardware atomics, and the add is made EXACT: every addend is first rounded to a multiple
+// of 2^-32 ((v + 1.5·2^20) − 1.5·2^20 in fp64), so as long as |sum| < 2^21 the 53-bit sums carry no
+// rounding at all and the result does not depend on arrival order — bitwise reproducible without the
+// separate reduce launch.  Consumers read the fp64 rows (X64 & 1) or consume-and-clear them as a
+// residual (X64 & 2).
+#define VH_GRID_MAGIC 1572864.0
+__device__ __forceinline__ f32x4 ld4(const double* p) {
+    typedef double d64x2 __attribute__((ext_vector_type(2)));
+    const d64x2 lo = *reinterpret_cast<const d64x2*>(p), hi = *reinterpret_cast<const d64x2*>(p + 2);
+    return f32x4{(float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y};
+}
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
 template <int EPI>
@@ -567,8 +583,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //     2 = folded (vh_ln_fold): the products run on the raw rows against W∘gamma while the statistics
 //         are computed beside them, and the epilogue applies rstd·(acc − mean·c1) + c2 — no
 //         statistics → normalise → MFMA dependency, one workgroup barrier instead of two.
-template <int MT, int NW, int EPI, int PW, int LN, int NJ>
+// X64: bit 0 = the A operand is the fp64 accumulator form (lda in doubles); bit 1 = the residual is
+//      the fp64 accumulator form (ldr in doubles) and is cleared once read, ready for the next
+//      EPI_ACC64 launch.  EPI_ACC64: a.out is that fp64 buffer (ldo in doubles); slice 0 also adds the
+//      fp32 bias and residual.
+template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
+    using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -576,9 +597,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     const int n0 = blockIdx.x * 16;
     const int koff = blockIdx.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
     const float* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
-    const float* xp[MT];
+    const AT* xp[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) xp[mt] = a.A + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
+    for (int mt = 0; mt < MT; ++mt)
+        xp[mt] = reinterpret_cast<const AT*>(a.A) + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
     const float* gp = LN == 1 ? ln.gamma + koff : nullptr;
     const float* bp = LN == 1 ? ln.beta + koff : nullptr;
 
@@ -602,7 +624,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     f32x4 v[NJ];
     auto ln_load = [&](int r0) {
         const int row = (r0 * NW + w) * 4 + g;
-        const float* xr = a.A + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
+        const AT* xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
     };
@@ -637,7 +659,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             e_c1 = ld4(ln.c1 + en);
             e_bias = ld4(ln.c2 + en);
         } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
-        if (EPI == EPI_PLAIN && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
+        if (EPI == EPI_PLAIN && a.res) {
+            if (X64 & 2) e_res = ld4(reinterpret_cast<const double*>(a.res) + (int64_t)em * a.ldr + en);
+            else e_res = ld4(a.res + (int64_t)em * a.ldr + en);
+        }
+        if (EPI == EPI_ACC64 && blockIdx.y == 0) {
+            if (a.bias) e_bias = ld4(a.bias + en);
+            if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
+        }
         if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -708,7 +737,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
             if (EPI == EPI_QKV) sacc += e_bias;
         }
-        if (!fin || EPI == EPI_PARTIAL) {
+        if (EPI == EPI_ACC64) {
+            if (fin) {                       // N % 16 == 0 (host check): every column group is whole
+                double* dst = reinterpret_cast<double*>(a.out) + (int64_t)em * a.ldo + en;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    // e_bias / e_res are zero except in slice 0
+                    const double t = (double)sacc[j] + ((double)e_bias[j] + (double)e_res[j]);
+                    unsafeAtomicAdd(dst + j, (t + VH_GRID_MAGIC) - VH_GRID_MAGIC);
+                }
+            }
+        } else if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
             sacc += e_bias;
@@ -717,6 +756,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
                 sacc.z = gelu_erf(sacc.z); sacc.w = gelu_erf(sacc.w);
             }
             st4(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
+            if ((X64 & 2) && a.res) {        // the accumulator row segment is consumed: clear it
+                typedef double d64x2 __attribute__((ext_vector_type(2)));
+                double* rp = reinterpret_cast<double*>(const_cast<float*>(a.res)) + (int64_t)em * a.ldr + en;
+                *reinterpret_cast<d64x2*>(rp) = d64x2{0.0, 0.0};
+                *reinterpret_cast<d64x2*>(rp + 2) = d64x2{0.0, 0.0};
+            }
         } else {  // EPI_QKV with the cache position already in a register
             const int which = en / a.d_model, c = en - which * a.d_model;
             if (which == 0) {
@@ -809,8 +854,11 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
 }
 
 template <int EPI>
-static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s) {
+static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, int x64 = 0) {
     if (a.M == 0) return VH_OK;
+    VH_REQUIRE(x64 == 0 || (a.M <= 64 && a.K <= 1024 && a.K % 128 == 0), VH_EUNSUPPORTED,
+               "%s: the fp64 accumulator form is the decode path: M <= 64, K <= 1024, K %% 128 == 0 "
+               "(M=%d K=%d)", name, a.M, a.K);
     if (a.M <= 64) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
@@ -818,16 +866,41 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool has_ln = ln.gamma != nullptr || ln.c1 != nullptr;
         const bool fold = ln.c1 != nullptr;
         // ---- compact fast path: K = 16*NW*PW*passes
-#define SF(MT, NW, PW, LN, NJ) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, a, ln)
-#define SF_MT(NW, PW, LN, NJ)                                                  \
+#define SFX(MT, NW, PW, LN, NJ, X) \
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, a, ln)
+#define SF(MT, NW, PW, LN, NJ) SFX(MT, NW, PW, LN, NJ, 0)
+#define SFX_MT(NW, PW, LN, NJ, X)                                              \
     do {                                                                       \
-        if (mt == 1) SF(1, NW, PW, LN, NJ);                                    \
-        else if (mt == 2) SF(2, NW, PW, LN, NJ);                               \
-        else SF(4, NW, PW, LN, NJ);                                            \
+        if (mt == 1) SFX(1, NW, PW, LN, NJ, X);                                \
+        else if (mt == 2) SFX(2, NW, PW, LN, NJ, X);                           \
+        else SFX(4, NW, PW, LN, NJ, X);                                        \
         VH_CHECK_LAUNCH(name);                                                 \
         return VH_OK;                                                          \
     } while (0)
+#define SF_MT(NW, PW, LN, NJ) SFX_MT(NW, PW, LN, NJ, 0)
+        // ---- fp64 accumulator form of the residual stream (x64: 1 = A operand, 2 = consumed residual)
+        if (x64) {
+            if constexpr (EPI == EPI_QKV) {
+                VH_REQUIRE(x64 == 1 && fold, VH_EUNSUPPORTED, "%s: fp64 rows need the folded LayerNorm", name);
+                if (a.K == 128) SFX_MT(8, 1, 2, 2, 1);
+                if (a.K == 256) SFX_MT(8, 2, 2, 4, 1);
+                if (a.K == 512) SFX_MT(8, 4, 2, 8, 1);
+                if (a.K == 1024) SFX_MT(8, 4, 2, 16, 1);
+            } else if constexpr (EPI == EPI_PLAIN) {
+                VH_REQUIRE(!has_ln, VH_EUNSUPPORTED, "%s: fp64 rows / residual without LayerNorm only", name);
+                if (x64 == 1) {
+                    if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, 1);
+                    if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, 1);
+                    SFX_MT(8, 1, 0, 1, 1);
+                } else {
+                    if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, 2);
+                    if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, 2);
+                    SFX_MT(8, 1, 0, 1, 2);
+                }
+            }
+            vh_set_error("%s: no fp64-form kernel for K=%d", name, a.K);
+            return VH_EUNSUPPORTED;
+        }
         if (has_ln) {  // K <= 1024 (check_gemm); statistics need K = 64*NJ
             if (fold) {
                 if (a.K == 128) SF_MT(8, 1, 2, 2);
@@ -854,7 +927,9 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             if (a.K % 1024 == 0) SF_MT(16, 4, 0, 1);
         }
 #undef SF_MT
+#undef SFX_MT
 #undef SF
+#undef SFX
         // ---- generic guarded kernel for every other K (multiple of 16)
 #define SK(MT, NW, CH, LN) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI, CH, LN>), grid, dim3(NW * 64), 0, s, a, ln)
@@ -992,8 +1067,8 @@ extern "C" int vh_linear_folded(const float* A, int lda, const float* Wf, const 
     return launch_gemm<EPI_PLAIN>("vh_linear_folded", a, ln, (hipStream_t)stream);
 }
 
-extern "C" int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
-                                    float* q_out, int ldq, float* kcache, float* vcache,
+extern "C" int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const float* Wf, const float* c1,
+                                    const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
                                     const int32_t* cache_len, int B, int T, int d_model, int n_heads,
                                     int S_max, float ln_eps, void* stream) {
     VH_REQUIRE(kcache && vcache, VH_EINVAL, "vh_linear_qkv_folded: null cache");
@@ -1002,13 +1077,67 @@ extern "C" int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, co
     VH_REQUIRE(S_max >= T && ldq >= d_model, VH_EINVAL, "vh_linear_qkv_folded: S_max=%d < T=%d or ldq", S_max, T);
     VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache), VH_EALIGN, "vh_linear_qkv_folded: cache alignment");
     GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq; a.M = B * T; a.N = 3 * d_model;
+    a.A = reinterpret_cast<const float*>(A); a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq;
+    a.M = B * T; a.N = 3 * d_model;
     a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE; a.kc = kcache; a.vc = vcache; a.cache_len = cache_len;
     a.T = T > 0 ? T : 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
     LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
     if (int rc = check_gemm("vh_linear_qkv_folded", a, ln)) return rc;
     if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
-    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream);
+    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream, a_f64 ? 1 : 0);
+}
+
+// ---- fp64 accumulator form -----------------------------------------------------------------------
+extern "C" int vh_linear_acc64(const float* A, int lda, const float* W, const float* bias,
+                               const float* residual, int ldr, double* acc, int ldacc, int M, int N, int K,
+                               void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr;
+    a.out = reinterpret_cast<float*>(acc); a.ldo = ldacc; a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE;
+    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    VH_REQUIRE(M <= 64 && N % 16 == 0 && K % 128 == 0, VH_EUNSUPPORTED,
+               "vh_linear_acc64: decode path only: M <= 64, N %% 16 == 0, K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
+    VH_REQUIRE(ldacc >= N && ldacc % 2 == 0 && (!residual || ldr >= N), VH_EINVAL, "vh_linear_acc64: ldacc/ldr");
+    const int splits = splitk_plan(M, N, K);
+    a.k_len = splits ? K / splits : K;
+    a.ldo = 4;   // check_gemm looks at fp32 leading dimensions; the real one is restored below
+    if (int rc = check_gemm("vh_linear_acc64", a, none)) return rc;
+    a.ldo = ldacc;
+    if (M == 0) return VH_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int mt = (M + 15) / 16;
+#define ACC(MT, NW, PW) \
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI_ACC64, PW, 0, 1>), grid, dim3(NW * 64), 0, s, a, none)
+#define ACC_MT(NW, PW) do { if (mt == 1) ACC(1, NW, PW); else if (mt == 2) ACC(2, NW, PW); else ACC(4, NW, PW); } while (0)
+    if (splits) {           // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
+        dim3 grid((N + 15) / 16, splits);
+        ACC_MT(4, 4);
+    } else {
+        dim3 grid((N + 15) / 16, 1);
+        if (K % 512 == 0) ACC_MT(8, 4);
+        else if (K % 256 == 0) ACC_MT(8, 2);
+        else ACC_MT(8, 1);
+    }
+#undef ACC_MT
+#undef ACC
+    VH_CHECK_LAUNCH("vh_linear_acc64");
+    return VH_OK;
+}
+
+extern "C" int vh_linear_x64(const void* A, int a_f64, int lda, const float* W, const float* bias,
+                             double* residual64, int ldr, float* out, int ldo, int M, int N, int K,
+                             void* stream) {
+    GemmArgs a{};
+    a.A = reinterpret_cast<const float*>(A); a.lda = lda; a.W = W; a.bias = bias;
+    a.res = reinterpret_cast<const float*>(residual64); a.ldr = ldr; a.out = out;
+    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K;
+    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    VH_REQUIRE((a_f64 != 0) != (residual64 != nullptr), VH_EUNSUPPORTED,
+               "vh_linear_x64: exactly one of the A rows / the residual is in fp64 accumulator form");
+    VH_REQUIRE(ldo >= N && (!residual64 || (ldr >= N && N % 16 == 0)), VH_EINVAL,
+               "vh_linear_x64: ldo/ldr < N, or a consumed residual with N %% 16 != 0");
+    if (int rc = check_gemm("vh_linear_x64", a, none)) return rc;
+    return launch_gemm<EPI_PLAIN>("vh_linear_x64", a, none, (hipStream_t)stream, a_f64 ? 1 : 2);
 }
 
 extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,

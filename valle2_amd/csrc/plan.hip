@@ -57,6 +57,11 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                    d->logits && d->cache_len && d->audio_pos && d->eos_count && d->codes,
                VH_EINVAL, "vh_ar_decoder: null buffer in desc");
     VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
+    VH_REQUIRE((d->x64 == nullptr) == (d->xmid == nullptr), VH_EINVAL, "vh_ar_decoder: x64 and xmid go together");
+    if (d->x64)
+        for (int i = 0; i < d->n_layers; ++i)
+            VH_REQUIRE(d->layers[i].wqkv_f && d->layers[i].w1_f, VH_EINVAL,
+                       "vh_ar_decoder: the fp64 accumulator form needs folded weights (layer %d)", i);
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
     return VH_OK;
@@ -87,8 +92,11 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
-        if (L.wqkv_f)
-            TRY(vh_linear_qkv_folded(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
+        if (d.x64)
+            TRY(vh_linear_qkv_folded(d.x64, 1, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
+                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
+        else if (L.wqkv_f)
+            TRY(vh_linear_qkv_folded(d.x, 0, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
                                      d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
         else
             TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
@@ -109,6 +117,15 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
             TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
                                d.S_max, d.n_split, d.attn_partial, s));
         }
+        if (d.x64) {
+            // accumulator form: out-proj consumes (reads + clears) the fp64 rows → xmid; LN2 + linear_1
+            // on xmid; the K slices of linear_2 add (partials + bias + xmid) back onto the fp64 rows
+            TRY(vh_linear_x64(d.attn, 0, D, L.wo, L.bo, d.x64, D, d.xmid, D, B, D, D, s));
+            TRY(vh_linear_folded(d.xmid, D, L.w1_f, L.w1_c1, L.w1_c2, nullptr, 0, d.hidden, d.dff, B, d.dff, D,
+                                 VH_ACT_GELU_ERF, d.ln_eps, s));
+            TRY(vh_linear_acc64(d.hidden, d.dff, L.w2, L.b2, d.xmid, D, d.x64, D, B, D, d.dff, s));
+            continue;
+        }
         // out-proj + bias + residual (modules.py:171,277)
         TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
                       nullptr, nullptr, 0.f, s));
@@ -124,15 +141,19 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                          d.gemm_ws_bytes, s));
     }
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
-    TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
-                  nullptr, nullptr, nullptr, nullptr, 0.f, s));
+    if (d.x64)
+        TRY(vh_linear_x64(d.x64, 1, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, s));
+    else
+        TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
+                      nullptr, nullptr, nullptr, nullptr, 0.f, s));
+    float* xf = d.x64 ? nullptr : d.x;
     if (d.top_k == 1)
         TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
-                           d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+                           d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, xf, d.x64, B, D, s));
     else
         TRY(vh_sample_step(d.logits, dec->ldl, d.V, d.eos, d.top_k, d.top_p, d.temperature, d.seed,
                            d.codes, d.codes_stride, d.eos_count, d.pos_base, d.sum_logprobs, d.audio_emb,
-                           d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+                           d.audio_pe, d.audio_pos, d.cache_len, xf, d.x64, B, D, s));
     return VH_OK;
 }
 

@@ -14,6 +14,7 @@ Data layout in HBM (all fp32):
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -48,7 +49,14 @@ def _layer_params(layer):
             ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias)
 
 
-FOLD_LAYERNORM = True   # decode step: LayerNorm folded into the QKV / linear_1 weights (vh_ln_fold)
+# Forms of the decode step's GEMM chain (A/B switches; every form is under the same parity tests):
+FOLD_LAYERNORM = os.environ.get('VALLE2_FOLD_LN', '1') != '0'   # LayerNorm folded into the QKV / linear_1
+                                                                 # weights (vh_ln_fold)
+ACC64_RESIDUAL = os.environ.get('VALLE2_ACC64', '0') == '1'     # residual stream in fp64 accumulator form
+                                                                 # (vh_linear_acc64: linear_2's K slices add
+                                                                 # onto it with exact atomics, no reduce launch).
+                                                                 # Off: measured 1.7 us per layer SLOWER at
+                                                                 # 12L/512d, kept as an option.
 
 
 def folded_layer_norms(transformer):
@@ -175,6 +183,9 @@ class ArDecoder:
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
         self._folded = folded_layer_norms(model.transformer)   # kept alive: the table holds raw pointers
+        self.acc64 = bool(ACC64_RESIDUAL and self._folded is not None and d % 128 == 0 and dff % 128 == 0)
+        self.x64 = torch.zeros(batch, d, device=dev, dtype=torch.float64) if self.acc64 else None
+        self.xmid = torch.empty(batch, d, **f32) if self.acc64 else None
         self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
@@ -188,7 +199,7 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
-            sum_logprobs=ptr(self.sum_logprobs))
+            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:
@@ -196,6 +207,11 @@ class ArDecoder:
             raise _lib.VhError(f'vh_ar_decoder_create: {msg.decode() if msg else "failed"}')
         self._captured = False
         self.use_graph = use_graph
+
+    @property
+    def x_in(self):
+        """Where a step expects the current token's embedding (fp64 rows in accumulator form)."""
+        return self.x64 if self.acc64 else self.x
 
     def close(self):
         if getattr(self, '_h', None):
@@ -210,12 +226,12 @@ class ArDecoder:
         kernels.linear(hidden_last, m[0], out=self.logits[:, : self.V])
         if self.sampling[0] == 1:
             kernels.greedy_step(self.logits, self.V, self._desc.eos, self.codes, self.eos_count, m[1], m[2],
-                                self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
+                                self.audio_pos, self.cache_len, self.x_in, pos_base=self.pos_base)
         else:
             top_k, top_p, temp, seed = self.sampling
             kernels.sample_step(self.logits, self.V, self._desc.eos, top_k, top_p, temp, seed, self.codes,
                                 self.eos_count, self.sum_logprobs, m[1], m[2], self.audio_pos,
-                                self.cache_len, self.x, pos_base=self.pos_base)
+                                self.cache_len, self.x_in, pos_base=self.pos_base)
 
     def run(self, n_steps):
         """Enqueue n_steps decode steps on the current stream (graph replay when enabled)."""

@@ -161,10 +161,45 @@ def linear_qkv_folded(a, folded, q_out, kcache, vcache, B, T, n_heads, cache_len
     if M != B * T or tuple(wf.shape) != (3 * d, d) or tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM):
         raise _lib.VhError(f'linear_qkv_folded: shapes a={tuple(a.shape)} w={tuple(wf.shape)}')
     check(_lib.lib().vh_linear_qkv_folded(
-        _f32(a, 'a').data_ptr(), a.stride(0), ptr(wf), ptr(c1), ptr(c2), q_out.data_ptr(),
-        q_out.stride(0), ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max, eps,
-        stream()), 'vh_linear_qkv_folded')
+        _f32_or_f64(a, 'a').data_ptr(), int(a.dtype == torch.float64), a.stride(0), ptr(wf), ptr(c1), ptr(c2),
+        q_out.data_ptr(), q_out.stride(0), ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max,
+        eps, stream()), 'vh_linear_qkv_folded')
     return q_out
+
+
+def _f32_or_f64(t, name):
+    if t.dtype not in (torch.float32, torch.float64) or not t.is_cuda or t.stride(-1) != 1:
+        raise _lib.VhError(f'{name}: expected a row-major fp32 / fp64 device tensor, got {t.dtype} on {t.device}')
+    return t
+
+
+def linear_acc64(a, w, acc, bias=None, residual=None):
+    """acc (M,N) float64 += a @ w.T (+ bias + residual): split-K with exact fp64 atomics (reproducible)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if acc.dtype != torch.float64 or tuple(acc.shape) != (M, N) or acc.stride(1) != 1:
+        raise _lib.VhError(f'linear_acc64: acc must be float64 ({M},{N}), got {acc.dtype} {tuple(acc.shape)}')
+    check(_lib.lib().vh_linear_acc64(
+        _f32(a, 'a').data_ptr(), a.stride(0), ptr(w), ptr(bias), ptr(residual),
+        residual.stride(0) if residual is not None else 0, acc.data_ptr(), acc.stride(0), M, N, K,
+        stream()), 'vh_linear_acc64')
+    return acc
+
+
+def linear_x64(a, w, bias=None, residual64=None, out=None):
+    """out = a @ w.T + bias [+ residual64, cleared as read].  Exactly one of `a` (float64 rows) and
+    `residual64` is in the fp64 accumulator form."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
+    if residual64 is not None and (residual64.dtype != torch.float64 or residual64.stride(1) != 1):
+        raise _lib.VhError('linear_x64: residual64 must be a row-major float64 tensor')
+    check(_lib.lib().vh_linear_x64(
+        _f32_or_f64(a, 'a').data_ptr(), int(a.dtype == torch.float64), a.stride(0), ptr(w), ptr(bias),
+        ptr(residual64), residual64.stride(0) if residual64 is not None else 0, out.data_ptr(),
+        out.stride(0), M, N, K, stream()), 'vh_linear_x64')
+    return out
 
 
 def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_dev=None,
@@ -203,13 +238,21 @@ def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=
     return out
 
 
+def _x_next_ptrs(x_next):
+    """(fp32 pointer, fp64 pointer) for the next-embedding output: a float64 tensor is the fp64
+    accumulator form of the residual stream (linear_acc64)."""
+    if not x_next.is_contiguous():
+        raise _lib.VhError('x_next must be contiguous')
+    return (None, ptr(x_next)) if x_next.dtype == torch.float64 else (ptr(x_next), None)
+
+
 def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next,
                 pos_base=None):
     B = logits.shape[0]
     d = x_next.shape[1]
     check(_lib.lib().vh_greedy_step(
         logits.data_ptr(), logits.stride(0), V, eos, ptr(codes), codes.stride(0), ptr(eos_count),
-        ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
+        ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next), B, d,
         stream()), 'vh_greedy_step')
 
 
@@ -220,8 +263,8 @@ def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_coun
     check(_lib.lib().vh_sample_step(
         logits.data_ptr(), logits.stride(0), V, eos, int(top_k), float(top_p), float(temperature),
         int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
-        ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(x_next), B, d,
-        stream()), 'vh_sample_step')
+        ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next),
+        B, d, stream()), 'vh_sample_step')
 
 
 def gemm(a, b, out, a_kmajor=False, b_kmajor=False):
