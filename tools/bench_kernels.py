@@ -116,7 +116,9 @@ def bench_gemm():
         'out-proj (N=512,K=512)': lambda: K.linear(x, wo[nxt()], bo, o1, out=o1),
         'ffn1+ln  (N=2048,K=512)': lambda: K.linear(x, w1[nxt()], b1, out=o2, act=1, ln=ln),
         'ffn2     (N=512,K=2048)': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
-        'ffn2-splitk (N=512,K=2048)': lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2),
+        'ffn2-splitk reduce=64thr': tuned(3, 64, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
+        'ffn2-splitk reduce=128thr': tuned(3, 128, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
+        'ffn2-splitk reduce=256thr': tuned(3, 256, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
     }
     # graph-captured so the Python/ctypes launch cost is out of the picture
     for name, fn in cases.items():

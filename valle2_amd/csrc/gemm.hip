@@ -787,7 +787,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
 // =============================================================================================
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int n_split,
                                                             GemmArgs a, int lds_) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int ngroups = lds_ / 4;
     const int m = idx / ngroups, n = (idx - m * ngroups) * 4;
     if (m >= a.M || n >= a.N) return;
@@ -1173,7 +1173,9 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
     else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
     const int items = M * (lds_ / 4);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items + 255) / 256), dim3(256), 0, s,
+    // small workgroups: the slabs (splits x 64 KB) are pulled through as many CUs as possible
+    const int rb = vh_tuning(VH_TUNE_REDUCE_BLOCK) > 0 ? vh_tuning(VH_TUNE_REDUCE_BLOCK) : 128;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items + rb - 1) / rb), dim3(rb), 0, s,
                        (const float*)workspace, splits, fin, lds_);
     VH_CHECK_LAUNCH("vh_linear_ws");
     return VH_OK;
