@@ -287,6 +287,21 @@ int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, c
 /* bias gradient: out[c] += sum_r x[r, c] */
 int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
 
+/* ---- optimizer step over one flat fp32 buffer ------------------------------------------------
+ * replaces optim.AdamW(fused) (valle/models/valle_ar.py:182-194), the global-norm clip
+ * `gradient_clip_val` of the Trainer (valle/train_model.py:31-32) and the 1/world scale after the
+ * gradient all-reduce, in two launches with no host read:
+ *   norm = grad_scale * ||grad||_2 (double accumulation, fixed order: reproducible);
+ *   coef = max_norm > 0 ? min(1, max_norm / (norm + 1e-6)) : 1;   g = grad * grad_scale * coef;
+ *   p *= 1 - lr*wd;  m += (g - m)(1-b1);  v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)       (torch.optim.AdamW, amsgrad off).
+ * param/grad/exp_avg/exp_avg_sq: n floats each (n % 4 == 0); zero_grad != 0 clears grad afterwards;
+ * norm_out (1 float, optional) receives norm; workspace: vh_adamw_ws_bytes() bytes. */
+size_t vh_adamw_ws_bytes(void);
+int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  float max_norm, int zero_grad, void* workspace, float* norm_out, void* stream);
+
 /* General batched fp32 GEMM of the backward pass: C[b,h] = op(A[b,h]) . op(B[b,h]) on the fp32 matrix
  * cores (128x128x32 tiles).  a_kmajor = 0: A stored (M,K) k contiguous; 1: stored (K,M) m contiguous.
  * b_kmajor = 0: B stored (N,K) (an nn.Linear weight as stored); 1: stored (K,N).  C is (M,N) ldc.

@@ -33,6 +33,61 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _reducer_worker(rank, world, port, out):
+    """GradReducer on a toy model: flat gradient views, hooks firing during backward, two buckets,
+    gradient accumulation with the exchange on the last micro-batch only."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dp.init_distributed('gloo')
+    from valle2_amd.optim import flat_layout
+    torch.manual_seed(0)                                   # same weights on both ranks
+    model = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Tanh(), torch.nn.Linear(10, 5),
+                                torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    params = list(model.parameters())
+    slots, total = flat_layout(params)
+    flat = torch.zeros(total)
+    for p, off, n in slots:
+        p.grad = flat[off:off + n].view_as(p)
+    red = dp.GradReducer(flat, slots, bucket_bytes=160)    # 40 floats per bucket → several buckets
+    g = torch.Generator().manual_seed(100 + rank)
+    xs = [torch.randn(4, 6, generator=g) for _ in range(2)]
+    for i, x in enumerate(xs):                             # 2 micro-batches, exchange on the last
+        red.enabled = i == 1
+        model(x).square().sum().backward()
+    launched_in_backward = sum(w is not None for w in red._work)
+    red.finish()
+    # reference: plain autograd on fresh copies, summed over micro-batches
+    ref_model = torch.nn.Sequential(torch.nn.Linear(6, 10), torch.nn.Tanh(), torch.nn.Linear(10, 5),
+                                    torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    ref_model.load_state_dict(model.state_dict())
+    for x in xs:
+        ref_model(x).square().sum().backward()
+    local = [p.grad.clone() for p in ref_model.parameters()]
+    out.put((rank, len(red.buckets), launched_in_backward, [t.tolist() for t in local],
+             [p.grad.tolist() for p in params], all(p.grad.data_ptr() == red.view_of[id(p)].data_ptr() for p in params)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_overlapped_buckets_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, nb0, inb0, l0, r0, v0), (_, nb1, inb1, l1, r1, v1) = res
+    assert nb0 == nb1 and nb0 >= 2 and v0 and v1
+    assert inb0 >= 1 and inb1 >= 1                      # at least one bucket left during backward
+    for a, b, ra, rb in zip(l0, l1, r0, r1):
+        total = torch.tensor(a) + torch.tensor(b)        # SUM over ranks (the mean is the optimizer's grad_scale)
+        assert torch.allclose(torch.tensor(ra), total, atol=1e-6) and torch.allclose(torch.tensor(rb), total, atol=1e-6)
+
+
 def test_two_rank_gloo():
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')

@@ -179,3 +179,69 @@ def test_train_loop_reduces_the_loss(tmp_path):
     model, losses = train(cfg, 'ValleAR', batches=[fixed] * 24, log=logs.append)
     assert len(losses) == 24 and len(logs) == 3
     assert sum(losses[-4:]) / 4 < 0.8 * sum(losses[:4]) / 4, losses
+
+
+# ---- optimizer step (optim.FlatAdamW = AdamW + global-norm clip + 1/world scale in one flat pass) ---------
+@pytest.mark.parametrize('max_norm,grad_scale', [(1.0, 1.0), (0.0, 0.5), (1e9, 0.25)])
+def test_flat_adamw_matches_torch_adamw_and_clip(max_norm, grad_scale):
+    from valle2_amd.optim import FlatAdamW
+    shapes = [(7, 5), (13,), (64, 64), (1025, 128), (3,), (2, 3, 4)]
+    g0 = torch.Generator().manual_seed(7)
+    init = [torch.randn(*s, generator=g0) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    kw = dict(lr=3e-3, betas=(0.9, 0.95), weight_decay=0.05)
+    opt = FlatAdamW(mine, **kw)
+    ropt = torch.optim.AdamW(ref, eps=1e-8, **kw)
+    for p in mine:                                           # parameters live in the flat buffer, 16-B aligned
+        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0
+    for step in range(6):
+        lr = 3e-3 * (1.0 - 0.1 * step)                       # a scheduler changing the group's lr
+        opt.param_groups[0]['lr'] = ropt.param_groups[0]['lr'] = lr
+        grads = [(10.0 if step == 2 else 1.0) * torch.randn(*s, generator=g0) for s in shapes]
+        for p, r, g in zip(mine, ref, grads):
+            p.grad.copy_(g.to(DEV))
+            r.grad = (g * grad_scale).to(DEV)
+        norm = opt.step(grad_scale=grad_scale, max_norm=max_norm, zero_grad=True)
+        ref_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm if max_norm > 0 else float('inf'))
+        ropt.step()
+        torch.testing.assert_close(norm.cpu().reshape(()), ref_norm.cpu().reshape(()), rtol=1e-5, atol=0)
+        for p, r in zip(mine, ref):
+            torch.testing.assert_close(p.detach().cpu(), r.detach().cpu(), rtol=2e-5, atol=2e-7)
+            assert float(p.grad.abs().sum()) == 0.0          # zero_grad=True cleared the flat gradient
+    # bitwise reproducible: the same sequence again gives the same bits
+    again = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    opt2 = FlatAdamW(again, **kw)
+    g1 = torch.Generator().manual_seed(7)
+    _ = [torch.randn(*s, generator=g1) for s in shapes]
+    for step in range(6):
+        opt2.param_groups[0]['lr'] = 3e-3 * (1.0 - 0.1 * step)
+        for p, s in zip(again, shapes):
+            p.grad.copy_(((10.0 if step == 2 else 1.0) * torch.randn(*s, generator=g1)).to(DEV))
+        opt2.step(grad_scale=grad_scale, max_norm=max_norm, zero_grad=True)
+    assert torch.equal(opt.flat_param, opt2.flat_param)
+
+
+def test_flat_adamw_drives_the_model_and_invalidates_folded_weights():
+    """configure_optimizers → FlatAdamW: module parameters become views of the flat buffer, a step
+    changes what the kernels read, and the decode path's folded LayerNorm weights are rebuilt."""
+    from tests.test_models_gpu import build
+    from valle2_amd import engine
+    kw, sd, batch = C.ar_train_inputs()
+    model = build('ValleAR', kw, sd).train()
+    before = engine.folded_layer_norms(model.transformer)
+    conf = model.configure_optimizers()
+    opt, sched = conf['optimizer'], conf['lr_scheduler']
+    assert all(p.data_ptr() >= opt.flat_param.data_ptr() for p in model.parameters())
+    loss0 = model.training_step({k: v.clone() for k, v in batch.items()})
+    loss0.backward()
+    assert all(s[0].grad.data_ptr() == opt.grad_view(s).data_ptr() for s in opt.slots)   # accumulated in place
+    opt.step(max_norm=model.config.gradient_clip_val, zero_grad=True)
+    sched.step()
+    after = engine.folded_layer_norms(model.transformer)
+    assert after is not before
+    w = model.transformer.layers[0].self_attn.qkv.weight.detach()
+    g = model.transformer.layers[0].norm1.weight.detach()
+    torch.testing.assert_close(after[0][0][0], w * g, rtol=0, atol=0)
+    loss1 = model.training_step({k: v.clone() for k, v in batch.items()})
+    assert float(loss1.detach()) < float(loss0.detach())

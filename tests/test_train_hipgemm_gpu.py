@@ -43,7 +43,7 @@ def test_both_engines_agree():
         model = build('ValleAR', kw, sd)
         loss = model.training_step({k: v.clone() for k, v in batch.items()})
         loss.backward()
-        grads[engine] = {n: p.grad.clone() for n, p in model.named_parameters()}, float(loss)
+        grads[engine] = {n: p.grad.clone() for n, p in model.named_parameters()}, float(loss.detach())
     # the forward is the same kernels; the mean loss is an fp32 atomic sum (order varies per run)
     assert abs(grads['hip'][1] - grads['library'][1]) < 1e-5 * abs(grads['library'][1])
     for n, g in grads['hip'][0].items():

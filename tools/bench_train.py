@@ -25,8 +25,8 @@ def main(steps=5):
                           batch_size=16)
         torch.manual_seed(0)
         model = get_model_class(name)(cfg).to(dev).train()
-        opt = model.configure_optimizers()['optimizer']
-        params = [p for p in model.parameters() if p.requires_grad]
+        opt = model.configure_optimizers()['optimizer']          # optim.FlatAdamW
+        reducer = dp.GradReducer(opt.flat_grad, opt.slots)
         times, phases = [], []
         for i in range(steps + 2):
             if name == 'ValleAR':
@@ -41,10 +41,8 @@ def main(steps=5):
             loss.backward()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
-            dp.allreduce_mean_([p.grad for p in params if p.grad is not None])
-            torch.nn.utils.clip_grad_norm_(params, cfg.gradient_clip_val)
-            opt.step()
-            opt.zero_grad(set_to_none=True)
+            reducer.finish()                                     # buckets were launched during backward
+            opt.step(grad_scale=1.0 / world, max_norm=cfg.gradient_clip_val, zero_grad=True)
             torch.cuda.synchronize()
             t3 = time.perf_counter()
             if i >= 2:
@@ -54,7 +52,7 @@ def main(steps=5):
             f, b, o = (sum(p[k] for p in phases) / len(phases) * 1e3 for k in range(3))
             rows = batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])
             print(f'{name}: {sum(times) / len(times) * 1e3:.1f} ms/step (fwd {f:.1f}, bwd {b:.1f}, '
-                  f'allreduce+clip+AdamW {o:.1f}) world={world} last batch rows={rows} loss={float(loss):.3f} '
+                  f'allreduce tail + clip + AdamW {o:.1f}) world={world} last batch rows={rows} loss={float(loss.detach()):.3f} '
                   f'peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
 
 

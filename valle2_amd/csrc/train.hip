@@ -338,3 +338,91 @@ extern "C" int vh_colsum(const float* x, int ld, float* out, int rows, int cols,
     VH_CHECK_LAUNCH("vh_colsum");
     return VH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Optimizer step over ONE flat fp32 buffer (valle/models/valle_ar.py:182-194 AdamW; global-norm clip
+// of valle/train_model.py:31-32; the 1/world scale of the gradient all-reduce).  Two launches, no
+// host read: (1) per-workgroup partial sums of g^2 in double, (2) every workgroup adds the partials
+// in the same fixed order (reproducible), derives the clip coefficient and updates its slice.
+// ---------------------------------------------------------------------------------------------
+#define VH_SUMSQ_BLOCKS 1024
+
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ g, int64_t n4,
+                                                             double* __restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = ld4(g + 4 * i);
+        acc += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    __shared__ double s[4];
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v,
+                                                         int64_t n4, const double* __restrict__ partials,
+                                                         float lr, float beta1, float beta2, float eps,
+                                                         float weight_decay, float bc1, float sqrt_bc2,
+                                                         float grad_scale, float max_norm, int zero_grad,
+                                                         float* __restrict__ norm_out) {
+    // total gradient norm: 1024 partials, 4 per thread, fixed order
+    __shared__ double s[4];
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < VH_SUMSQ_BLOCKS / 256; ++i) acc += partials[threadIdx.x * (VH_SUMSQ_BLOCKS / 256) + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float total_norm = (float)sqrt((s[0] + s[1]) + (s[2] + s[3])) * grad_scale;
+    if (norm_out && blockIdx.x == 0 && threadIdx.x == 0) *norm_out = total_norm;
+    // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+    const float coef = max_norm > 0.f ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;
+    const float gs = grad_scale * coef;
+    const float decay = 1.0f - lr * weight_decay, step_size = lr / bc1;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 gg = ld4(g + 4 * i) * gs;
+        f32x4 pp = ld4(p + 4 * i) * decay;
+        f32x4 mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+        mm = mm + (gg - mm) * (1.0f - beta1);                 // lerp, weight < 0.5
+        vv = vv * beta2 + gg * gg * (1.0f - beta2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pp[j] -= step_size * (mm[j] / (sqrtf(vv[j]) / sqrt_bc2 + eps));
+        st4(p + 4 * i, pp);
+        st4(m + 4 * i, mm);
+        st4(v + 4 * i, vv);
+        if (zero_grad) st4(g + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+}
+
+extern "C" size_t vh_adamw_ws_bytes(void) { return VH_SUMSQ_BLOCKS * sizeof(double); }
+
+extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                             float grad_scale, float max_norm, int zero_grad, void* workspace,
+                             float* norm_out, void* stream) {
+    VH_REQUIRE(param && grad && exp_avg && exp_avg_sq && workspace, VH_EINVAL, "vh_adamw_flat: null pointer");
+    VH_REQUIRE(n >= 0 && n % 4 == 0, VH_EINVAL, "vh_adamw_flat: n=%lld must be a multiple of 4", (long long)n);
+    VH_REQUIRE(step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
+               VH_EINVAL, "vh_adamw_flat: step=%d lr=%g betas=(%g,%g) eps=%g", step, lr, beta1, beta2, eps);
+    VH_REQUIRE(vh_aligned16(param) && vh_aligned16(grad) && vh_aligned16(exp_avg) && vh_aligned16(exp_avg_sq) &&
+                   vh_aligned16(workspace),
+               VH_EALIGN, "vh_adamw_flat: pointers must be 16-byte aligned");
+    if (n == 0) return VH_OK;
+    const int64_t n4 = n / 4;
+    hipStream_t s = (hipStream_t)stream;
+    double* partials = (double*)workspace;
+    hipLaunchKernelGGL(sumsq_partials_kernel, dim3(VH_SUMSQ_BLOCKS), dim3(256), 0, s, grad, n4, partials);
+    // bias corrections in double on the host, as torch.optim does in Python floats
+    const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n4,
+                       partials, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale,
+                       max_norm, zero_grad, norm_out);
+    VH_CHECK_LAUNCH("vh_adamw_flat");
+    return VH_OK;
+}

@@ -77,3 +77,78 @@ def allreduce_mean_(tensors, bucket_bytes: int = 64 << 20):
         if size >= bucket_bytes:
             flush()
     flush()
+
+
+class GradReducer:
+    """Sum-all-reduce of a flat gradient buffer, overlapped with backward.
+
+    `slots` = [(param, offset, numel)] laid out in the order backward produces gradients
+    (`optim.flat_layout`).  The buffer is cut into buckets of about `bucket_bytes` on parameter
+    boundaries; a post-accumulate hook on every parameter counts arrivals and, when a bucket is
+    complete, starts its all-reduce asynchronously on the communicator's stream while backward keeps
+    computing the earlier layers.  `finish()` starts whatever is left (parameters that received no
+    gradient), waits, and returns; the 1/world mean is left to the optimizer kernel (`grad_scale`).
+    Few large messages: xGMI is point-to-point, 7 links per GPU, so a bucket is sized per link
+    (64 MB default ≈ 3 buckets for the 156 MB AR model), not for a switch.
+    """
+
+    def __init__(self, flat_grad: torch.Tensor, slots, bucket_bytes: int = 64 << 20):
+        self.flat = flat_grad
+        self.enabled = True
+        self.buckets = []          # (start, end, n_params)
+        self.bucket_of = {}
+        self.view_of = {id(p): flat_grad[off:off + n].view_as(p) for p, off, n in slots}
+        start, count = 0, 0
+        end = 0
+        for p, off, n in slots:
+            self.bucket_of[id(p)] = len(self.buckets)
+            count += 1
+            end = off + n
+            if (end - start) * flat_grad.element_size() >= bucket_bytes:
+                self.buckets.append((start, end, count))
+                start, count = end, 0
+        if count:
+            self.buckets.append((start, end, count))
+        if self.buckets:                                   # the padded tail belongs to the last bucket
+            s0, _, c0 = self.buckets[-1]
+            self.buckets[-1] = (s0, flat_grad.numel(), c0)
+        self._arrived = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p, _, _ in slots]
+
+    @property
+    def active(self):
+        return self.enabled and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        if not self.active:
+            return
+        view = self.view_of[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != view.data_ptr():   # autograd replaced the view
+            view.copy_(p.grad)
+            p.grad = view
+        b = self.bucket_of[id(p)]
+        self._arrived[b] += 1
+        if self._arrived[b] == self.buckets[b][2] and self._work[b] is None:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward of the last micro-batch: every bucket reduced when this returns (on
+        the current stream for NCCL/RCCL)."""
+        if self.active:
+            for b in range(len(self.buckets)):
+                if self._work[b] is None:
+                    self._launch(b)
+            for w in self._work:
+                w.wait()
+        self._arrived = [0] * len(self.buckets)
+        self._work = [None] * len(self.buckets)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -59,6 +59,16 @@ ACC64_RESIDUAL = os.environ.get('VALLE2_ACC64', '0') == '1'     # residual strea
                                                                  # 12L/512d, kept as an option.
 
 
+_WEIGHTS_EPOCH = 0
+
+
+def bump_weights_epoch():
+    """Called by code that rewrites parameters behind torch's back (the flat optimizer kernel), so
+    that derived weights (the folded LayerNorm forms) are rebuilt."""
+    global _WEIGHTS_EPOCH
+    _WEIGHTS_EPOCH += 1
+
+
 def folded_layer_norms(transformer):
     """Per layer ((Wqkv∘γ1, c1, c2), (W1∘γ2, c1, c2)) for the decode step, or None when the shape is
     outside the folded kernels (d_model not in {128,256,512,1024}) or the norms are adaptive.  Cached
@@ -70,7 +80,7 @@ def folded_layer_norms(transformer):
         return None
     srcs = [(l.norm1.weight, l.norm1.bias, l.self_attn.qkv.weight, l.norm2.weight, l.norm2.bias,
              l.ffn.linear_1.weight, l.ffn.linear_1.bias) for l in layers]
-    key = tuple((t.data_ptr(), t._version) for ps in srcs for t in ps)
+    key = (_WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version) for ps in srcs for t in ps)
     cached = getattr(transformer, '_vh_folded', None)
     if cached is not None and cached[0] == key:
         return cached[1]

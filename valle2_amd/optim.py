@@ -1,0 +1,115 @@
+"""Optimizer step of the training path: `FlatAdamW` keeps parameters, gradients and
+both AdamW moments in ONE flat fp32 buffer each, so that
+
+  * the gradient all-reduce runs on contiguous slices of the flat gradient (no pack / unpack copies,
+    `dp.GradReducer` launches each slice as soon as backward has filled it), and
+  * AdamW (valle/models/valle_ar.py:182-194), the global-norm clip (`gradient_clip_val`,
+    valle/train_model.py:31-32) and the 1/world mean of the all-reduce are one elementwise HIP pass
+    (`vh_adamw_flat`: one partial-norm launch + one update launch, no host read of the norm).
+
+It subclasses `torch.optim.Optimizer` only for the `param_groups` contract the reference's
+`CosineAnnealingWarmRestarts` scheduler drives (`lr` is read from the group at every step).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+ALIGN = 4   # floats: every parameter view starts 16-byte aligned (the GEMM kernels require it)
+
+
+def flat_layout(params):
+    """[(param, offset, numel)] in REVERSE registration order (backward produces gradients roughly
+    last layer first, so the first slices of the flat buffer fill first) and the padded total."""
+    slots, off = [], 0
+    for p in reversed(list(params)):
+        slots.append((p, off, p.numel()))
+        off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+    return slots, off
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError('FlatAdamW: no trainable parameters')
+        dev = params[0].device
+        if any(p.dtype != torch.float32 or p.device != dev for p in params):
+            raise _lib.VhError('FlatAdamW: parameters must be fp32 on one device')
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.slots, self.numel = flat_layout(params)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.flat_param = torch.zeros(self.numel, **f32)
+        self.flat_grad = torch.zeros(self.numel, **f32)
+        self.exp_avg = torch.zeros(self.numel, **f32)
+        self.exp_avg_sq = torch.zeros(self.numel, **f32)
+        self.grad_norm = torch.zeros(1, **f32)
+        self._ws = None
+        self.steps = 0
+        with torch.no_grad():
+            for p, off, n in self.slots:
+                view = self.flat_param[off:off + n].view_as(p)
+                view.copy_(p)
+                p.data = view                      # the module now computes on the flat buffer
+        self._point_grads()
+
+    # ---- gradient views -------------------------------------------------------------------------
+    def grad_view(self, slot):
+        p, off, n = slot
+        return self.flat_grad[off:off + n].view_as(p)
+
+    def _point_grads(self):
+        for slot in self.slots:
+            slot[0].grad = self.grad_view(slot)
+
+    def gather_grads(self):
+        """Autograd accumulates in place into the views; a gradient that was replaced (set_to_none,
+        a foreign zero_grad) is copied back into its slice."""
+        for slot in self.slots:
+            p, view = slot[0], self.grad_view(slot)
+            if p.grad is None:
+                view.zero_()
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+            p.grad = view
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()
+        self._point_grads()
+
+    # ---- the step -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None, *, grad_scale: float = 1.0, max_norm: float = 0.0, zero_grad: bool = False):
+        """One AdamW update of every parameter.  grad_scale multiplies the gradients first (1/world
+        after a sum all-reduce), max_norm > 0 clips their global norm as clip_grad_norm_ does.
+        Returns the (device) gradient norm after scaling, before clipping."""
+        if closure is not None:
+            raise _lib.VhError('FlatAdamW.step: closures are not supported')
+        self.gather_grads()
+        g = self.param_groups[0]
+        lib = _lib.lib()
+        if self._ws is None:
+            self._ws = torch.empty(lib.vh_adamw_ws_bytes() // 8, device=self.flat_param.device, dtype=torch.float64)
+        self.steps += 1
+        _lib.check(lib.vh_adamw_flat(
+            ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
+            float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
+            float(g['weight_decay']), self.steps, float(grad_scale), float(max_norm), int(zero_grad),
+            ptr(self._ws), ptr(self.grad_norm), torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
+        from . import engine
+        engine.bump_weights_epoch()                # the update bypasses torch's version counters
+        return self.grad_norm
+
+    # ---- checkpointing: the four flat buffers + the step count ------------------------------------
+    def state_dict(self):
+        return {'steps': self.steps, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+                'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.steps = int(sd['steps'])
+        self.exp_avg.copy_(sd['exp_avg'])
+        self.exp_avg_sq.copy_(sd['exp_avg_sq'])
+        for g, saved in zip(self.param_groups, sd['param_groups']):
+            g.update(saved)

@@ -1,8 +1,10 @@
 """`train(hparams_fp, model_name)` with the reference's signature (valle/train_model.py:13-35), as a
 plain data-parallel loop: one process per GPU (torch.distributed, RCCL over xGMI), per-rank
-micro-batches, one bucketed mean all-reduce of fp32 gradients per optimizer step (what Lightning's
-implicit DDP does for the reference), global-norm clipping (`gradient_clip_val`), gradient
-accumulation (`grad_accum`), AdamW + CosineAnnealingWarmRestarts from `configure_optimizers`.
+micro-batches, one sum all-reduce of the flat fp32 gradient per optimizer step, launched bucket by
+bucket while backward is still running (`dp.GradReducer`; what Lightning's implicit DDP does for the
+reference), then the 1/world mean, global-norm clipping (`gradient_clip_val`) and AdamW in one flat
+HIP pass (`optim.FlatAdamW`), CosineAnnealingWarmRestarts from `configure_optimizers`, gradient
+accumulation (`grad_accum`).
 
 The reference's data pipeline (HF dataset + g2p + on-the-fly EnCodec, valle/data.py) is out of
 scope: pass any iterable of collated batches as `batches`, or none to train on seeded synthetic
@@ -39,25 +41,26 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
     rank, world = dp.init_distributed(device=device if device.type == 'cuda' else None)
     torch.manual_seed(config.seed)                       # identical initial weights on every rank
     model = get_model_class(model_name)(config).to(device).train()
-    opt = model.configure_optimizers()
+    opt = model.configure_optimizers()                   # FlatAdamW + CosineAnnealingWarmRestarts
     optimizer, scheduler = opt['optimizer'], opt['lr_scheduler']
-    params = [p for p in model.parameters() if p.requires_grad]
+    reducer = dp.GradReducer(optimizer.flat_grad, optimizer.slots)
     accum = max(1, config.grad_accum)
     if batches is None:
         batches = synthetic_batches(model_name, config, rank, world, config.max_steps * accum)
     step, t0, losses = 0, time.perf_counter(), []
-    optimizer.zero_grad(set_to_none=True)
+    optimizer.zero_grad()
     for i, batch in enumerate(batches):
+        last = (i + 1) % accum == 0
+        reducer.enabled = last                           # accumulate locally, exchange once per step
         loss = model.training_step(batch)
-        (loss / accum).backward()
+        (loss / accum).backward()                        # buckets are all-reduced as they complete
         losses.append(float(loss.detach()))
-        if (i + 1) % accum:
+        if not last:
             continue
-        dp.allreduce_mean_([p.grad for p in params if p.grad is not None])
-        torch.nn.utils.clip_grad_norm_(params, config.gradient_clip_val)
-        optimizer.step()
+        reducer.finish()
+        # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
+        optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
         scheduler.step()
-        optimizer.zero_grad(set_to_none=True)
         step += 1
         if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
             log(f'step {step}: train/loss {sum(losses[-accum:]) / accum:.4f} '

@@ -246,7 +246,8 @@ class ValleAR(_Base):
 
     def configure_optimizers(self):
         """valle_ar.py:182-194"""
-        optimizer = optim.AdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
-                                weight_decay=self.config.weight_decay, fused=self.device.type == 'cuda')
+        from .optim import FlatAdamW           # AdamW(fused=True) as one flat HIP pass (+ clip, + 1/world)
+        optimizer = FlatAdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
+                              weight_decay=self.config.weight_decay)
         scheduler = optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, self.config.lr_warmup)
         return {'optimizer': optimizer, 'lr_scheduler': scheduler}

@@ -138,8 +138,9 @@ class ValleNAR(_Base):
     def configure_optimizers(self):
         """The reference's ValleNAR has no configure_optimizers; same recipe as AR."""
         from torch import optim
-        optimizer = optim.AdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
-                                weight_decay=self.config.weight_decay, fused=self.device.type == 'cuda')
+        from .optim import FlatAdamW
+        optimizer = FlatAdamW(self.parameters(), lr=self.config.lr, betas=self.config.betas,
+                              weight_decay=self.config.weight_decay)
         scheduler = optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, self.config.lr_warmup)
         return {'optimizer': optimizer, 'lr_scheduler': scheduler}
 
