@@ -55,7 +55,6 @@ const char* vh_last_error(void);
  * Results are identical up to fp32 summation order whatever the setting. */
 enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16-key pipelined */
        VH_TUNE_DECODE_WAVES = 1,    /* waves per decode-attention workgroup: 4, 8 or 16 */
-       VH_TUNE_GEMM_TILE = 2,       /* large-M GEMM tile: 1 = 128x128, 2 = 256x256 where it fits */
        VH_TUNE_REDUCE_BLOCK = 3,    /* threads per workgroup of the split-K reduce: 64, 128 (default), 256 */
        VH_TUNE_COUNT = 8 };
 int vh_set_tuning(int knob, int value);

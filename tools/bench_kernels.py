@@ -167,8 +167,8 @@ def bench_rows():
 
 
 def bench_tile():
-    """128x128 vs 256x256 tile kernel vs the library GEMM on the NAR-stage / prefill shapes."""
-    lib = _lib.lib()
+    """The tile GEMM (bias + residual epilogue, and the QKV scatter) vs the library GEMM on the
+    NAR-stage / prefill shapes."""
     B, T, h = 32, 1024, 8
     for M in (32 * 1024, 8 * 1024, 32 * 1500):
         for name, N, Kk in (('qkv', 1536, 512), ('out', 512, 512), ('ffn1', 2048, 512), ('ffn2', 512, 2048)):
@@ -178,34 +178,20 @@ def bench_tile():
             res = torch.randn(M, N, device=DEV)
             o = torch.empty(M, N, device=DEV)
             ref = torch.addmm(bias, a, w.t()) + res
-            line = f'tile M={M} {name} N={N} K={Kk}:'
-            for tune in (1, 2):
-                lib.vh_set_tuning(2, tune)
-                us = []
-                for _ in range(3):
-                    us.append(timeit(lambda: K.linear(a, w, bias, res, out=o), iters=10, warm=2))
-                err = float((o - ref).abs().max())
-                u = statistics.median(us)
-                line += f'  tile{128 * tune}: {u:7.1f} us {2 * M * N * Kk / u / 1e6:6.1f} TF (err {err:.1e})'
+            us = statistics.median(timeit(lambda: K.linear(a, w, bias, res, out=o), iters=10, warm=2) for _ in range(3))
+            err = float((o - ref).abs().max())
+            line = f'tile M={M} {name} N={N} K={Kk}: {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF (err {err:.1e})'
             us = timeit(lambda: torch.addmm(bias, a, w.t(), out=o), iters=10, warm=2)
             line += f'  library: {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF'
             print(line, flush=True)
-    # QKV scatter epilogue
     M = B * T
     x = torch.randn(M, 512, device=DEV)
     w = 0.02 * torch.randn(1536, 512, device=DEV)
-    outs = {}
-    for tune in (1, 2):
-        lib.vh_set_tuning(2, tune)
-        q = torch.zeros(M, 512, device=DEV)
-        kc = torch.zeros(B, h, T, 64, device=DEV)
-        vc = torch.zeros_like(kc)
-        us = timeit(lambda: K.linear_qkv(x, w, q, kc, vc, B, T, h), iters=10, warm=2)
-        outs[tune] = (q, kc, vc)
-        print(f'tile qkv-scatter tile{128 * tune}: {us:7.1f} us {2 * M * 1536 * 512 / us / 1e6:6.1f} TF', flush=True)
-    for x1, x2 in zip(outs[1], outs[2]):
-        print('  qkv-scatter max diff 128 vs 256:', float((x1 - x2).abs().max()))
-    lib.vh_set_tuning(2, 0)
+    q = torch.zeros(M, 512, device=DEV)
+    kc = torch.zeros(B, h, T, 64, device=DEV)
+    vc = torch.zeros_like(kc)
+    us = timeit(lambda: K.linear_qkv(x, w, q, kc, vc, B, T, h), iters=10, warm=2)
+    print(f'tile qkv-scatter: {us:7.1f} us {2 * M * 1536 * 512 / us / 1e6:6.1f} TF', flush=True)
 
 
 if __name__ == '__main__':

@@ -188,243 +188,115 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     gload(0);
     lstore(0);
 
-    // The residual tile and bias are fetched now, so the epilogue is stores only: two workgroups
-    // share a CU in lockstep and a load-latency-bound epilogue would leave the MFMA pipe idle.
-    f32x16 resv[2][2];
-    float nbias[2];
+    // Epilogue layout: the accumulators are transposed through LDS so that a lane owns 4 consecutive
+    // columns of one row: thread tid handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.
+    // A wave then stores (and reads the residual as) two whole 512-B rows per instruction, a quarter
+    // of the memory instructions of the accumulator layout (lane = column, 4 B per lane).  That count
+    // is what matters: the CU's memory pipeline is shared with the other workgroup's operand loads,
+    // and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the residual loads
+    // (tools/tile_diag.py).  Residual and bias are fetched NOW, so the epilogue waits for nothing.
+    const int ec4 = tid & 31, erow = tid >> 5;
+    const int en = n0 + 4 * ec4;
+    const bool ecol_full = en + 3 < a.N;
+    f32x4 resv[16];
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (EPI == EPI_PLAIN) {
+        if (a.bias && ecol_full) bias4 = ld4(a.bias + en);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + wn * 64 + nt * 32 + r;
-            nbias[nt] = (a.bias && n < a.N) ? a.bias[n] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    resv[mt][nt][e] = (a.res && m < a.M && n < a.N) ? a.res[(int64_t)m * a.ldr + n] : 0.f;
-                }
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + erow + 8 * it;
+            resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     __syncthreads();
+    // Main loop, software-pipelined by hand: the operand fragments of k-sub-step t+1 are read from LDS
+    // while the 16 MFMAs of sub-step t run (two register sets), and the first fragments of the next
+    // k-step are read right after the barrier, behind the last 16 MFMAs of this one.  Left to the
+    // compiler the loop was "8 ds_read, wait, 32 MFMA" twice per k-step.  (Worth about 1 %: with two
+    // workgroups per CU the other wave of the SIMD already covered most of that wait.)
+    f32x4 fa[2][2], fw[2][2];
+    auto fload = [&](int set, int buf, int t) {
+        const float* As = &lds[buf][0][(wm * 64 + r) * LDS_LD + 4 * h + 8 * t];
+        const float* Ws = &lds[buf][1][(wn * 64 + r) * LDS_LD + 4 * h + 8 * t];
+        fa[set][0] = ld4(As);
+        fa[set][1] = ld4(As + 32 * LDS_LD);
+        fw[set][0] = ld4(Ws);
+        fw[set][1] = ld4(Ws + 32 * LDS_LD);
+    };
+    fload(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) gload((kt + 1) * TK);
-        const float* As = &lds[cur][0][(wm * 64 + r) * LDS_LD + 4 * h];
-        const float* Ws = &lds[cur][1][(wn * 64 + r) * LDS_LD + 4 * h];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const f32x4 a0 = ld4(As + 8 * t), a1 = ld4(As + 32 * LDS_LD + 8 * t);
-            const f32x4 w0 = ld4(Ws + 8 * t), w1 = ld4(Ws + 32 * LDS_LD + 8 * t);
+            if (t < 3) fload((t + 1) & 1, cur, t + 1);
+            __builtin_amdgcn_sched_barrier(0);       // reads first: they fly under the 16 MFMAs below
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], w0[j], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], w1[j], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], w0[j], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], w1[j], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][0][j], fw[t & 1][0][j], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][0][j], fw[t & 1][1][j], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][1][j], fw[t & 1][0][j], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t & 1][1][j], fw[t & 1][1][j], acc[1][1], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (kt + 1 < nk) lstore(cur ^ 1);
         __syncthreads();
+        if (kt + 1 < nk) fload(0, cur ^ 1, 0);
     }
 
-    // epilogue: D reg e of tile (mt,nt): row = (e&3)+8(e>>2)+4h, col = r.  32 lanes of a half
-    // write 32 consecutive floats of one row (128 B), the other half another row.
-    // The column part of every address (and of the QKV scatter) is computed once per 32-column
-    // group, the row part once per row.
-    int ncol[2];
-    float* qbase[2];
-    bool qcache[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + wn * 64 + nt * 32 + r;
-        ncol[nt] = n;
-        qbase[nt] = nullptr;
-        qcache[nt] = false;
-        if (EPI == EPI_QKV && n < a.N) {
-            const int which = n >= 2 * a.d_model ? 2 : (n >= a.d_model ? 1 : 0);
-            const int c = n - which * a.d_model;
-            if (which == 0) {
-                qbase[nt] = a.out + c;
-            } else {
-                qbase[nt] = (which == 1 ? a.kc : a.vc) +
-                            (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
-                qcache[nt] = true;
-            }
-        }
-    }
+    // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
+    // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
+    constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
+    float* ct = &lds[0][0][0];                        // 128 x 132 floats = 66 KB of the 72 KB
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= a.M) continue;
-            if (EPI == EPI_QKV) {
-                const int b = m / a.T, t = m - b * a.T;
-                const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
-                const int64_t qrow = (int64_t)m * a.ldo;
-                const int64_t crow = ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM;
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    if (ncol[nt] < a.N) qbase[nt][qcache[nt] ? crow : qrow] = acc[mt][nt][e];
-            } else {
-                float* orow = a.out + (int64_t)m * a.ldo;
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    if (ncol[nt] >= a.N) continue;
-                    float s = acc[mt][nt][e] + nbias[nt];
-                    if (a.act == VH_ACT_GELU_ERF) s = gelu_erf(s);
-                    orow[ncol[nt]] = s + resv[mt][nt][e];
-                }
-            }
-        }
-}
-
-// =============================================================================================
-// Large-M, wide-N tile kernel: 256(M) x 256(N) x 32(K), 4 waves, each wave a 128x128 register tile
-// (4x4 accumulators of 32x32 = 256 accumulator registers per lane, one workgroup per CU).
-// Against the 128x128 kernel this halves the LDS fragment reads per MFMA (8 ds_read_b128 per 64
-// MFMAs) and quarters the L2→LDS bytes per flop: less energy per MFMA, so the chip sustains a higher
-// clock under the fp32 matrix load (the 128x128 main loop already issues MFMAs back to back; its
-// ceiling is the clock the chip gives, MI355X_MICROARCH "DVFS give-back").  The epilogue hoists the
-// row / column decompositions (QKV scatter) out of the 256-element store loop.
-// =============================================================================================
-#define BM 256
-#define BN 256
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_tile256_kernel(GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) float lds256[];   // [buf][A|W][256 * LDS_LD]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    constexpr int OP = BM * LDS_LD;   // floats per operand per buffer
-
-    const int srow = tid >> 3, skq = (tid & 7) * 4;
-    f32x4 ra[8], rw[8];
-    auto gload = [&](int k0) {
-        const int k = k0 + skq;
-        const bool kin = k < a.K;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = srow + 32 * i;
-            ra[i] = (m0 + row < a.M && kin) ? ld4(a.A + (int64_t)(m0 + row) * a.lda + k)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-            rw[i] = (n0 + row < a.N && kin) ? ld4(a.W + (int64_t)(n0 + row) * a.K + k)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto lstore = [&](int buf) {
-        float* base = lds256 + buf * 2 * OP;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int row = srow + 32 * i;
-            st4(base + row * LDS_LD + skq, ra[i]);
-            st4(base + OP + row * LDS_LD + skq, rw[i]);
-        }
-    };
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
-
-    const int nk = (a.K + TK - 1) / TK;
-    gload(0);
-    lstore(0);
+            for (int e = 0; e < 16; ++e)
+                ct[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * TK);
-        const float* As = lds256 + cur * 2 * OP + (wm * 128 + r) * LDS_LD + 4 * h;
-        const float* Ws = lds256 + cur * 2 * OP + OP + (wn * 128 + r) * LDS_LD + 4 * h;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            f32x4 af[4], wf[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) {
-                af[x] = ld4(As + x * 32 * LDS_LD + 8 * t);
-                wf[x] = ld4(Ws + x * 32 * LDS_LD + 8 * t);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int x = 0; x < 4; ++x)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[x][j], wf[y][j], acc[x][y], 0, 0, 0);
-        }
-        if (kt + 1 < nk) lstore(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue.  column part (per y): n, bias, QKV destination; row part (per x,e): m, QKV row offset
-    int ncol[4];
-    float nbias[4];
-    float* qbase[4];      // EPI_QKV: base pointer of column n (q matrix, K cache or V cache) without the row term
-    bool qcache[4];
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        const int n = n0 + wn * 128 + y * 32 + r;
-        ncol[y] = n;
-        nbias[y] = (EPI == EPI_PLAIN && a.bias && n < a.N) ? a.bias[n] : 0.f;
-        qbase[y] = nullptr;
-        qcache[y] = false;
-        if (EPI == EPI_QKV && n < a.N) {
-            const int which = n >= 2 * a.d_model ? 2 : (n >= a.d_model ? 1 : 0);
-            const int c = n - which * a.d_model;
-            if (which == 0) {
-                qbase[y] = a.out + c;
-            } else {
-                const int head = c >> 6, e = c & 63;   // VH_HEAD_DIM == 64
-                qbase[y] = (which == 1 ? a.kc : a.vc) + (int64_t)head * a.S_max * VH_HEAD_DIM + e;
-                qcache[y] = true;
-            }
+    if (en >= a.N) return;
+    // column part of the destination, once per thread
+    float* qdst = nullptr;
+    bool qcache = false;
+    if (EPI == EPI_QKV) {
+        const int which = en >= 2 * a.d_model ? 2 : (en >= a.d_model ? 1 : 0);
+        const int c = en - which * a.d_model;
+        if (which == 0) {
+            qdst = a.out + c;
+        } else {
+            qdst = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
+            qcache = true;
         }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
-        // residual rows of this 32-row group, all 64 loads in flight before the first store (out and
-        // res may be the same buffer, so the compiler cannot hoist them itself)
-        f32x16 resv[4];
-        if (EPI == EPI_PLAIN) {
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int m = m0 + wm * 128 + x * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    resv[y][e] = (a.res && m < a.M && ncol[y] < a.N) ? a.res[(int64_t)m * a.ldr + ncol[y]] : 0.f;
-                }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + wm * 128 + x * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (m >= a.M) continue;
-            if (EPI == EPI_QKV) {
+    for (int it = 0; it < 16; ++it) {
+        const int row = erow + 8 * it, m = m0 + row;
+        if (m >= a.M) break;
+        f32x4 v = ld4(ct + row * LDC + 4 * ec4);
+        if (EPI == EPI_QKV) {                          // N = 3 d_model, a multiple of 4: groups are whole
+            if (qcache) {
                 const int b = m / a.T, t = m - b * a.T;
                 const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
-                const int64_t qrow = (int64_t)m * a.ldo;
-                const int64_t crow = ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM;
-#pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    if (ncol[y] < a.N) qbase[y][qcache[y] ? crow : qrow] = acc[x][y][e];
+                st4(qdst + ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM, v);
             } else {
-                float* orow = a.out + (int64_t)m * a.ldo;
-#pragma unroll
-                for (int y = 0; y < 4; ++y) {
-                    if (ncol[y] >= a.N) continue;
-                    float s = acc[x][y][e] + nbias[y];
-                    if (a.act == VH_ACT_GELU_ERF) s = gelu_erf(s);
-                    orow[ncol[y]] = s + resv[y][e];
-                }
+                st4(qdst + (int64_t)m * a.ldo, v);
+            }
+        } else if (ecol_full) {
+            v += bias4;
+            if (a.act == VH_ACT_GELU_ERF) {
+                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            }
+            st4(a.out + (int64_t)m * a.ldo + en, v + resv[it]);
+        } else {                                       // ragged last column group (e.g. N = 1025 logits)
+            for (int j = 0; j < 4 && en + j < a.N; ++j) {
+                float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
+                if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
+                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
+                a.out[(int64_t)m * a.ldo + en + j] = sv;
             }
         }
     }
@@ -942,28 +814,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         }
 #undef SK
     } else {
-        const int tm2 = (a.M + BM - 1) / BM, tn2 = (a.N + BN - 1) / BN;
-        const int tune = vh_tuning(VH_TUNE_GEMM_TILE);
-        // 256x256 tiles only when they fill the chip at one workgroup per CU and waste little on edges
-        // (measured, DESIGN.md §5: +10 % on the QKV scatter, no gain with the plain epilogue)
-        const bool big = tune == 2 || (tune == 0 && EPI == EPI_QKV && tm2 * tn2 >= 192 &&
-                                       (int64_t)tm2 * BM * tn2 * BN <= (int64_t)a.M * a.N * 9 / 8);
-        if (big) {
-            constexpr int lds_bytes = 2 * 2 * BM * LDS_LD * (int)sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                hipError_t e = hipFuncSetAttribute((const void*)gemm_tile256_kernel<EPI>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-                VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "%s: cannot reserve %d B of LDS: %s", name,
-                           lds_bytes, hipGetErrorString(e));
-                attr_set = true;
-            }
-            hipLaunchKernelGGL((gemm_tile256_kernel<EPI>), dim3(tm2 * tn2), dim3(256), lds_bytes, s, a,
-                               tm2, tn2);
-        } else {
-            const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
-            hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
-        }
+        const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
+        hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
     }
     VH_CHECK_LAUNCH(name);
     return VH_OK;
