@@ -122,9 +122,12 @@ def main():
 
     from valle2_amd import ConfigValle, dp, get_model_class, synth
 
+    # rehearsal knobs (a one-GPU box, several ranks on `gloo`): VALLE2_FORCE_DEVICE, VALLE2_DIST_BACKEND
+    local = int(os.environ.get('VALLE2_FORCE_DEVICE', local))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dp.init_distributed('nccl', dev)                         # "nccl" is RCCL on ROCm; no-op at N=1
+    backend = os.environ.get('VALLE2_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; no-op at N=1
+    dp.init_distributed(backend, dev)
 
     rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
     ar_kw = dict(AR)
