@@ -30,7 +30,10 @@ def _mm(a, b, out, a_kmajor=False, b_kmajor=False):
         return kernels.gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
     left = a.transpose(-1, -2) if a_kmajor else a
     right = b if b_kmajor else b.transpose(-1, -2)
-    out.copy_(torch.matmul(left, right))
+    if out.is_contiguous():
+        torch.matmul(left, right, out=out)      # straight into the result: no temporary, no copy
+    else:
+        out.copy_(torch.matmul(left, right))    # strided gradient views (dq/dk/dv inside dqkv): small
     return out
 
 
@@ -164,17 +167,39 @@ class QkvAttentionFn(torch.autograd.Function):
         do = dout.contiguous().view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)
         dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
         dq, dk, dv = (dqkv.view(B, T, 3, h, HEAD_DIM)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
-        dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        if BACKWARD_GEMM == 'library' and tp != T:
+            # the (T,T) maps keep a 16-byte row stride: give K and V tp - T zero rows, so the library
+            # GEMMs write whole dense (T,tp) maps (their pad columns are exact zeros) instead of
+            # producing a temporary that is then copied into a strided view — 1 GB per layer at T = 1000
+            kp = torch.zeros(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
+            vp = torch.zeros_like(kp)
+            kp[:, :, :T] = k
+            vp[:, :, :T] = v
+            k, v = kp, vp
+            P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)
+            dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)
+        else:
+            P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+            dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
         _mm(qh, k, P)                                                     # S = Q K^T (raw scores)
         check(L.vh_softmax_rows(P.data_ptr(), tp, B, h, T, T, scale, spec['mode'], spec.get('x_len', 0),
                                 ptr(spec.get('x_len_dev')), ptr(spec.get('kv_len')), ptr(spec.get('mask')),
                                 ptr(spec.get('pad')), stream()), 'vh_softmax_rows')
-        _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                      # dV = P^T dO   → dqkv[:, 2d:]
+        if P.shape[-1] != T:
+            dvp = torch.empty(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
+            _mm(P, do, dvp, a_kmajor=True, b_kmajor=True)
+            dv.copy_(dvp[:, :, :T])
+        else:
+            _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                  # dV = P^T dO   → dqkv[:, 2d:]
         _mm(do, v, dP)                                                    # dP = dO V^T
         check(L.vh_softmax_bwd(P.data_ptr(), dP.data_ptr(), tp, B * h * T, T, scale, stream()), 'vh_softmax_bwd')
         _mm(dP, k, dq, b_kmajor=True)                                     # dQ = dS K     → dqkv[:, :d]
-        _mm(dP, qh, dk, a_kmajor=True, b_kmajor=True)                     # dK = dS^T Q   → dqkv[:, d:2d]
+        if P.shape[-1] != T:                                              # padded maps: dK/dV rows >= T are zeros
+            dkp = torch.empty(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
+            _mm(dP, qh, dkp, a_kmajor=True, b_kmajor=True)
+            dk.copy_(dkp[:, :, :T])
+        else:
+            _mm(dP, qh, dk, a_kmajor=True, b_kmajor=True)                 # dK = dS^T Q   → dqkv[:, d:2d]
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = _mm(dqkv, wqkv, torch.empty_like(x), b_kmajor=True)

@@ -17,7 +17,7 @@ __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.
 //   du = dy*s;  dgamma += sum_rows du*xhat;  dbeta += sum_rows du;  ds += sum_rows dy*u;  dt += sum_rows dy
 //   g = du*gamma;  dx = rstd*(g - mean(g) - xhat*mean(g*xhat))
 // Waves stride over rows and keep their column partial sums in registers; one atomicAdd per
-// column per wave at the end.
+// column per WORKGROUP at the end.
 // ---------------------------------------------------------------------------------------------
 template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
@@ -85,20 +85,24 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
             if (c < d) st4(dx + (int64_t)row * d + c, (g[i] - m1 - v[i] * m2) * rstd);
         }
     }
+    // Column sums: the four waves of the workgroup meet in LDS first, so each column receives ONE atomic
+    // per workgroup and quantity.  (Per-wave atomics — 2M adds onto the same 1024 addresses at 16k rows —
+    // ran at the contended-atomic rate of the chip and took 250 us per launch, 8x the row work.)
+    __shared__ __attribute__((aligned(16))) float colbuf[4][NV * 256];
+    const int w = threadIdx.x >> 6;
+    auto reduce_to = [&](f32x4 (&part)[NV], float* __restrict__ dst) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        if (c < d) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                atomicAdd(dgamma + c + j, ag[i][j]);
-                atomicAdd(dbeta + c + j, ab[i][j]);
-                if (s) {
-                    atomicAdd(ds + c + j, as[i][j]);
-                    atomicAdd(dt + c + j, at[i][j]);
-                }
-            }
-        }
+        for (int i = 0; i < NV; ++i) st4(&colbuf[w][(lane + 64 * i) * 4], part[i]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < d; c += 256)
+            atomicAdd(dst + c, (colbuf[0][c] + colbuf[1][c]) + (colbuf[2][c] + colbuf[3][c]));
+        __syncthreads();
+    };
+    reduce_to(ag, dgamma);
+    reduce_to(ab, dbeta);
+    if (s) {
+        reduce_to(as, ds);
+        reduce_to(at, dt);
     }
 }
 
@@ -115,7 +119,7 @@ extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float*
                    vh_aligned16(beta) && vh_aligned16(ada_scale),
                VH_EALIGN, "vh_layernorm_bwd: pointers must be 16-byte aligned");
     if (rows == 0) return VH_OK;
-    const int blocks = rows < 4 * 512 ? (rows + 3) / 4 : 512;
+    const int blocks = rows < 4 * 256 ? (rows + 3) / 4 : 256;
     hipStream_t st = (hipStream_t)stream;
 #define LNB(NV)                                                                                    \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, gamma, beta,   \
