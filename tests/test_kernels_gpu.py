@@ -196,6 +196,41 @@ def test_linear_qkv_folded_scatter(K):
     assert int((kc != 0).any(-1).sum()) == B * h       # exactly one row per (b, head) written
 
 
+@pytest.mark.parametrize('M', [17, 32, 48, 64])
+def test_decode_gemm_row_groups_are_bit_identical(K, M):
+    """16 < M <= 64: one workgroup per (16 rows, 16 columns) (default) against one per 16 columns."""
+    from valle2_amd import _lib
+    lib = _lib.lib()
+    d, dff, h = 256, 512, 4
+    gen = torch.Generator().manual_seed(M)
+    x = (torch.randn(M, d, generator=gen) + 0.3).to(DEV)
+    wq, w1, wo = (0.05 * torch.randn(n, d, generator=gen) for n in (3 * d, dff, d))
+    gm, bt = 1 + 0.1 * torch.randn(d, generator=gen), 0.1 * torch.randn(d, generator=gen)
+    b1, bo = torch.randn(dff, generator=gen), torch.randn(d, generator=gen)
+    wh = (0.05 * torch.randn(1025, d, generator=gen)).to(DEV)
+    res0 = torch.randn(M, d, generator=gen)
+    fq = K.ln_fold(wq.to(DEV), gm.to(DEV), bt.to(DEV))
+    f1 = K.ln_fold(w1.to(DEV), gm.to(DEV), bt.to(DEV), b1.to(DEV))
+    cl = torch.randint(0, 20, (M,), generator=gen, dtype=torch.int32).to(DEV)
+    outs = []
+    try:
+        for knob in (1, 2):
+            lib.vh_set_tuning(2, knob)
+            kc = torch.zeros(M, h, 24, 64, device=DEV)
+            vc = torch.zeros_like(kc)
+            q = torch.zeros(M, d, device=DEV)
+            K.linear_qkv_folded(x, fq, q, kc, vc, M, 1, h, cache_len=cl)
+            res = res0.to(DEV)
+            outs.append((q, kc, vc, K.linear_folded(x, f1, act=1), K.linear(x, wo.to(DEV), bo.to(DEV), res, out=res),
+                         K.linear(x, wh), K.linear(x, wq.to(DEV), ln=(gm.to(DEV), bt.to(DEV), None, None, 1e-5))))
+    finally:
+        lib.vh_set_tuning(2, 0)
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    ref = F.linear(F.layer_norm(x.cpu(), (d,), gm, bt, 1e-5), w1, b1)
+    close(outs[0][3], F.gelu(ref), atol=5e-5)
+
+
 # ---- residual stream in fp64 accumulator form (vh_linear_acc64 and its consumers) --------------------
 @pytest.mark.parametrize('M,N,K_', [(32, 512, 2048), (5, 64, 512), (64, 128, 128), (17, 512, 4096), (32, 96, 1280)])
 def test_linear_acc64_exact_atomics(K, M, N, K_):

@@ -462,6 +462,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
     using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
+    // Row groups (gridDim.z > 1): this workgroup owns rows [16·MT·z, 16·MT·(z+1)) of the problem — it
+    // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
+    // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
+    if (gridDim.z > 1) {
+        const int r0 = blockIdx.z * (16 * MT);
+        a.A = reinterpret_cast<const float*>(reinterpret_cast<const AT*>(a.A) + (int64_t)r0 * a.lda);
+        if (a.res) {
+            if (X64 & 2) a.res = reinterpret_cast<const float*>(reinterpret_cast<const double*>(a.res) + (int64_t)r0 * a.ldr);
+            else a.res += (int64_t)r0 * a.ldr;
+        }
+        a.out += (int64_t)r0 * a.ldo;
+        if (EPI == EPI_QKV) {                 // T == 1 (host check): row = batch index
+            a.kc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
+            a.vc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
+            if (a.cache_len) a.cache_len += r0;
+        }
+        a.M = min(a.M - r0, 16 * MT);
+    }
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -737,13 +755,17 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool wide = a.K > 1024;
         const bool has_ln = ln.gamma != nullptr || ln.c1 != nullptr;
         const bool fold = ln.c1 != nullptr;
+        // one workgroup per (16 columns, 16 rows) instead of (16 columns, all rows): see the kernel
+        const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && !wide && EPI != EPI_PARTIAL &&
+                               EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
         // ---- compact fast path: K = 16*NW*PW*passes
 #define SFX(MT, NW, PW, LN, NJ, X) \
     hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, a, ln)
 #define SF(MT, NW, PW, LN, NJ) SFX(MT, NW, PW, LN, NJ, 0)
 #define SFX_MT(NW, PW, LN, NJ, X)                                              \
     do {                                                                       \
-        if (mt == 1) SFX(1, NW, PW, LN, NJ, X);                                \
+        if (rowgroups) { grid.z = mt; SFX(1, NW, PW, LN, NJ, X); }             \
+        else if (mt == 1) SFX(1, NW, PW, LN, NJ, X);                           \
         else if (mt == 2) SFX(2, NW, PW, LN, NJ, X);                           \
         else SFX(4, NW, PW, LN, NJ, X);                                        \
         VH_CHECK_LAUNCH(name);                                                 \
