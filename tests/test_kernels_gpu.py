@@ -214,7 +214,7 @@ def test_decode_gemm_row_groups_are_bit_identical(K, M):
     cl = torch.randint(0, 20, (M,), generator=gen, dtype=torch.int32).to(DEV)
     outs = []
     try:
-        for knob in (1, 2):
+        for knob in (1, 2, 3):
             lib.vh_set_tuning(2, knob)
             kc = torch.zeros(M, h, 24, 64, device=DEV)
             vc = torch.zeros_like(kc)
@@ -225,8 +225,8 @@ def test_decode_gemm_row_groups_are_bit_identical(K, M):
                          K.linear(x, wh), K.linear(x, wq.to(DEV), ln=(gm.to(DEV), bt.to(DEV), None, None, 1e-5))))
     finally:
         lib.vh_set_tuning(2, 0)
-    for u, v in zip(*outs):
-        assert torch.equal(u, v)
+    for u, v, t in zip(*outs):
+        assert torch.equal(u, v) and torch.equal(u, t)
     ref = F.linear(F.layer_norm(x.cpu(), (d,), gm, bt, 1e-5), w1, b1)
     close(outs[0][3], F.gelu(ref), atol=5e-5)
 

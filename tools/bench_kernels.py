@@ -110,6 +110,8 @@ def bench_gemm():
         'ffn1 fold, no row groups': tuned(2, 2, lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1)),
         'out-proj, no row groups': tuned(2, 2, lambda: K.linear(x, wo[nxt()], bo, o1, out=o1)),
         'head f32 rows, no row groups': tuned(2, 2, lambda: K.linear(x, wh, out=logits[:, :1025])),
+        'out-proj, 16-row groups': tuned(2, 3, lambda: K.linear(x, wo[nxt()], bo, o1, out=o1)),
+        'head f32 rows, 16-row groups': tuned(2, 3, lambda: K.linear(x, wh, out=logits[:, :1025])),
         'qkv fold f64 rows': lambda: K.linear_qkv_folded(x64, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
         'ffn1 fold': lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1),
         'out-proj, residual64 consumed': lambda: K.linear_x64(x, wo[nxt()], bo, residual64=acc, out=o1),

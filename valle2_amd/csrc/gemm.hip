@@ -35,6 +35,7 @@ struct GemmArgs {
     const int32_t* cache_len;
     int T, S_max, d_model, n_heads;
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
+    int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
 #ifdef VH_STAMPS
     long long* dbg;  // diagnostic build only (tools/probe_skinny.hip): per-wave phase stamps
 #endif
@@ -462,11 +463,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
     using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
-    // Row groups (gridDim.z > 1): this workgroup owns rows [16·MT·z, 16·MT·(z+1)) of the problem — it
+    // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
     if (gridDim.z > 1) {
-        const int r0 = blockIdx.z * (16 * MT);
+        const int r0 = blockIdx.z * a.rg_rows;
         a.A = reinterpret_cast<const float*>(reinterpret_cast<const AT*>(a.A) + (int64_t)r0 * a.lda);
         if (a.res) {
             if (X64 & 2) a.res = reinterpret_cast<const float*>(reinterpret_cast<const double*>(a.res) + (int64_t)r0 * a.ldr);
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
             a.vc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
             if (a.cache_len) a.cache_len += r0;
         }
-        a.M = min(a.M - r0, 16 * MT);
+        a.M = min(a.M - r0, a.rg_rows);
     }
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
@@ -758,13 +759,18 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         // one workgroup per (16 columns, 16 rows) instead of (16 columns, all rows): see the kernel
         const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && !wide && EPI != EPI_PARTIAL &&
                                EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
+        GemmArgs ag = a;                  // groups of 16 rows, or of 8 while that keeps the grid within the CUs
+        if (rowgroups) {
+            ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) <= 256) ? 8 : 16;
+            grid.z = (a.M + ag.rg_rows - 1) / ag.rg_rows;
+        }
         // ---- compact fast path: K = 16*NW*PW*passes
 #define SFX(MT, NW, PW, LN, NJ, X) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, a, ln)
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, ag, ln)
 #define SF(MT, NW, PW, LN, NJ) SFX(MT, NW, PW, LN, NJ, 0)
 #define SFX_MT(NW, PW, LN, NJ, X)                                              \
     do {                                                                       \
-        if (rowgroups) { grid.z = mt; SFX(1, NW, PW, LN, NJ, X); }             \
+        if (rowgroups) SFX(1, NW, PW, LN, NJ, X);                              \
         else if (mt == 1) SFX(1, NW, PW, LN, NJ, X);                           \
         else if (mt == 2) SFX(2, NW, PW, LN, NJ, X);                           \
         else SFX(4, NW, PW, LN, NJ, X);                                        \
