@@ -156,24 +156,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     // staging: thread loads 4 float4 of A and 4 of W per K step: rows (tid>>3)+32i, k-quad tid&7
     const int srow = tid >> 3, skq = (tid & 7) * 4;
     f32x4 ra[4], rw[4];
+    // row pointers and bounds of this thread's 4 + 4 staging rows, computed once
+    const float* pa[4];
+    const float* pw[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = srow + 32 * i;
+        pa[i] = a.A + (int64_t)min(m0 + row, a.M - 1) * a.lda + skq;
+        pw[i] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.K + skq;
+    }
+    // Loads are unconditional (no branches, no use of the loaded value inside the main loop): rows
+    // beyond M / N are clamped to the last valid row — their products only reach output rows / columns
+    // that are never stored — and a K tail (K % 32 = 16) is clamped here and zeroed when the slab is
+    // written to LDS.
+    auto gload1 = [&](int i, int k0) {           // one A row + one W row of the K slab at k0
+        const int kk = k0 + skq < a.K ? k0 : 0;  // K % 4 == 0 is guaranteed by the host check
+        ra[i] = ld4(pa[i] + kk);
+        rw[i] = ld4(pw[i] + kk);
+    };
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = srow + 32 * i;
-            const int k = k0 + skq;
-            const bool kin = k < a.K;  // K % 4 == 0 is guaranteed by the host check
-            ra[i] = (m0 + row < a.M && kin) ? ld4(a.A + (int64_t)(m0 + row) * a.lda + k)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-            rw[i] = (n0 + row < a.N && kin) ? ld4(a.W + (int64_t)(n0 + row) * a.K + k)
-                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int i = 0; i < 4; ++i) gload1(i, k0);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf, int k0) {
+        const bool kin = k0 + skq < a.K;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 32 * i;
-            st4(&lds[buf][0][row * LDS_LD + skq], ra[i]);
-            st4(&lds[buf][1][row * LDS_LD + skq], rw[i]);
+            st4(&lds[buf][0][row * LDS_LD + skq], kin ? ra[i] : f32x4{0.f, 0.f, 0.f, 0.f});
+            st4(&lds[buf][1][row * LDS_LD + skq], kin ? rw[i] : f32x4{0.f, 0.f, 0.f, 0.f});
         }
     };
 
@@ -187,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 
     const int nk = (a.K + TK - 1) / TK;
     gload(0);
-    lstore(0);
+    lstore(0, 0);
 
     // Epilogue layout: the accumulators are transposed through LDS so that a lane owns 4 consecutive
     // columns of one row: thread tid handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.
@@ -226,11 +237,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
         fw[set][1] = ld4(Ws + 32 * LDS_LD);
     };
     fload(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // one K step; PF = there is a next slab to fetch (every step but the last): no branch inside the step
+    auto kstep = [&](int kt, auto pf) {
+        constexpr bool PF = decltype(pf)::value;
         const int cur = kt & 1;
-        if (kt + 1 < nk) gload((kt + 1) * TK);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
+            // the next K slab is fetched a quarter per sub-step: two loads and their address math fit in
+            // the shadow of the MFMAs already issued, a burst of eight at the top of the step does not
+            if constexpr (PF) gload1(t, (kt + 1) * TK);
             if (t < 3) fload((t + 1) & 1, cur, t + 1);
             __builtin_amdgcn_sched_barrier(0);       // reads first: they fly under the 16 MFMAs below
 #pragma unroll
@@ -242,10 +257,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) lstore(cur ^ 1);
+        if constexpr (PF) lstore(cur ^ 1, (kt + 1) * TK);
         __syncthreads();
-        if (kt + 1 < nk) fload(0, cur ^ 1, 0);
-    }
+        if constexpr (PF) fload(0, cur ^ 1, 0);
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
 
     // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
     // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
