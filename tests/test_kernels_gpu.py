@@ -196,6 +196,32 @@ def test_linear_qkv_folded_scatter(K):
     assert int((kc != 0).any(-1).sum()) == B * h       # exactly one row per (b, head) written
 
 
+def test_linear_random_shape_sweep(K):
+    """Every dispatch path of vh_linear (compact / guarded skinny kernels, row groups, tile kernel and
+    its ragged edges) on 60 seeded random shapes with the full epilogue, against torch fp32 on the CPU."""
+    gen = torch.Generator().manual_seed(2024)
+    ks = [16, 32, 48, 64, 128, 144, 256, 384, 512, 1024, 1040, 2048]
+    for case in range(60):
+        M = int(torch.randint(1, 330, (1,), generator=gen))
+        N = int(torch.randint(1, 1100, (1,), generator=gen))
+        K_ = ks[int(torch.randint(0, len(ks), (1,), generator=gen))]
+        act = int(torch.randint(0, 2, (1,), generator=gen))
+        a = torch.randn(M, K_, generator=gen)
+        w = torch.randn(N, K_, generator=gen) / K_ ** 0.5
+        bias = torch.randn(N, generator=gen) if case % 3 else None
+        res = torch.randn(M, N, generator=gen) if case % 2 else None
+        ref = F.linear(a, w, bias)
+        ref = F.gelu(ref) if act else ref
+        if res is not None:
+            ref = ref + res
+        resd = None
+        if res is not None:
+            resd = torch.zeros(M, (N + 3) // 4 * 4, device=DEV)[:, :N]
+            resd.copy_(res)
+        out = K.linear(a.to(DEV), w.to(DEV), None if bias is None else bias.to(DEV), resd, act=act)
+        torch.testing.assert_close(out.cpu(), ref, atol=5e-5, rtol=5e-5, msg=lambda m: f'M={M} N={N} K={K_} act={act}: {m}')
+
+
 @pytest.mark.parametrize('M', [17, 32, 48, 64])
 def test_decode_gemm_row_groups_are_bit_identical(K, M):
     """16 < M <= 64: one workgroup per (16 rows, 16 columns) (default) against one per 16 columns."""
