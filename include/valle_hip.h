@@ -168,6 +168,26 @@ int vh_attn_rows(const float* q, int ldq, const float* kcache, const float* vcac
                  const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
                  const uint8_t* pad, void* stream);
 
+/* vh_attn_rows that also writes lse2 (B, n_heads, Tq): log2 of the softmax denominator of every query row
+ * in the scaled-score units the backward kernels use (lse2 = max + log2(sum 2^(s - max)), s = q.k/8*log2 e). */
+int vh_attn_rows_lse(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
+                     int ldo, int B, int n_heads, int Tq, int Tk, int S_max, int mode, int x_len,
+                     const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+                     const uint8_t* pad, float* lse2, void* stream);
+
+/* ---- backward of vh_attn_rows (training, Tq == Tk == T): dQ, dK, dV without materialising P -----
+ * replaces the autograd backward of F.scaled_dot_product_attention (valle/models/modules.py:167) in
+ * loss.backward() of training_step.  q (B*T, ldq) / kcache, vcache (B,h,S_max,64) / out (B*T, ldo) /
+ * lse2 as produced by vh_attn_rows_lse, dout (B*T, lddo) the gradient of out; same mask arguments.
+ * dq, dk, dv: (B*T, ldg) each with head h at columns h*64 (three column blocks of one (B*T, 3d) buffer
+ * work: ldg = 3d).  dsum (B, n_heads, T) is scratch (D = rowsum(dout * out)).  Two launches, no atomics:
+ * results are bitwise reproducible. */
+int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* vcache, const float* out,
+                     int ldo, const float* dout, int lddo, const float* lse2, float* dsum, float* dq,
+                     float* dk, float* dv, int ldg, int B, int n_heads, int T, int S_max, int mode,
+                     int x_len, const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+                     const uint8_t* pad, void* stream);
+
 /* ---- K8b: single-row decode attention over the KV cache (HBM-bound) -------------------------
  * replaces SDPA with q-len 1 (valle/models/modules.py:167 reached via :336-338).
  * q (B, ldq); keys 0 .. cache_len[b] + len_bias - 1 of row b are attended (len_bias = 1 when the

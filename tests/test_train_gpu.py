@@ -245,3 +245,66 @@ def test_flat_adamw_drives_the_model_and_invalidates_folded_weights():
     torch.testing.assert_close(after[0][0][0], w * g, rtol=0, atol=0)
     loss1 = model.training_step({k: v.clone() for k, v in batch.items()})
     assert float(loss1.detach()) < float(loss0.detach())
+
+
+# ---- attention backward kernels (vh_attn_rows_bwd) directly against torch autograd -----------------------
+@pytest.mark.parametrize('B,h,T,mode', [(2, 2, 70, 'prefix'), (3, 2, 300, 'prefix'), (2, 4, 257, 'full'),
+                                         (1, 2, 129, 'explicit'), (2, 1, 33, 'full')])
+def test_attn_rows_bwd_vs_torch_autograd(B, h, T, mode):
+    from oracle.valle_oracle import build_attn_mask
+    from valle2_amd import kernels as K
+    d = 64 * h
+    gen = torch.Generator().manual_seed(T)
+    q = torch.randn(B, h, T, 64, generator=gen).requires_grad_()
+    k = torch.randn(B, h, T, 64, generator=gen).requires_grad_()
+    v = torch.randn(B, h, T, 64, generator=gen).requires_grad_()
+    dout = torch.randn(B, T, d, generator=gen)
+    kvl = torch.randint(max(T // 2, 1), T + 1, (B,), generator=gen, dtype=torch.int32)
+    kvl[0] = T
+    xl = T // 4
+    keypad = torch.arange(T)[None, :] >= kvl[:, None]
+    if mode == 'prefix':
+        masked = build_attn_mask(xl, T - xl)[None] | keypad[:, None, :]
+        spec = dict(mode=K.MASK_PREFIX, x_len=xl, kv_len=kvl.to(DEV))
+    elif mode == 'full':
+        masked = keypad[:, None, :].expand(B, T, T)
+        spec = dict(mode=K.MASK_FULL, kv_len=kvl.to(DEV))
+    else:
+        m2 = torch.rand(T, T, generator=gen) < 0.3
+        m2[torch.arange(T), torch.arange(T)] = False            # every row keeps at least its own key
+        masked = m2[None] | keypad[:, None, :]
+        masked[:, torch.arange(T), torch.arange(T)] = False
+        pad = keypad.clone()
+        spec = dict(mode=K.MASK_EXPLICIT, mask=m2.to(torch.uint8).to(DEV), pad=None)
+        masked = m2[None].expand(B, T, T)
+    ref = F.scaled_dot_product_attention(q, k, v, attn_mask=~masked[:, None])
+    ref.permute(0, 2, 1, 3).reshape(B, T, d).backward(dout)
+    # device: q as (B*T, d) rows with heads in columns; k, v in the cache layout
+    qd = q.detach().permute(0, 2, 1, 3).reshape(B * T, d).contiguous().to(DEV)
+    kd, vd = k.detach().contiguous().to(DEV), v.detach().contiguous().to(DEV)
+    out = torch.empty(B * T, d, device=DEV)
+    lse2 = torch.empty(B, h, T, device=DEV)
+    K.attn_rows(qd, kd, vd, out, B, h, T, T, lse2=lse2, **spec)
+    close(out, ref.detach().permute(0, 2, 1, 3).reshape(B * T, d), atol=3e-5)
+    dqkv = torch.full((B * T, 3 * d), float('nan'), device=DEV)
+    K.attn_rows_bwd(qd, kd, vd, out, dout.reshape(B * T, d).to(DEV), lse2, dqkv[:, :d], dqkv[:, d:2 * d],
+                    dqkv[:, 2 * d:], B, h, T, **spec)
+    got = dqkv.cpu().view(B, T, 3, h, 64).permute(2, 0, 3, 1, 4)
+    for name, gg, rr in zip('qkv', got, (q.grad, k.grad, v.grad)):
+        torch.testing.assert_close(gg, rr, atol=6e-5, rtol=1e-4, msg=lambda m: f'd{name}: {m}')
+    # bitwise reproducible (no atomics)
+    dqkv2 = torch.empty_like(dqkv)
+    K.attn_rows_bwd(qd, kd, vd, out, dout.reshape(B * T, d).to(DEV), lse2, dqkv2[:, :d], dqkv2[:, d:2 * d],
+                    dqkv2[:, 2 * d:], B, h, T, **spec)
+    assert torch.equal(dqkv, dqkv2)
+
+
+@pytest.mark.parametrize('mode', ['prefix', 'full'])
+def test_attention_backward_materialized_engine(mode):
+    from valle2_amd import autograd as A
+    old = A.ATTENTION_BACKWARD
+    A.ATTENTION_BACKWARD = 'materialized'
+    try:
+        test_qkv_attention_backward(mode)
+    finally:
+        A.ATTENTION_BACKWARD = old

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _hip_backward_gemm():
     from valle2_amd import autograd as A
-    old = A.BACKWARD_GEMM
-    A.BACKWARD_GEMM = 'hip'
+    old = A.BACKWARD_GEMM, A.ATTENTION_BACKWARD
+    A.BACKWARD_GEMM, A.ATTENTION_BACKWARD = 'hip', 'materialized'   # the path that runs on vh_gemm_batched
     yield
-    A.BACKWARD_GEMM = old
+    A.BACKWARD_GEMM, A.ATTENTION_BACKWARD = old
 
 
 def test_ar_gradients_hip_gemm():

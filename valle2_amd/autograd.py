@@ -23,6 +23,12 @@ HEAD_DIM = kernels.HEAD_DIM
 # Both pass the same gradient-parity tests; tools/bench_gemm_bwd.py holds the A/B.
 BACKWARD_GEMM = 'library'
 
+# Backward of the attention core:
+#   'flash'        — vh_attn_rows_bwd: two hand-written kernels that recompute P tile by tile from the saved
+#                    row log-sum-exp (no (T,T) maps in memory, no atomics);
+#   'materialized' — S, P, dP as (B,h,T,T) tensors through plain GEMMs + row softmax kernels.
+ATTENTION_BACKWARD = 'flash'
+
 
 def _mm(a, b, out, a_kmajor=False, b_kmajor=False):
     """out = op(a) @ op(b) with the operand-storage convention of kernels.gemm."""
@@ -149,17 +155,28 @@ class QkvAttentionFn(torch.autograd.Function):
         v = torch.empty_like(k)
         kernels.linear_qkv(x, wqkv.detach(), q, k, v, B, T, n_heads)
         out = torch.empty(B * T, d, device=dev, dtype=torch.float32)
-        kernels.attn_rows(q, k, v, out, B, n_heads, T, T, **spec)
-        ctx.save_for_backward(x, wqkv, q, k, v)
+        lse2 = torch.empty(B, n_heads, T, device=dev, dtype=torch.float32)
+        kernels.attn_rows(q, k, v, out, B, n_heads, T, T, lse2=lse2, **spec)
+        ctx.save_for_backward(x, wqkv, q, k, v, out, lse2)
         ctx.dims, ctx.spec = (B, T, n_heads), spec
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, wqkv, q, k, v = ctx.saved_tensors
+        x, wqkv, q, k, v, out, lse2 = ctx.saved_tensors
         B, T, h = ctx.dims
         d = h * HEAD_DIM
         spec = ctx.spec
+        if ATTENTION_BACKWARD == 'flash':
+            dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
+            kernels.attn_rows_bwd(q, k, v, out, dout.contiguous(), lse2, dqkv[:, :d], dqkv[:, d:2 * d],
+                                  dqkv[:, 2 * d:], B, h, T, **spec)
+            dx = dw = None
+            if ctx.needs_input_grad[0]:
+                dx = _mm(dqkv, wqkv, torch.empty_like(x), b_kmajor=True)
+            if ctx.needs_input_grad[1]:
+                dw = _mm(dqkv, x, torch.empty_like(wqkv), a_kmajor=True, b_kmajor=True)
+            return dx, dw, None, None, None, None
         scale = HEAD_DIM ** -0.5
         L = _lib.lib()
         tp = (T + 3) // 4 * 4                                              # row stride of the (T,T) maps

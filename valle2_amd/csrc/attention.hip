@@ -298,6 +298,7 @@ struct RowsArgs {
     const int32_t* x_len_dev; const int32_t* kv_len;
     const uint8_t* mask; const uint8_t* pad;
     int n_qblocks;
+    float* lse2;   // optional (B, h, Tq): log2-sum-exp of the scaled scores, for the backward kernels
 };
 
 __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
     // ---- normalise, transpose through LDS, store coalesced rows
     const float ltot = l + __shfl_xor(l, 32, 64);
     const float inv = 1.0f / ltot;  // fully masked row → 0/0 = NaN, as SDPA gives
+    if (a.lse2 && h == 0 && qi < a.Tq) a.lse2[(int64_t)bh * a.Tq + qi] = m + log2f(ltot);
     float* ob = lds;                // [128][KLD]; all K/V reads finished at the last barrier
 #pragma unroll
     for (int g4 = 0; g4 < 4; ++g4) {
@@ -464,10 +466,10 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
     }
 }
 
-extern "C" int vh_attn_rows(const float* q, int ldq, const float* kcache, const float* vcache,
+static int attn_rows_launch(const float* q, int ldq, const float* kcache, const float* vcache,
                             float* out, int ldo, int B, int n_heads, int Tq, int Tk, int S_max,
                             int mode, int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
-                            const uint8_t* mask, const uint8_t* pad, void* stream) {
+                            const uint8_t* mask, const uint8_t* pad, float* lse2, void* stream) {
     VH_REQUIRE(q && kcache && vcache && out, VH_EINVAL, "vh_attn_rows: null pointer");
     VH_REQUIRE(B >= 0 && n_heads > 0 && Tq >= 0 && Tk >= Tq && S_max >= Tk, VH_EINVAL,
                "vh_attn_rows: bad dims B=%d h=%d Tq=%d Tk=%d S_max=%d", B, n_heads, Tq, Tk, S_max);
@@ -481,9 +483,346 @@ extern "C" int vh_attn_rows(const float* q, int ldq, const float* kcache, const 
     if (B == 0 || Tq == 0) return VH_OK;
     const int nqb = (Tq + QB - 1) / QB;
     RowsArgs a{q, ldq, kcache, vcache, out, ldo, n_heads, Tq, Tk, S_max, mode, x_len,
-               x_len_dev, kv_len, mask, pad, nqb};
+               x_len_dev, kv_len, mask, pad, nqb, lse2};
     dim3 grid(nqb * B * n_heads);
     hipLaunchKernelGGL(attn_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     VH_CHECK_LAUNCH("vh_attn_rows");
+    return VH_OK;
+}
+
+extern "C" int vh_attn_rows(const float* q, int ldq, const float* kcache, const float* vcache,
+                            float* out, int ldo, int B, int n_heads, int Tq, int Tk, int S_max,
+                            int mode, int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
+                            const uint8_t* mask, const uint8_t* pad, void* stream) {
+    return attn_rows_launch(q, ldq, kcache, vcache, out, ldo, B, n_heads, Tq, Tk, S_max, mode, x_len,
+                            x_len_dev, kv_len, mask, pad, nullptr, stream);
+}
+
+extern "C" int vh_attn_rows_lse(const float* q, int ldq, const float* kcache, const float* vcache,
+                                float* out, int ldo, int B, int n_heads, int Tq, int Tk, int S_max,
+                                int mode, int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
+                                const uint8_t* mask, const uint8_t* pad, float* lse2, void* stream) {
+    VH_REQUIRE(lse2, VH_EINVAL, "vh_attn_rows_lse: null lse2");
+    return attn_rows_launch(q, ldq, kcache, vcache, out, ldo, B, n_heads, Tq, Tk, S_max, mode, x_len,
+                            x_len_dev, kv_len, mask, pad, lse2, stream);
+}
+
+// =============================================================================================
+// many-row attention, backward (training: Tq == Tk).  Two launches, no atomics, P never materialised:
+//   dq kernel : one workgroup per 128 queries of a (b,head), queries are lanes (the forward's layout);
+//               per 32-key tile   Sᵀ = K·Qᵀ,  P = exp2(Sᵀ − lse),  dPᵀ = V·dOᵀ,  dSᵀ = P∘(dPᵀ − D),
+//               dQᵀ += Kᵀ·dSᵀ   (D[q] = Σ_d dO[q][d]·O[q][d], lane-local, also written out for the next kernel)
+//   dkv kernel: one workgroup per 128 keys, keys are lanes; per 32-query tile
+//               S = Q·Kᵀ, P, dP = dO·Vᵀ, dS as above (lse, D per register now),  dVᵀ += dOᵀ·P,  dKᵀ += Qᵀ·dS
+// In both, the accumulator of the first product IS the B operand of the last (no shuffle, no LDS trip).
+// =============================================================================================
+struct BwdArgs {
+    const float* q; int ldq;          // (B*T, ldq), head h at columns h*64
+    const float* kc; const float* vc; // (B, h, S_max, 64)
+    const float* o; int ldo;          // forward output (B*T, ldo)
+    const float* dout; int lddo;      // its gradient
+    const float* lse2;                // (B, h, T) from vh_attn_rows_lse
+    float* dsum;                      // (B, h, T): D, written by the dq kernel, read by the dkv kernel
+    float* dq; float* dk; float* dv; int ldg;   // gradients, each (B*T, ldg) with head h at columns h*64
+    int n_heads, T, S_max, mode, x_len;
+    const int32_t* x_len_dev; const int32_t* kv_len;
+    const uint8_t* mask; const uint8_t* pad;
+    int n_blocks;
+};
+
+__device__ __forceinline__ bool bwd_visible(const BwdArgs& a, int b, int qi, int key, int kvl, int xl) {
+    if (a.mode == VH_MASK_EXPLICIT)
+        return key < a.T && qi < a.T && !a.mask[(int64_t)qi * a.T + key] && !(a.pad && a.pad[(int64_t)b * a.T + key]);
+    bool vis = key < kvl;
+    if (a.mode == VH_MASK_PREFIX) vis = vis && (key < xl || (qi >= xl && key <= qi));
+    return vis;
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KLD];   // [buf][K|V][key][KLD]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_bh = gridDim.x / a.n_blocks;
+    const int bh = blockIdx.x % n_bh, b = bh / a.n_heads, head = bh - b * a.n_heads;
+    const int q0 = (a.n_blocks - 1 - (int)(blockIdx.x / n_bh)) * QB;      // heaviest query blocks first
+    const int kvl = a.kv_len ? min(a.kv_len[b], a.T) : a.T;
+    const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
+    const int last_pos = min(q0 + QB, a.T) - 1;
+    int kmax = kvl;
+    if (a.mode == VH_MASK_PREFIX) kmax = min(kvl, max(xl, last_pos >= xl ? last_pos + 1 : 0));
+    if (a.mode == VH_MASK_EXPLICIT) kmax = a.T;
+    const int n_tiles = (kmax + KT - 1) / KT;
+
+    const int qi = q0 + w * 32 + r;
+    const bool qin = qi < a.T;
+    const float qscale = 0.125f * LOG2E;
+    f32x4 qf[8], df[8];
+    float dsum = 0.f;
+    {
+        const int64_t row = (int64_t)b * a.T + min(qi, a.T - 1);
+        const float* qp = a.q + row * a.ldq + head * HD + 4 * h;
+        const float* dp = a.dout + row * a.lddo + head * HD + 4 * h;
+        const float* op = a.o + row * a.ldo + head * HD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            qf[t] = ld4(qp + 8 * t) * qscale;
+            df[t] = ld4(dp + 8 * t);
+            const f32x4 ov = ld4(op + 8 * t);
+            dsum += (df[t].x * ov.x + df[t].y * ov.y) + (df[t].z * ov.z + df[t].w * ov.w);
+        }
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float lse = a.lse2[(int64_t)bh * a.T + min(qi, a.T - 1)];
+    if (h == 0 && qin) a.dsum[(int64_t)bh * a.T + qi] = dsum;
+
+    const float* kb = a.kc + (int64_t)bh * a.S_max * HD;
+    const float* vb = a.vc + (int64_t)bh * a.S_max * HD;
+    const int skey = tid >> 4, squad = (tid & 15) * 4;
+    f32x4 rk[2], rv[2];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int key = min(k0 + skey + 16 * i, a.T - 1);   // clamped: masked anyway
+            rk[i] = ld4(kb + (int64_t)key * HD + squad);
+            rv[i] = ld4(vb + (int64_t)key * HD + squad);
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* kd = lds + buf * (2 * KT * KLD);
+        float* vd = kd + KT * KLD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st4(kd + (skey + 16 * i) * KLD + squad, rk[i]);
+            st4(vd + (skey + 16 * i) * KLD + squad, rv[i]);
+        }
+    };
+    f32x16 G0, G1;                      // dQᵀ halves: d = r and r + 32
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { G0[e] = 0.f; G1[e] = 0.f; }
+    const int wpos_min = q0 + w * 32, wpos_max = wpos_min + 31;
+    if (n_tiles > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int cur = kt & 1, k0 = kt * KT;
+        if (kt + 1 < n_tiles) gload(k0 + KT);
+        bool any = k0 < kvl;
+        if (a.mode == VH_MASK_PREFIX) any = any && (k0 < xl || (wpos_max >= xl && k0 <= wpos_max));
+        else if (a.mode == VH_MASK_EXPLICIT) any = true;
+        if (any) {
+            const float* ks = lds + cur * (2 * KT * KLD);
+            const float* vs = ks + KT * KLD;
+            f32x16 S, P;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { S[e] = 0.f; P[e] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 kf = ld4(ks + r * KLD + 8 * t + 4 * h);
+                const f32x4 vf = ld4(vs + r * KLD + 8 * t + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], S, 0, 0, 0);   // Sᵀ[key][q]
+                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], df[t][j], P, 0, 0, 0);   // dPᵀ[key][q]
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const bool vis = qin && bwd_visible(a, b, qi, key, kvl, xl);
+                const float p = vis ? exp2f(S[e] - lse) : 0.f;
+                S[e] = p * (P[e] - dsum);                                                   // dSᵀ[key][q]
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float* krow = ks + ((e & 3) + 8 * (e >> 2) + 4 * h) * KLD + r;
+                G0 = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[0], S[e], G0, 0, 0, 0);
+                G1 = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[32], S[e], G1, 0, 0, 0);
+            }
+        }
+        if (kt + 1 < n_tiles) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    float* ob = lds;                // [128][KLD] transpose buffer
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        f32x4 v0 = {G0[4 * g4], G0[4 * g4 + 1], G0[4 * g4 + 2], G0[4 * g4 + 3]};
+        f32x4 v1 = {G1[4 * g4], G1[4 * g4 + 1], G1[4 * g4 + 2], G1[4 * g4 + 3]};
+        st4(ob + (w * 32 + r) * KLD + 8 * g4 + 4 * h, v0 * 0.125f);
+        st4(ob + (w * 32 + r) * KLD + 32 + 8 * g4 + 4 * h, v1 * 0.125f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = skey + 16 * i;
+        if (q0 + row < a.T)
+            st4(a.dq + ((int64_t)b * a.T + q0 + row) * a.ldg + head * HD + squad, ld4(ob + row * KLD + squad));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
+    // [buf][Q|dO][query][KLD] + [buf][lse|D][32]
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KLD];
+    __shared__ __attribute__((aligned(16))) float stat[2][2][KT];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_bh = gridDim.x / a.n_blocks;
+    const int bh = blockIdx.x % n_bh, b = bh / a.n_heads, head = bh - b * a.n_heads;
+    const int kb0 = (int)(blockIdx.x / n_bh) * QB;                          // first key of this block
+    const int kvl = a.kv_len ? min(a.kv_len[b], a.T) : a.T;
+    const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
+    // queries that can see a key of this block: all of them for keys < xl (or FULL / EXPLICIT), else q >= key
+    int qmin = 0;
+    if (a.mode == VH_MASK_PREFIX && kb0 >= xl) qmin = kb0;
+    const int t_first = qmin / KT, n_tiles = (a.T + KT - 1) / KT;
+
+    const int kj = kb0 + w * 32 + r;            // this lane's key
+    const bool kin = kj < a.T;
+    const float qscale = 0.125f * LOG2E;
+    f32x4 kf[8], vf[8];
+    {
+        const float* kp = a.kc + ((int64_t)bh * a.S_max + min(kj, a.T - 1)) * HD + 4 * h;
+        const float* vp = a.vc + ((int64_t)bh * a.S_max + min(kj, a.T - 1)) * HD + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            kf[t] = ld4(kp + 8 * t) * qscale;
+            vf[t] = ld4(vp + 8 * t);
+        }
+    }
+    const int sq = tid >> 4, squad = (tid & 15) * 4;   // staging: 2 query rows per thread per operand
+    f32x4 rq[2], rd[2];
+    float rstat = 0.f;
+    auto gload = [&](int q0t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t row = (int64_t)b * a.T + min(q0t + sq + 16 * i, a.T - 1);
+            rq[i] = ld4(a.q + row * a.ldq + head * HD + squad);
+            rd[i] = ld4(a.dout + row * a.lddo + head * HD + squad);
+        }
+        if (tid < 2 * KT) {
+            const int qq = min(q0t + (tid & 31), a.T - 1);
+            rstat = (tid < KT ? a.lse2 : a.dsum)[(int64_t)bh * a.T + qq];
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* qd = lds + buf * (2 * KT * KLD);
+        float* dd = qd + KT * KLD;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st4(qd + (sq + 16 * i) * KLD + squad, rq[i]);
+            st4(dd + (sq + 16 * i) * KLD + squad, rd[i]);
+        }
+        if (tid < 2 * KT) stat[buf][tid >> 5][tid & 31] = rstat;
+    };
+    f32x16 GK0, GK1, GV0, GV1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { GK0[e] = 0.f; GK1[e] = 0.f; GV0[e] = 0.f; GV1[e] = 0.f; }
+    const int wk_min = kb0 + w * 32;
+    if (t_first < n_tiles) {
+        gload(t_first * KT);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int qt = t_first; qt < n_tiles; ++qt) {
+        const int cur = (qt - t_first) & 1, q0t = qt * KT;
+        if (qt + 1 < n_tiles) gload(q0t + KT);
+        bool any = wk_min < kvl;
+        if (a.mode == VH_MASK_PREFIX) any = any && (wk_min < xl || q0t + KT - 1 >= wk_min);
+        else if (a.mode == VH_MASK_EXPLICIT) any = true;
+        if (any) {
+            const float* qs = lds + cur * (2 * KT * KLD);
+            const float* ds = qs + KT * KLD;
+            f32x16 S, P;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { S[e] = 0.f; P[e] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 qv = ld4(qs + r * KLD + 8 * t + 4 * h);
+                const f32x4 dv = ld4(ds + r * KLD + 8 * t + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[j], kf[t][j], S, 0, 0, 0);   // S[q][key]
+                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[j], vf[t][j], P, 0, 0, 0);   // dP[q][key]
+                }
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const f32x4 lse4 = ld4(&stat[cur][0][8 * g4 + 4 * h]);
+                const f32x4 d4 = ld4(&stat[cur][1][8 * g4 + 4 * h]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = 4 * g4 + j;
+                    const int qi = q0t + 8 * g4 + 4 * h + j;
+                    const bool vis = kin && qi < a.T && bwd_visible(a, b, qi, kj, kvl, xl);
+                    const float p = vis ? exp2f(S[e] - lse4[j]) : 0.f;
+                    S[e] = p;                                   // P[q][key]
+                    P[e] = p * (P[e] - d4[j]);                  // dS[q][key]
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qrow = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float* dorow = ds + qrow * KLD + r;
+                const float* qrowp = qs + qrow * KLD + r;
+                GV0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[0], S[e], GV0, 0, 0, 0);    // dVᵀ[d][key]
+                GV1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[32], S[e], GV1, 0, 0, 0);
+                GK0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qrowp[0], P[e], GK0, 0, 0, 0);    // dKᵀ[d][key]
+                GK1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qrowp[32], P[e], GK1, 0, 0, 0);
+            }
+        }
+        if (qt + 1 < n_tiles) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    float* ob = lds;
+    for (int which = 0; which < 2; ++which) {
+        const f32x16& A0 = which ? GV0 : GK0;
+        const f32x16& A1 = which ? GV1 : GK1;
+        const float sc = which ? 1.0f : 0.125f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v0 = {A0[4 * g4], A0[4 * g4 + 1], A0[4 * g4 + 2], A0[4 * g4 + 3]};
+            f32x4 v1 = {A1[4 * g4], A1[4 * g4 + 1], A1[4 * g4 + 2], A1[4 * g4 + 3]};
+            st4(ob + (w * 32 + r) * KLD + 8 * g4 + 4 * h, v0 * sc);
+            st4(ob + (w * 32 + r) * KLD + 32 + 8 * g4 + 4 * h, v1 * sc);
+        }
+        __syncthreads();
+        float* dst = which ? a.dv : a.dk;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = sq + 16 * i;
+            if (kb0 + row < a.T)
+                st4(dst + ((int64_t)b * a.T + kb0 + row) * a.ldg + head * HD + squad, ld4(ob + row * KLD + squad));
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* vcache,
+                                const float* out, int ldo, const float* dout, int lddo, const float* lse2,
+                                float* dsum, float* dq, float* dk, float* dv, int ldg, int B, int n_heads,
+                                int T, int S_max, int mode, int x_len, const int32_t* x_len_dev,
+                                const int32_t* kv_len, const uint8_t* mask, const uint8_t* pad, void* stream) {
+    VH_REQUIRE(q && kcache && vcache && out && dout && lse2 && dsum && dq && dk && dv, VH_EINVAL,
+               "vh_attn_rows_bwd: null pointer");
+    VH_REQUIRE(B >= 0 && n_heads > 0 && T >= 0 && S_max >= T, VH_EINVAL,
+               "vh_attn_rows_bwd: bad dims B=%d h=%d T=%d S_max=%d", B, n_heads, T, S_max);
+    VH_REQUIRE(mode == VH_MASK_FULL || mode == VH_MASK_PREFIX || (mode == VH_MASK_EXPLICIT && mask), VH_EINVAL,
+               "vh_attn_rows_bwd: mode=%d", mode);
+    const int wd = n_heads * HD;
+    VH_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && ldg % 4 == 0 && ldq >= wd && ldo >= wd &&
+                   lddo >= wd && ldg >= wd,
+               VH_EINVAL, "vh_attn_rows_bwd: leading dimensions");
+    VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(out) &&
+                   vh_aligned16(dout) && vh_aligned16(dq) && vh_aligned16(dk) && vh_aligned16(dv),
+               VH_EALIGN, "vh_attn_rows_bwd: pointers must be 16-byte aligned");
+    if (B == 0 || T == 0) return VH_OK;
+    const int nb = (T + QB - 1) / QB;
+    BwdArgs a{q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, dsum, dq, dk, dv, ldg,
+              n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nb};
+    dim3 grid(nb * B * n_heads);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    VH_CHECK_LAUNCH("vh_attn_rows_bwd");
     return VH_OK;
 }

@@ -203,7 +203,7 @@ def linear_x64(a, w, bias=None, residual64=None, out=None):
 
 
 def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_dev=None,
-              kv_len=None, mask=None, pad=None):
+              kv_len=None, mask=None, pad=None, lse2=None):
     S_max = kcache.shape[2]
     if tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM) or Tk > S_max or Tq > Tk:
         raise _lib.VhError(f'attn_rows: cache {tuple(kcache.shape)} Tq={Tq} Tk={Tk}')
@@ -213,11 +213,37 @@ def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_d
         raise _lib.VhError('attn_rows: mask must be uint8 (Tq,Tk)')
     if pad is not None and (pad.dtype != torch.uint8 or tuple(pad.shape) != (B, Tk)):
         raise _lib.VhError('attn_rows: pad must be uint8 (B,Tk)')
+    if lse2 is not None:        # training forward: keep the row log-sum-exp for attn_rows_bwd
+        if tuple(lse2.shape) != (B, n_heads, Tq) or lse2.dtype != torch.float32:
+            raise _lib.VhError('attn_rows: lse2 must be float32 (B, n_heads, Tq)')
+        check(_lib.lib().vh_attn_rows_lse(
+            q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0), B,
+            n_heads, Tq, Tk, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
+            ptr(lse2), stream()), 'vh_attn_rows_lse')
+        return out
     check(_lib.lib().vh_attn_rows(
         q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0), B,
         n_heads, Tq, Tk, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
         stream()), 'vh_attn_rows')
     return out
+
+
+def attn_rows_bwd(q, kcache, vcache, out, dout, lse2, dq, dk, dv, B, n_heads, T, mode, x_len=0,
+                  x_len_dev=None, kv_len=None, mask=None, pad=None):
+    """dq, dk, dv (each (B*T, d) views with a common row stride, heads at columns h*64) of
+    attn_rows(q, kcache, vcache) given dout; P is recomputed tile by tile, never materialised."""
+    S_max = kcache.shape[2]
+    if tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM) or kcache.shape != vcache.shape or T > S_max:
+        raise _lib.VhError(f'attn_rows_bwd: cache {tuple(kcache.shape)} T={T}')
+    if not (dq.stride(0) == dk.stride(0) == dv.stride(0)) or dq.stride(1) != 1:
+        raise _lib.VhError('attn_rows_bwd: dq/dk/dv must share one row stride')
+    dsum = torch.empty(B, n_heads, T, device=q.device, dtype=torch.float32)
+    check(_lib.lib().vh_attn_rows_bwd(
+        q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0),
+        dout.data_ptr(), dout.stride(0), ptr(lse2), ptr(dsum), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+        dq.stride(0), B, n_heads, T, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
+        stream()), 'vh_attn_rows_bwd')
+    return dq, dk, dv
 
 
 def attn_decode_ws(B, n_heads, n_split, device):
