@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     // of the memory instructions of the accumulator layout (lane = column, 4 B per lane).  That count
     // is what matters: the CU's memory pipeline is shared with the other workgroup's operand loads,
     // and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the residual loads
-    // (tools/tile_diag.py).  Residual and bias are fetched NOW, so the epilogue waits for nothing.
+    // (stores / residual loads switched off in a diagnostic build).  Residual and bias are fetched NOW, so
+    // the epilogue waits for nothing.
     const int ec4 = tid & 31, erow = tid >> 5;
     const int en = n0 + 4 * ec4;
     const bool ecol_full = en + 3 < a.N;
