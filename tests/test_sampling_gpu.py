@@ -105,3 +105,30 @@ def test_generate_with_default_sampling_config():
     length = (rows != 1024).sum(-1)
     best = int(torch.argmax(lps / length))
     assert torch.equal(rows[best, 256:], out1)
+
+
+@pytest.mark.parametrize('top_k,V', [(1, 1025), (2, 5), (50, 1025), (64, 1025), (200, 1025), (1024, 1025), (7, 2048)])
+def test_fast_top_k_path_matches_the_sorted_path_in_distribution(top_k, V):
+    """top_p == 1 takes the radix-select path (no sort); top_p just below 1 takes the sorted path with the
+    same support.  Same support, same per-token log-probabilities, frequencies within 4 sigma."""
+    from valle2_amd.utils import topk_sampling
+    g = torch.Generator().manual_seed(100 + top_k)
+    row = 2.0 * torch.randn(V, generator=g)
+    row[3] = row[min(V - 1, 17)]                           # an exact tie somewhere
+    if top_k >= 2 and V > 6:
+        srt = torch.sort(row, descending=True).values
+        row[5] = srt[top_k - 1]                             # and one exactly at the k-th place
+    probs = expected_probs(row, top_k, 1.0, 1.0)
+    dev_rows = row.to(DEV)[None].expand(N, -1).contiguous()
+    tok, lp = topk_sampling(dev_rows, top_k=top_k, tok_p=1.0, seed=77)
+    tok, lp = tok[:, 0].cpu(), lp.cpu()
+    assert bool((probs[tok] > 0).all()), 'a token outside the top-k support was drawn'
+    freq = torch.bincount(tok, minlength=V).float() / N
+    sigma = torch.sqrt(probs * (1 - probs) / N)
+    assert bool(((freq - probs).abs() <= 4 * sigma + 1e-4).all()), (freq - probs).abs().max()
+    torch.testing.assert_close(lp, torch.log(probs[tok]), atol=1e-5, rtol=1e-5)
+    # every token of the support is reachable when it is small
+    if top_k <= 7:
+        assert set(tok.tolist()) == set(torch.nonzero(probs > 0)[:, 0].tolist())
+    tok2, lp2 = topk_sampling(dev_rows, top_k=top_k, tok_p=1.0, seed=77)
+    assert torch.equal(tok2[:, 0].cpu(), tok) and torch.equal(lp2.cpu(), lp)      # seed-deterministic

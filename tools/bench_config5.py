@@ -1,0 +1,38 @@
+"""Decode timing at BASELINE.json configs[4]: 24L/1024d/h16/dff4096 AR, 8 rows, 400 text + 226 prompt
+frames, long context (developer tool; usage: python tools/bench_config5.py [new_tokens=256])."""
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from valle2_amd import ConfigValle, get_model_class, synth  # noqa: E402
+
+
+def main(new=256):
+    cfg = ConfigValle(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0, norm='LayerNorm',
+                      num_beams=8, max_audio_len=new)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=0, rich=False), cfg)
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to('cuda').eval()
+    for frames in (225, 2250):        # 3 s prompt; and the end of a 30 s utterance (context ~2876)
+        utts = [synth.synth_utterance(cfg, 200, 200, frames, seed=7 + u) for u in range(8)]
+        texts = [torch.cat([u[0], u[2]]).cuda() for u in utts]
+        firsts = [u[1][:, 0].cuda() for u in utts]
+        for it in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = m.generate_batch(texts, firsts)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        s0 = 400 + frames + 1
+        kv = 2 * 24 * 8 * 1024 * 4 * (s0 + new / 2)
+        w = 24 * (4 * 1024 * 1024 + 2 * 1024 * 4096) * 4
+        print(f'context {s0}..{s0 + new}: {dt * 1e3:.1f} ms per generate of {new} tokens x 8 rows = '
+              f'{8 * new / dt:.0f} tokens/s; decode bytes/step ~ {(kv + w) / 1e9:.2f} GB', flush=True)
+
+
+if __name__ == '__main__':
+    main(*[int(a.split('=')[1]) for a in sys.argv[1:]])
