@@ -190,13 +190,33 @@ extern "C" int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* strea
 }
 
 extern "C" int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream,
-                                          float* mean_ms) {
+                                          float* mean_ms, float* floor_ms) {
     VH_REQUIRE(dec && mean_ms && n_steps > 0, VH_EINVAL, "vh_ar_decoder_profile_attn: bad args");
     hipStream_t s = (hipStream_t)stream;
-    std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> ev, fl;
     int rc = VH_OK;
-    for (int i = 0; i < n_steps && rc == VH_OK; ++i) rc = decoder_enqueue(dec, s, &ev);
+    for (int i = 0; i < n_steps && rc == VH_OK; ++i) {
+        rc = decoder_enqueue(dec, s, &ev);
+        // measurement floor: the same bracket with nothing inside, once per step
+        hipEvent_t f0, f1;
+        if (floor_ms && hipEventCreate(&f0) == hipSuccess && hipEventCreate(&f1) == hipSuccess) {
+            (void)hipEventRecord(f0, s);
+            (void)hipEventRecord(f1, s);
+            fl.push_back(f0);
+            fl.push_back(f1);
+        }
+    }
     (void)hipStreamSynchronize(s);
+    if (floor_ms) {
+        double ft = 0.0;
+        int fn = 0;
+        for (size_t i = 0; i + 1 < fl.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, fl[i], fl[i + 1]) == hipSuccess) { ft += ms; ++fn; }
+        }
+        for (hipEvent_t e : fl) (void)hipEventDestroy(e);
+        *floor_ms = fn ? (float)(ft / fn) : 0.f;
+    }
     double total = 0.0;
     int n = 0;
     for (size_t i = 0; i + 1 < ev.size(); i += 2) {

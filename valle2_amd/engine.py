@@ -262,9 +262,10 @@ class ArDecoder:
                 check(L.vh_ar_decoder_step(self._h, s), 'vh_ar_decoder_step')
 
     def profile_attn(self, n_steps):
-        """Mean duration (ms) of the decode-attention launches over n_steps eager steps, measured
-        with HIP events on the launch stream (advances the decode state by n_steps)."""
-        ms = C.c_float(0)
-        check(_lib.lib().vh_ar_decoder_profile_attn(self._h, n_steps, stream(), C.byref(ms)),
+        """(bracket_ms, floor_ms): mean event-to-event time of the HIP-event brackets around the
+        decode-attention launches over n_steps eager steps, and the mean time of an empty bracket on the
+        same stream (advances the decode state by n_steps)."""
+        ms, floor = C.c_float(0), C.c_float(0)
+        check(_lib.lib().vh_ar_decoder_profile_attn(self._h, n_steps, stream(), C.byref(ms), C.byref(floor)),
               'vh_ar_decoder_profile_attn')
-        return ms.value
+        return ms.value, floor.value
