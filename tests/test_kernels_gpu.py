@@ -109,6 +109,29 @@ def test_linear_splitk_workspace_path(K, M, N, K_):
     assert torch.equal(o1, o2)
 
 
+@pytest.mark.parametrize('M,N,K_', [(884, 1024, 4096), (300, 512, 2048), (129, 1025, 1024), (1137, 1024, 1024),
+                                    (700, 128, 1536)])
+def test_linear_splitk_tile_path(K, M, N, K_):
+    """65 <= M with few 128x128 tiles and a long K: K slices in the tile kernel + fixed-order reduce."""
+    from valle2_amd import _lib
+    assert _lib.lib().vh_linear_ws_bytes(M, N, K_) > 0
+    a = torch.randint(-3, 4, (M, K_), generator=g(180)).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g(181)).float()
+    w[:, 2] += torch.arange(N).float() % 5
+    assert torch.equal(K.linear_ws(a.to(DEV), w.to(DEV)).cpu(), a @ w.T)
+    a = torch.randn(M, K_, generator=g(182))
+    w = torch.randn(N, K_, generator=g(183)) / K_ ** 0.5
+    bias, res = torch.randn(N, generator=g(184)), torch.randn(M, N, generator=g(185))
+    resd = torch.zeros(M, (N + 3) // 4 * 4, device=DEV)[:, :N]
+    resd.copy_(res)
+    out = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV), resd, out=resd, act=1)
+    close(out, F.gelu(F.linear(a, w, bias)) + res, atol=5e-5)
+    o1 = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV))
+    o2 = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV))
+    assert torch.equal(o1, o2)                               # fixed-order reduction
+    close(o1, K.linear(a.to(DEV), w.to(DEV), bias.to(DEV)).cpu(), atol=5e-5)
+
+
 @pytest.mark.parametrize('M', [7, 32, 200])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_epilogues(K, M, act):

@@ -162,15 +162,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = srow + 32 * i;
-        pa[i] = a.A + (int64_t)min(m0 + row, a.M - 1) * a.lda + skq;
-        pw[i] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.K + skq;
+        // split-K (EPI_PARTIAL): this workgroup's K range starts at blockIdx.y * k_len
+        pa[i] = a.A + (int64_t)min(m0 + row, a.M - 1) * a.lda + skq + blockIdx.y * a.k_len;
+        pw[i] = a.W + (int64_t)min(n0 + row, a.N - 1) * a.K + skq + blockIdx.y * a.k_len;
     }
     // Loads are unconditional (no branches, no use of the loaded value inside the main loop): rows
     // beyond M / N are clamped to the last valid row — their products only reach output rows / columns
     // that are never stored — and a K tail (K % 32 = 16) is clamped here and zeroed when the slab is
     // written to LDS.
     auto gload1 = [&](int i, int k0) {           // one A row + one W row of the K slab at k0
-        const int kk = k0 + skq < a.K ? k0 : 0;  // K % 4 == 0 is guaranteed by the host check
+        const int kk = k0 + skq < a.k_len ? k0 : 0;  // K % 4 == 0 is guaranteed by the host check
         ra[i] = ld4(pa[i] + kk);
         rw[i] = ld4(pw[i] + kk);
     };
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
         for (int i = 0; i < 4; ++i) gload1(i, k0);
     };
     auto lstore = [&](int buf, int k0) {
-        const bool kin = k0 + skq < a.K;
+        const bool kin = k0 + skq < a.k_len;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = srow + 32 * i;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (a.K + TK - 1) / TK;
+    const int nk = (a.k_len + TK - 1) / TK;
     gload(0);
     lstore(0, 0);
 
@@ -296,7 +297,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
         const int row = erow + 8 * it, m = m0 + row;
         if (m >= a.M) break;
         f32x4 v = ld4(ct + row * LDC + 4 * ec4);
-        if (EPI == EPI_QKV) {                          // N = 3 d_model, a multiple of 4: groups are whole
+        if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y → slab [split][M][ldo]
+            float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
+            if (ecol_full) st4(dst, v);
+            else
+                for (int j = 0; j < 4 && en + j < a.N; ++j) dst[j] = v[j];
+        } else if (EPI == EPI_QKV) {                   // N = 3 d_model, a multiple of 4: groups are whole
             if (qcache) {
                 const int b = m / a.T, t = m - b * a.T;
                 const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
@@ -723,7 +729,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 static int splitk_plan(int M, int N, int K) {
     // number of K slices (0 = do not split)
-    if (M > 64 || K <= 1024 || K % 256 != 0) return 0;
+    if (M > 64) {
+        // tile kernel: too few 128x128 tiles for the 256 CUs (a single utterance through the NAR stack, a short
+        // prefill) and a long K: cut K so that the grid approaches two workgroups per CU
+        const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+        if (tiles > 128 || K < 1024) return 0;
+        int splits = 1;
+        while (splits < 8 && tiles * splits * 2 <= 512 && K % (splits * 2 * TK) == 0 && K / (splits * 2) >= 256) splits *= 2;
+        return splits >= 2 ? splits : 0;
+    }
+    if (K <= 1024 || K % 256 != 0) return 0;
     const int tiles = (N + 15) / 16;
     int splits = min(16, 256 / tiles);
     while (splits > 1 && (K % (splits * 256) != 0)) --splits;
@@ -1064,6 +1079,16 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
                    (!residual || ldr % 4 == 0),
                VH_EALIGN, "vh_linear_ws: out/bias/residual alignment");
     hipStream_t s = (hipStream_t)stream;
+    if (M > 64) {                                 // tile kernel, K slices in gridDim.y
+        const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
+        hipLaunchKernelGGL((gemm_tile_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
+        const int items_t = M * (lds_ / 4);
+        const int rbt = 256;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items_t + rbt - 1) / rbt), dim3(rbt), 0, s,
+                           (const float*)workspace, splits, fin, lds_);
+        VH_CHECK_LAUNCH("vh_linear_ws");
+        return VH_OK;
+    }
     dim3 grid((N + 15) / 16, splits);
     const int mt = (M + 15) / 16;
     // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass

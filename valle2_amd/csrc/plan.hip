@@ -249,14 +249,14 @@ extern "C" int vh_transformer_forward(const vh_forward_desc* f, void* stream) {
                           f->S_max, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
         TRY(vh_attn_rows(f->q, D, L.kcache, L.vcache, f->attn, D, B, f->n_heads, T, T, f->S_max,
                          f->mode, f->x_len, f->x_len_dev, f->kv_len, f->mask, f->pad, stream));
-        TRY(vh_linear(f->attn, D, L.wo, L.bo, f->x, D, f->x, D, M, D, D, VH_ACT_NONE, nullptr, nullptr,
-                      nullptr, nullptr, 0.f, stream));
+        TRY(vh_linear_ws(f->attn, D, L.wo, L.bo, f->x, D, f->x, D, M, D, D, VH_ACT_NONE, f->gemm_ws,
+                         f->gemm_ws_bytes, stream));
         TRY(vh_layernorm(f->x, L.ln2_g, L.ln2_b, ada ? ada + 2 * D : nullptr, ada ? ada + 3 * D : nullptr,
                          f->xn, M, D, f->ln_eps, stream));
         TRY(vh_linear(f->xn, D, L.w1, L.b1, nullptr, 0, f->hidden, f->dff, M, f->dff, D,
                       VH_ACT_GELU_ERF, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
-        TRY(vh_linear(f->hidden, f->dff, L.w2, L.b2, f->x, D, f->x, D, M, D, f->dff, VH_ACT_NONE,
-                      nullptr, nullptr, nullptr, nullptr, 0.f, stream));
+        TRY(vh_linear_ws(f->hidden, f->dff, L.w2, L.b2, f->x, D, f->x, D, M, D, f->dff, VH_ACT_NONE, f->gemm_ws,
+                         f->gemm_ws_bytes, stream));
     }
     return VH_OK;
 }

@@ -130,6 +130,9 @@ class ForwardScratch:
         self.q = torch.empty(rows, d, device=device, dtype=torch.float32)
         self.attn = torch.empty(rows, d, device=device, dtype=torch.float32)
         self.hidden = torch.empty(rows, dff, device=device, dtype=torch.float32)
+        L = _lib.lib()
+        self.ws_bytes = max(L.vh_linear_ws_bytes(rows, d, d), L.vh_linear_ws_bytes(rows, d, dff))
+        self.ws = torch.empty(self.ws_bytes // 4, device=device, dtype=torch.float32) if self.ws_bytes else None
 
 
 def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_dev=None,
@@ -154,7 +157,7 @@ def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_
         S_max=cache.s_max, mode=mode, x_len=int(x_len), ln_eps=1e-5, layers=table, ada=ptr(ada),
         x_len_dev=ptr(x_len_dev), kv_len=ptr(kv_len), mask=ptr(mask), pad=ptr(pad),
         x=ptr(x), xn=ptr(scratch.xn), q=ptr(scratch.q), attn=ptr(scratch.attn),
-        hidden=ptr(scratch.hidden))
+        hidden=ptr(scratch.hidden), gemm_ws=ptr(scratch.ws), gemm_ws_bytes=scratch.ws_bytes)
     check(_lib.lib().vh_transformer_forward(C.byref(desc), stream()), 'vh_transformer_forward')
     return x
 
