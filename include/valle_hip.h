@@ -98,7 +98,7 @@ int vh_linear(const float* A, int lda, const float* W, const float* bias, const 
  * vh_linear_ws_bytes(M,N,K) bytes: for M <= 64 and K > 1024 (linear_2, K = dim_feedforward) the K
  * range is split over ~256 workgroups whose partial sums meet in the workspace and are added in a
  * fixed order by a second small kernel (bitwise reproducible; no atomics).  The same is done for
- * M > 64 when the (M,N) grid has at most 128 tiles of 128x128 and K >= 1024 (one utterance through
+ * M > 64 when the (M,N) grid has at most 256 tiles of 128x128 and K >= 1024 (one utterance through
  * the NAR stack, a short prefill): K slices in the second grid dimension of the tile kernel.
  * Falls back to vh_linear when the shape does not split or workspace == NULL. */
 size_t vh_linear_ws_bytes(int M, int N, int K);
@@ -356,7 +356,7 @@ typedef struct {
     const uint8_t *mask, *pad;
     float *x, *xn, *q, *attn, *hidden;
     /* optional split-K workspace for the out-projection and linear_2 when B*T is small (few 128x128 tiles,
-     * long K): max(vh_linear_ws_bytes(B*T, d_model, d_model), vh_linear_ws_bytes(B*T, d_model, dff)) bytes */
+     * long K): the largest of vh_linear_ws_bytes(B*T, d_model, d_model), (B*T, d_model, dff), (B*T, dff, d_model) */
     void *gemm_ws;
     size_t gemm_ws_bytes;
 } vh_forward_desc;

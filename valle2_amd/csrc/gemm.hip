@@ -733,7 +733,7 @@ static int splitk_plan(int M, int N, int K) {
         // tile kernel: too few 128x128 tiles for the 256 CUs (a single utterance through the NAR stack, a short
         // prefill) and a long K: cut K so that the grid approaches two workgroups per CU
         const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
-        if (tiles > 128 || K < 1024) return 0;
+        if (tiles > 256 || K < 1024) return 0;
         int splits = 1;
         while (splits < 8 && tiles * splits * 2 <= 512 && K % (splits * 2 * TK) == 0 && K / (splits * 2) >= 256) splits *= 2;
         return splits >= 2 ? splits : 0;

@@ -253,8 +253,8 @@ extern "C" int vh_transformer_forward(const vh_forward_desc* f, void* stream) {
                          f->gemm_ws_bytes, stream));
         TRY(vh_layernorm(f->x, L.ln2_g, L.ln2_b, ada ? ada + 2 * D : nullptr, ada ? ada + 3 * D : nullptr,
                          f->xn, M, D, f->ln_eps, stream));
-        TRY(vh_linear(f->xn, D, L.w1, L.b1, nullptr, 0, f->hidden, f->dff, M, f->dff, D,
-                      VH_ACT_GELU_ERF, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
+        TRY(vh_linear_ws(f->xn, D, L.w1, L.b1, nullptr, 0, f->hidden, f->dff, M, f->dff, D, VH_ACT_GELU_ERF,
+                         f->gemm_ws, f->gemm_ws_bytes, stream));
         TRY(vh_linear_ws(f->hidden, f->dff, L.w2, L.b2, f->x, D, f->x, D, M, D, f->dff, VH_ACT_NONE, f->gemm_ws,
                          f->gemm_ws_bytes, stream));
     }

@@ -131,7 +131,8 @@ class ForwardScratch:
         self.attn = torch.empty(rows, d, device=device, dtype=torch.float32)
         self.hidden = torch.empty(rows, dff, device=device, dtype=torch.float32)
         L = _lib.lib()
-        self.ws_bytes = max(L.vh_linear_ws_bytes(rows, d, d), L.vh_linear_ws_bytes(rows, d, dff))
+        self.ws_bytes = max(L.vh_linear_ws_bytes(rows, d, d), L.vh_linear_ws_bytes(rows, d, dff),
+                            L.vh_linear_ws_bytes(rows, dff, d))
         self.ws = torch.empty(self.ws_bytes // 4, device=device, dtype=torch.float32) if self.ws_bytes else None
 
 
