@@ -1,14 +1,18 @@
 // fp32 GEMMs of the path:  out = act(LN?(A) · Wᵀ + bias) + residual   (A (M,K), W (N,K))
 //
-// Two kernels, both on the exact-f32 matrix cores (no TF32 on gfx950):
-//   * gemm_tile_kernel    M large (prefill / NAR / training): 128x128x32 LDS-tiled,
-//                         v_mfma_f32_32x32x2_f32, 4 waves x (2x2 tiles of 32x32), register-staged
-//                         double buffer, XCD-aware tile order.  MFMA-bound (157 TF peak).
-//   * gemm_skinny_kernel  M <= 64 (decode step, heads, AdaLN vectors): weight-streaming,
-//                         v_mfma_f32_16x16x4_f32 with W as the A operand so a lane's 4 results are
-//                         4 consecutive output columns; K split over the waves of a block and
-//                         reduced through LDS in fixed order (deterministic); optional LayerNorm
-//                         fused into the activation operand load.  HBM/latency-bound.
+// All on the exact-f32 matrix cores (no TF32 on gfx950):
+//   * gemm_tile_kernel    M > 64 (prefill / NAR / training forward): 128x128x32 LDS-tiled,
+//                         v_mfma_f32_32x32x2_f32, 4 waves x (2x2 tiles of 32x32), register-staged double
+//                         buffer, branch-free hand-pipelined main loop, LDS-transposed float4 epilogue
+//                         (bias / GELU / residual / QKV scatter / split-K slab), XCD-aware tile order.
+//                         MFMA-bound (157 TF peak).
+//   * gemm_skinny_fast    M <= 64 (decode step, heads): weight-streaming, v_mfma_f32_16x16x4_f32 with W
+//                         as the A operand so a lane's 4 results are 4 consecutive output columns; K over
+//                         the waves of a workgroup, reduced through LDS in fixed order; one workgroup per
+//                         (16 columns, 8..16 rows); LayerNorm in the operand load or folded into the
+//                         weights (vh_ln_fold); split-K slabs + splitk_reduce_kernel for K > 1024; the
+//                         opt-in fp64 accumulator form (exact atomics).  Latency-bound.
+//   * gemm_skinny_kernel  the guarded generic version for K off the fast shapes.
 //
 // MFMA operand maps used (cdna_hip_programming.md §3):
 //   32x32x2 : A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]; D reg r: row i=(r&3)+8(r>>2)+4(l>>5), col j=l&31
