@@ -189,3 +189,10 @@ def test_collate_matches_reference_golden():
     with pytest.raises(AssertionError):       # codes must be longer than tokens (collate.py:37)
         ValleARCollate(cfg)([{'codes': torch.zeros(8, 3, dtype=torch.int64),
                               'tokens': torch.zeros(9, dtype=torch.int64)}])
+
+
+def test_flat_adamw_refuses_cpu_parameters():
+    from valle2_amd._lib import VhError
+    from valle2_amd.optim import FlatAdamW
+    with pytest.raises(VhError, match='HIP device'):
+        FlatAdamW([torch.nn.Parameter(torch.zeros(4, 4))])

@@ -38,6 +38,9 @@ class FlatAdamW(torch.optim.Optimizer):
         dev = params[0].device
         if any(p.dtype != torch.float32 or p.device != dev for p in params):
             raise _lib.VhError('FlatAdamW: parameters must be fp32 on one device')
+        if dev.type != 'cuda':
+            raise _lib.VhError('FlatAdamW: move the model to its HIP device first (model.to("cuda")); the '
+                               'optimizer re-homes the parameters into one flat device buffer')
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.slots, self.numel = flat_layout(params)
         f32 = dict(device=dev, dtype=torch.float32)
