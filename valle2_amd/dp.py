@@ -26,7 +26,8 @@ def init_distributed(backend: str | None = None, device: torch.device | None = N
     if world == 1 or dist.is_initialized():
         return rank, world
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+    # VALLE2_DIST_BACKEND=gloo: rehearsal of several ranks on one GPU (RCCL wants one device per rank)
+    backend = os.environ.get('VALLE2_DIST_BACKEND') or backend or ('nccl' if torch.cuda.is_available() else 'gloo')
     kwargs = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
     dist.init_process_group(backend, **kwargs)
     return rank, world

@@ -13,6 +13,7 @@ batches in the collate wire format.
 from __future__ import annotations
 
 import argparse
+import os
 import time
 from pathlib import Path
 
@@ -35,6 +36,7 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
     from . import get_model_class
     config = ConfigValle.from_json(hparams_fp) if not isinstance(hparams_fp, ConfigValle) else hparams_fp
     rank, local, _ = dp.env_world()
+    local = int(os.environ.get('VALLE2_FORCE_DEVICE', local))     # rehearsal: several ranks on one GPU
     device = device or torch.device('cuda', local)
     if device.type == 'cuda':
         torch.cuda.set_device(device)
