@@ -245,6 +245,19 @@ def test_flat_adamw_drives_the_model_and_invalidates_folded_weights():
     torch.testing.assert_close(after[0][0][0], w * g, rtol=0, atol=0)
     loss1 = model.training_step({k: v.clone() for k, v in batch.items()})
     assert float(loss1.detach()) < float(loss0.detach())
+    # a checkpoint loads INTO the flat buffer (parameters stay views of it) and the optimizer state round-trips
+    ptrs = [p.data_ptr() for p in model.parameters()]
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert [p.data_ptr() for p in model.parameters()] == ptrs
+    w0 = model.transformer.layers[0].self_attn.qkv.weight
+    assert torch.equal(w0.detach().cpu(), sd['transformer.layers.0.self_attn.qkv.weight'])
+    off = next(o for p_, o, n in opt.slots if p_ is w0)
+    assert torch.equal(opt.flat_param[off:off + w0.numel()].view_as(w0), w0.detach())
+    state = opt.state_dict()
+    opt2 = type(opt)(model.parameters(), lr=1.0)
+    opt2.load_state_dict(state)
+    assert opt2.steps == opt.steps and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    assert opt2.param_groups[0]['lr'] == opt.param_groups[0]['lr']
 
 
 # ---- attention backward kernels (vh_attn_rows_bwd) directly against torch autograd -----------------------
