@@ -88,9 +88,11 @@ def attn_algorithmic_bytes(rows, d_model, s0, new):
     return 4.0 * (2 * rows * mean_s * d_model + 2 * rows * d_model), mean_s
 
 
-def cpu_baseline(cfg_kw, sd, utt, rows, new):
+def cpu_baseline(cfg_kw, sd, utt, rows, new, gpu_tokens=None):
     """Oracle (CPU restatement, proven bit-identical to the reference on the golden fixtures) on
-    this host's cores: prefill once, then 16 decode steps; extrapolated to `new` tokens."""
+    this host's cores: prefill once, then 16 decode steps; extrapolated to `new` tokens.  The 17 tokens
+    it produces are also compared with what the HIP path generated for the same utterance (full-size
+    parity check; steps whose top-1/top-2 margin is below 1e-4 do not count as mismatches)."""
     import torch
 
     from oracle import valle_oracle as O          # checker/baseline only (never the product path)
@@ -100,13 +102,23 @@ def cpu_baseline(cfg_kw, sd, utt, rows, new):
     for n in (1, 17):
         log(f'cpu_baseline: oracle generate with {n} step(s) on {torch.get_num_threads()} threads')
         cfg = ConfigValle(**dict(cfg_kw, num_beams=rows, max_audio_len=n))
+        trace = {} if n == 17 else None
         t0 = time.perf_counter()
-        O.ar_generate(sd, cfg, *utt)
+        toks = O.ar_generate(sd, cfg, *utt, trace=trace)
         times[n] = time.perf_counter() - t0
     t_prefill, t_step = times[1], (times[17] - times[1]) / 16
     total = t_prefill + (new - 1) * t_step
+    parity = None
+    if gpu_tokens is not None:
+        ref = [int(t) for t in toks][:17]
+        got = [int(t) for t in gpu_tokens[:len(ref)]]
+        margins = [float(m) for m in (trace or {}).get('margin', [])] + [float('inf')] * len(ref)
+        bad = [i for i, (a, b) in enumerate(zip(ref, got)) if a != b and margins[i] > 1e-4]
+        parity = {'tokens_compared': len(ref), 'mismatches': len(bad),
+                  'note': 'HIP greedy tokens of utterance 0 vs the oracle at full size'}
+        log(f'cpu_baseline: full-size greedy parity on {len(ref)} tokens: {len(bad)} mismatches')
     return {'value': rows * new / total, 'unit': 'tokens/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
+            'kind': 'port', 'parity': parity,
             'sample': f'oracle ar_generate, same shapes: 1 prefill ({t_prefill:.2f} s) + 16 decode steps '
                       f'({t_step * 1e3:.1f} ms/step at S~{TEXT + FRAMES + 1}), extrapolated to {new} tokens'}
 
@@ -255,7 +267,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # same model, same first utterance, all `rows` beams, on the host cores of this box
-        result['cpu_baseline'] = cpu_baseline(ar_kw, sd, utts[0], rows, new)
+        result['cpu_baseline'] = cpu_baseline(ar_kw, sd, utts[0], rows, new,
+                                              gpu_tokens=out[0, frames + 1:].cpu())
 
     if rank == 0:
         print(json.dumps(result), flush=True)
