@@ -193,7 +193,7 @@ def main():
                                '1024-token prompt -> 512 new tokens, 1xMI355X per rank'
                                if not args.small else 'SMALL functional check (not the metric)',
                    'rows_per_gpu': rows, 'prompt_tokens': text + frames + 1, 'new_tokens': new,
-                   'layers': cfg.num_layers, 'd_model': cfg.d_model, 'sharding': f'utterance-batch x{world}',
+                   'sharding': f'utterance-batch x{world}',
                    'timed_region': 'embed + prefill + (new-1) hipGraph-replayed decode steps'},
     }
 
