@@ -58,6 +58,8 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16
        VH_TUNE_ROW_GROUPS = 2,      /* decode GEMMs (16 < M <= 64): 1 (default) = one workgroup per 16 rows x 16 columns,
                                        (8 rows while the grid stays within the CUs), 2 = one workgroup per
                                        16 columns (all rows), 3 = groups of 16 rows only */
+       VH_TUNE_TILE_DMA = 4,        /* large-M GEMM operand staging: 0 (default) = LDS-DMA when K % 32 == 0,
+                                       1 = always through registers, 2 = LDS-DMA whenever eligible */
        VH_TUNE_REDUCE_BLOCK = 3,    /* threads per workgroup of the split-K reduce: 64, 128 (default), 256 */
        VH_TUNE_COUNT = 8 };
 int vh_set_tuning(int knob, int value);

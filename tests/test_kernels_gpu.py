@@ -25,6 +25,16 @@ def K():
     return kernels
 
 
+@pytest.fixture(params=[1, 2], ids=['staged', 'lds-dma'])
+def tile_staging(request):
+    """Run a large-M GEMM test under both operand-staging kernels (VH_TUNE_TILE_DMA: 1 = through registers,
+    2 = LDS-DMA whenever K % 32 == 0); the default (0) picks between them by shape."""
+    from valle2_amd import _lib
+    _lib.lib().vh_set_tuning(4, request.param)
+    yield request.param
+    _lib.lib().vh_set_tuning(4, 0)
+
+
 def close(a, b, atol=2e-5, rtol=2e-5):
     torch.testing.assert_close(a.cpu(), b, atol=atol, rtol=rtol)
 
@@ -42,7 +52,7 @@ def test_linear_skinny_integer_exact(K, M, N, K_):
 
 @pytest.mark.parametrize('M,N,K_', [(65, 16, 16), (128, 128, 32), (300, 1025, 128), (257, 1536, 512),
                                     (1000, 100, 2048)])
-def test_linear_tile_integer_exact(K, M, N, K_):
+def test_linear_tile_integer_exact(K, M, N, K_, tile_staging):
     a = torch.randint(-3, 4, (M, K_), generator=g(3)).float()
     w = torch.randint(-3, 4, (N, K_), generator=g(4)).float()
     w[:, 1] += torch.arange(N).float() % 7
@@ -52,7 +62,7 @@ def test_linear_tile_integer_exact(K, M, N, K_):
 
 @pytest.mark.parametrize('M,N,K_', [(65, 16, 16), (256, 256, 32), (300, 1025, 128), (513, 1536, 512),
                                     (1000, 100, 2048)])
-def test_linear_tile_epilogues(K, M, N, K_):
+def test_linear_tile_epilogues(K, M, N, K_, tile_staging):
     """bias / GELU / in-place residual through the LDS-transposed float4 epilogue, ragged M and N."""
     a = torch.randn(M, K_, generator=g(5))
     w = 0.05 * torch.randn(N, K_, generator=g(6))
@@ -67,7 +77,7 @@ def test_linear_tile_epilogues(K, M, N, K_):
     close(K.linear(a.to(DEV), w.to(DEV), bias.to(DEV)), F.linear(a, w, bias), atol=5e-5)
 
 
-def test_linear_qkv_scatter_large_m(K):
+def test_linear_qkv_scatter_large_m(K, tile_staging):
     B, T, h = 3, 200, 4
     d = 64 * h
     S_max = 260
@@ -87,6 +97,24 @@ def test_linear_qkv_scatter_large_m(K):
         close(kc[b, :, p0:p0 + T], kref[b], atol=5e-5)
         close(vc[b, :, p0:p0 + T], vref[b], atol=5e-5)
         assert float(kc[b, :, :p0].abs().sum()) == 0 and float(kc[b, :, p0 + T:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('M,N,K_', [(257, 1536, 512), (1000, 100, 2048), (6144, 2048, 64), (130, 132, 96)])
+def test_linear_tile_staging_kernels_bit_identical(K, M, N, K_):
+    """The register-staged and the LDS-DMA tile kernels accumulate K in the same order: same bits.  (6144 x 2048
+    is the 768-tile shape the default routes to the staged kernel.)"""
+    from valle2_amd import _lib
+    a = torch.randn(M, K_, generator=g(300)).to(DEV)
+    w = (0.05 * torch.randn(N, K_, generator=g(301))).to(DEV)
+    bias = torch.randn(N, generator=g(302)).to(DEV)
+    res = torch.randn(M, N, generator=g(303)).to(DEV)
+    outs = []
+    for mode in (1, 2, 0):
+        _lib.lib().vh_set_tuning(4, mode)
+        outs.append(K.linear(a, w, bias, res, act=1).clone())
+    _lib.lib().vh_set_tuning(4, 0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    close(outs[0], F.gelu(F.linear(a.cpu(), w.cpu(), bias.cpu())) + res.cpu(), atol=5e-5)
 
 
 @pytest.mark.parametrize('M,N,K_', [(32, 512, 2048), (16, 512, 2048), (4, 1024, 4096), (33, 100, 1280),
@@ -111,7 +139,7 @@ def test_linear_splitk_workspace_path(K, M, N, K_):
 
 @pytest.mark.parametrize('M,N,K_', [(884, 1024, 4096), (300, 512, 2048), (129, 1025, 1024), (1137, 1024, 1024),
                                     (700, 128, 1536)])
-def test_linear_splitk_tile_path(K, M, N, K_):
+def test_linear_splitk_tile_path(K, M, N, K_, tile_staging):
     """65 <= M with few 128x128 tiles and a long K: K slices in the tile kernel + fixed-order reduce."""
     from valle2_amd import _lib
     assert _lib.lib().vh_linear_ws_bytes(M, N, K_) > 0

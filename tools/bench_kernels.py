@@ -184,9 +184,13 @@ def bench_tile():
             res = torch.randn(M, N, device=DEV)
             o = torch.empty(M, N, device=DEV)
             ref = torch.addmm(bias, a, w.t()) + res
-            us = statistics.median(timeit(lambda: K.linear(a, w, bias, res, out=o), iters=10, warm=2) for _ in range(3))
-            err = float((o - ref).abs().max())
-            line = f'tile M={M} {name} N={N} K={Kk}: {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF (err {err:.1e})'
+            line = f'tile M={M} {name} N={N} K={Kk}:'
+            for knob, label in ((1, 'staged'), (2, 'dma')):
+                _lib.lib().vh_set_tuning(4, knob)
+                us = statistics.median(timeit(lambda: K.linear(a, w, bias, res, out=o), iters=10, warm=2) for _ in range(3))
+                err = float((o - ref).abs().max())
+                line += f'  {label} {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF (err {err:.1e})'
+            _lib.lib().vh_set_tuning(4, 0)
             us = timeit(lambda: torch.addmm(bias, a, w.t(), out=o), iters=10, warm=2)
             line += f'  library: {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF'
             print(line, flush=True)
@@ -200,8 +204,27 @@ def bench_tile():
     print(f'tile qkv-scatter: {us:7.1f} us {2 * M * 1536 * 512 / us / 1e6:6.1f} TF', flush=True)
 
 
+def bench_tilesweep():
+    """Staged vs LDS-DMA tile kernel over tile counts around multiples of the 512 resident workgroups."""
+    for N, Kk in ((2048, 512), (512, 2048)):
+        for M in [128 * t for t in ((40, 44, 48, 52, 56, 60, 80, 96, 112) if N == 2048 else (136, 160, 176, 192, 208, 224, 240, 320, 384))]:
+            a = torch.randn(M, Kk, device=DEV)
+            w = 0.02 * torch.randn(N, Kk, device=DEV)
+            bias = torch.randn(N, device=DEV)
+            o = torch.empty(M, N, device=DEV)
+            line = f'M={M} N={N} K={Kk} tiles={(M + 127) // 128 * ((N + 127) // 128)}:'
+            for knob, label in ((1, 'staged'), (2, 'dma')):
+                _lib.lib().vh_set_tuning(4, knob)
+                us = statistics.median(timeit(lambda: K.linear(a, w, bias, None, out=o), iters=10, warm=2) for _ in range(3))
+                line += f'  {label} {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF'
+            _lib.lib().vh_set_tuning(4, 0)
+            print(line, flush=True)
+
+
 if __name__ == '__main__':
     what = sys.argv[1:] or ['attn', 'gemm', 'rows']
+    if 'tilesweep' in what:
+        bench_tilesweep()
     if 'tile' in what:
         bench_tile()
     if 'gemm' in what:

@@ -9,8 +9,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int KIND>   // 0: 32x32x2, 4 accumulators; 1: 16x16x4, 16 accumulators
-__global__ __launch_bounds__(256) void mfma_loop(const float* in, float* out, int iters) {
+__global__ __launch_bounds__(256) void mfma_loop(const float* in, float* out, int iters, int prio) {
     const int t = blockIdx.x * 256 + threadIdx.x;
+    // prio 1: the second half of the grid runs at wave priority 1; prio 2: odd workgroups do
+    if (prio == 1 && (blockIdx.x >> 8)) __builtin_amdgcn_s_setprio(1);
+    if (prio == 2 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);
     float a[8], b[8];
     for (int i = 0; i < 8; ++i) { a[i] = in[(t * 8 + i) & 65535]; b[i] = in[(t * 8 + i + 4096) & 65535]; }
     if (KIND == 0) {
@@ -53,19 +56,20 @@ int main() {
         for (auto& v : h) { s = s * 1664525u + 1013904223u; v = rnd ? ((s >> 8) & 0xFFFF) / 65536.0f - 0.5f : 0.f; }
         CK(hipMemcpy(in, h.data(), 65536 * 4, hipMemcpyHostToDevice));
         for (int kind = 0; kind < 2; ++kind)
-            for (int wgs = 256; wgs <= 512; wgs *= 2) {       // 1 or 2 waves per SIMD
+            for (int prio = 0; prio < 3; ++prio)
+            for (int wgs = (prio ? 512 : 256); wgs <= 512; wgs *= 2) {       // 1 or 2 waves per SIMD
                 const int iters = 20000;
                 hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
                 for (int rep = 0; rep < 2; ++rep) {
                     hipEventRecord(e0, 0);
-                    if (kind == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(wgs), dim3(256), 0, 0, in, out, iters);
-                    else hipLaunchKernelGGL(mfma_loop<1>, dim3(wgs), dim3(256), 0, 0, in, out, iters);
+                    if (kind == 0) hipLaunchKernelGGL(mfma_loop<0>, dim3(wgs), dim3(256), 0, 0, in, out, iters, prio);
+                    else hipLaunchKernelGGL(mfma_loop<1>, dim3(wgs), dim3(256), 0, 0, in, out, iters, prio);
                     hipEventRecord(e1, 0); hipEventSynchronize(e1);
                 }
                 float ms; hipEventElapsedTime(&ms, e0, e1);
                 const double flops = (double)wgs * 4 * iters * (kind == 0 ? 32.0 * 4096 : 64.0 * 2048);
-                printf("%s operands, %s, %d wave(s)/SIMD: %.1f ms -> %.1f TFLOP/s\n", rnd ? "random" : "zero  ",
-                       kind == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", wgs / 256, ms, flops / ms / 1e9);
+                printf("%s operands, %s, prio mode %d, %d wave(s)/SIMD: %.1f ms -> %.1f TFLOP/s\n", rnd ? "random" : "zero  ",
+                       kind == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", prio, wgs / 256, ms, flops / ms / 1e9);
             }
     }
     return 0;

@@ -332,6 +332,192 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 }
 
 // =============================================================================================
+// LDS-DMA variant of the tile kernel (k_len % 32 == 0): the operand slabs go global -> LDS directly
+// (global_load_lds_dwordx4, 1 KB = 8 rows x 128 B per wave-instruction), no staging registers and no
+// ds_write.  The LDS image is lane-linear, so rows are unpadded (32 floats) and bank conflicts are
+// avoided by an XOR swizzle of the 16-byte chunk index with (row >> 1) & 7 — applied to the per-lane
+// SOURCE address of the DMA and to the fragment reads alike (cdna_hip_programming.md rule 21).
+// =============================================================================================
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];  // [buf][A|W][row][32] (+ slack for the epilogue)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+
+    // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
+    // a contiguous run of tiles; tiles are numbered n-fastest so a run shares its A row panel in L2.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+
+    // DMA staging: wave w issues pieces q = 8w .. 8w+7 of a slab (16 pieces of A, then 16 of W); lane L of a
+    // piece fills LDS slot L = (row in the 8-row group, chunk position p): it must fetch chunk p ^ swz(row).
+    const float* pq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = w * 8 + i, op = q >> 4, row = (q & 15) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        pq[i] = (op == 0 ? a.A + (int64_t)min(m0 + row, a.M - 1) * a.lda
+                         : a.W + (int64_t)min(n0 + row, a.N - 1) * a.K) + blockIdx.y * a.k_len + 4 * c;
+    }
+    auto dma1 = [&](int i, int buf, int k0) {
+        const int q = w * 8 + i;
+        __builtin_amdgcn_global_load_lds(pq[i] + k0, &lds[buf][q >> 4][(q & 15) * 8 * 32], 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nk = a.k_len / TK;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
+
+    // Epilogue layout: the accumulators are transposed through LDS so that a lane owns 4 consecutive
+    // columns of one row: thread tid handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.
+    // A wave then stores (and reads the residual as) two whole 512-B rows per instruction, a quarter
+    // of the memory instructions of the accumulator layout (lane = column, 4 B per lane).  That count
+    // is what matters: the CU's memory pipeline is shared with the other workgroup's operand loads,
+    // and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the residual loads
+    // (stores / residual loads switched off in a diagnostic build).  Residual and bias are fetched NOW, so
+    // the epilogue waits for nothing.
+    const int ec4 = tid & 31, erow = tid >> 5;
+    const int en = n0 + 4 * ec4;
+    const bool ecol_full = en + 3 < a.N;
+    f32x4 resv[16];
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (EPI == EPI_PLAIN) {
+        if (a.bias && ecol_full) bias4 = ld4(a.bias + en);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + erow + 8 * it;
+            resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __syncthreads();
+    // Main loop.  Each K step is four groups of 16 MFMAs on one register set of fragments; the other set is
+    // read from LDS four MFMAs into the group, so its latency sits under the remaining twelve.  The next
+    // slab's DMA is requested during groups 0 and 1 into the other buffer (free since the previous step's
+    // barrier); the step's barrier sits inside group 3, after this wave's last read of the current buffer,
+    // and is followed by the first fragment read of the next buffer.
+    const int swz = (r >> 1) & 7;
+    f32x4 fa[2][2], fw[2][2];
+    auto fload = [&](int set, int buf, int t) {
+        const int off = (((2 * t + h) ^ swz) << 2);
+        const float* As = &lds[buf][0][(wm * 64 + r) * 32 + off];
+        const float* Ws = &lds[buf][1][(wn * 64 + r) * 32 + off];
+        fa[set][0] = ld4(As);
+        fa[set][1] = ld4(As + 32 * 32);
+        fw[set][0] = ld4(Ws);
+        fw[set][1] = ld4(Ws + 32 * 32);
+    };
+    auto mfma4 = [&](int set, int j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][j], fw[set][0][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][j], fw[set][1][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][0][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][1][j], acc[1][1], 0, 0, 0);
+    };
+    fload(0, 0, 0);
+    auto kstep = [&](int kt, auto pf) {
+        constexpr bool PF = decltype(pf)::value;
+        const int cur = kt & 1;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mfma4(t & 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PF) {
+                if (t < 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, (kt + 1) * TK);
+                }
+            }
+            if (t < 3) {
+                fload((t + 1) & 1, cur, t + 1);
+            } else if constexpr (PF) {
+                __syncthreads();
+                fload(0, cur ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(t & 1, 1);
+            mfma4(t & 1, 2);
+            mfma4(t & 1, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
+    kstep(nk - 1, std::false_type{});
+    __syncthreads();
+
+    // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
+    // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
+    constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
+    float* ct = &lds[0][0][0];                        // 128 x 132 floats = 66 KB of the 72 KB
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                ct[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
+    __syncthreads();
+    if (en >= a.N) return;
+    // column part of the destination, once per thread
+    float* qdst = nullptr;
+    bool qcache = false;
+    if (EPI == EPI_QKV) {
+        const int which = en >= 2 * a.d_model ? 2 : (en >= a.d_model ? 1 : 0);
+        const int c = en - which * a.d_model;
+        if (which == 0) {
+            qdst = a.out + c;
+        } else {
+            qdst = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
+            qcache = true;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = erow + 8 * it, m = m0 + row;
+        if (m >= a.M) break;
+        f32x4 v = ld4(ct + row * LDC + 4 * ec4);
+        if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y → slab [split][M][ldo]
+            float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
+            if (ecol_full) st4(dst, v);
+            else
+                for (int j = 0; j < 4 && en + j < a.N; ++j) dst[j] = v[j];
+        } else if (EPI == EPI_QKV) {                   // N = 3 d_model, a multiple of 4: groups are whole
+            if (qcache) {
+                const int b = m / a.T, t = m - b * a.T;
+                const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
+                st4(qdst + ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM, v);
+            } else {
+                st4(qdst + (int64_t)m * a.ldo, v);
+            }
+        } else if (ecol_full) {
+            v += bias4;
+            if (a.act == VH_ACT_GELU_ERF) {
+                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            }
+            st4(a.out + (int64_t)m * a.ldo + en, v + resv[it]);
+        } else {                                       // ragged last column group (e.g. N = 1025 logits)
+            for (int j = 0; j < 4 && en + j < a.N; ++j) {
+                float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
+                if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
+                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
+                a.out[(int64_t)m * a.ldo + en + j] = sv;
+            }
+        }
+    }
+}
+
+// =============================================================================================
 // Skinny kernel: M <= 16*MT rows.  Block = NW waves, owns 16 output columns n0..n0+15 over all K.
 // wave w owns a contiguous run of k-steps of 16; lane: i = l&15 (W row / activation row), g = l>>4.
 //
@@ -880,7 +1066,17 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
 #undef SK
     } else {
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
-        hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
+        // The LDS-DMA variant needs whole 32-wide K slabs.  One launch shape goes to the staged kernel by
+        // measurement: when the last round of workgroups is exactly one per CU (tiles % 512 in (192, 256], one and a
+        // half rounds in all) the dispatcher pairs the DMA kernel's second-round workgroups on half the CUs (138 us
+        // vs 115 us at 768 tiles, tools/bench_kernels.py tilesweep); the staged kernel's finish order spreads them.
+        const int tune_dma = vh_tuning(VH_TUNE_TILE_DMA);
+        const int tiles = tm * tn, tail = tiles % 512;
+        const bool half_round = tiles > 512 && tiles < 1024 && tail > 192 && tail <= 256;
+        if (a.k_len % TK == 0 && tune_dma != 1 && (tune_dma == 2 || !half_round))
+            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
+        else
+            hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
     }
     VH_CHECK_LAUNCH(name);
     return VH_OK;
@@ -1085,7 +1281,10 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     hipStream_t s = (hipStream_t)stream;
     if (M > 64) {                                 // tile kernel, K slices in gridDim.y
         const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
-        hipLaunchKernelGGL((gemm_tile_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
+        if (part.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1)
+            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
+        else
+            hipLaunchKernelGGL((gemm_tile_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
         const int items_t = M * (lds_ / 4);
         const int rbt = 256;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items_t + rbt - 1) / rbt), dim3(rbt), 0, s,
