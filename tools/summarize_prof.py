@@ -45,12 +45,13 @@ def main(src, dst, title=''):
     counters = glob.glob(f'{src}/**/*counter_collection.csv', recursive=True)
     if counters:
         agg = defaultdict(list)
-        for r in csv.DictReader(open(counters[0])):
-            agg[(short(r['Kernel_Name']), r['Grid_Size'] if 'Grid_Size' in r else r.get('Grid_Size_X', ''),
-                 r['Counter_Name'])].append(float(r['Counter_Value']))
+        for path in counters:                                # one file per --pmc pass
+            for r in csv.DictReader(open(path)):
+                agg[(short(r['Kernel_Name']), r['Grid_Size'] if 'Grid_Size' in r else r.get('Grid_Size_X', ''),
+                     r['Counter_Name'])].append(float(r['Counter_Value']))
         out += ['## PMC counters per dispatch (mean over dispatches)', '',
                 '| kernel | grid | counter | dispatches | mean | min | max |', '|---|---|---|---|---|---|---|']
-        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:30]:
+        for k, v in sorted(agg.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2]))[:120]:
             out.append(f'| {k[0]} | {k[1]} | {k[2]} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |')
         out.append('')
     open(dst, 'w').write('\n'.join(out) + '\n')

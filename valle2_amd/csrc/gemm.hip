@@ -331,6 +331,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     }
 }
 
+#ifdef VH_TILE_PROBE
+// Timeline instrumentation (tools/probe_tile_timeline.hip only): every wave stamps clock64() at the start of
+// each K step, before and after the step's barrier, into the 2 KB of slack behind its LDS region; the stamps
+// and the hardware id of the workgroup go to global memory before the epilogue.
+__device__ long long vh_tile_probe[8192 * 4 * 200];
+__device__ unsigned vh_tile_hwid[8192 * 2];
+#define VH_TP(ev, step) do { if (lane == 0) tp[(ev) * 64 + (step)] = clock64(); } while (0)
+#else
+#define VH_TP(ev, step) do { } while (0)
+#endif
+
 // =============================================================================================
 // LDS-DMA variant of the tile kernel (k_len % 32 == 0): the operand slabs go global -> LDS directly
 // (global_load_lds_dwordx4, 1 KB = 8 rows x 128 B per wave-instruction), no staging registers and no
@@ -341,7 +352,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];  // [buf][A|W][row][32] (+ slack for the epilogue)
+    // Outside the main loop the wave runs at raised priority: its scalar/vector bookkeeping competes for issue slots
+    // with the MFMA stream of the CU's other workgroup, and a short prologue / epilogue is worth more than the few
+    // MFMA slots it displaces.
+    __builtin_amdgcn_s_setprio(3);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#ifdef VH_TILE_PROBE
+    const long long t_entry = clock64();
+#endif
     const int r = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
 
@@ -355,17 +373,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 
     // DMA staging: wave w issues pieces q = 8w .. 8w+7 of a slab (16 pieces of A, then 16 of W); lane L of a
     // piece fills LDS slot L = (row in the 8-row group, chunk position p): it must fetch chunk p ^ swz(row).
-    const float* pq[8];
+    // The address is split the way the instruction wants it: a wave-uniform 64-bit base per operand (advanced by
+    // scalar adds, K step by K step) plus one 32-bit per-lane byte offset per piece, computed once — the main
+    // loop then holds no vector address arithmetic at all, which matters because ordinary VALU instructions and
+    // MFMAs share an issue port (every one of them is a bubble in the MFMA stream of a CU's other workgroup too).
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const char* baseA = (const char*)(a.A + (int64_t)m0 * a.lda + blockIdx.y * a.k_len);
+    const char* baseW = (const char*)(a.W + (int64_t)n0 * a.K + blockIdx.y * a.k_len);
+    uint32_t voff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int q = w * 8 + i, op = q >> 4, row = (q & 15) * 8 + (lane >> 3);
+        const int q = ws * 8 + i, row = (q & 15) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
-        pq[i] = (op == 0 ? a.A + (int64_t)min(m0 + row, a.M - 1) * a.lda
-                         : a.W + (int64_t)min(n0 + row, a.N - 1) * a.K) + blockIdx.y * a.k_len + 4 * c;
+        voff[i] = q < 16 ? (uint32_t)(min(row, a.M - 1 - m0) * a.lda + 4 * c) * 4u
+                         : (uint32_t)(min(row, a.N - 1 - n0) * a.K + 4 * c) * 4u;
     }
     auto dma1 = [&](int i, int buf, int k0) {
-        const int q = w * 8 + i;
-        __builtin_amdgcn_global_load_lds(pq[i] + k0, &lds[buf][q >> 4][(q & 15) * 8 * 32], 16, 0, 0);
+        const int q = ws * 8 + i;
+        const char* base = (q < 16 ? baseA : baseW) + (int64_t)k0 * 4;
+        const uint32_t dst = (uint32_t)(uintptr_t)&lds[buf][q >> 4][(q & 15) * 8 * 32];   // low half of the flat address = LDS offset
+        // scalar-base form by hand: the compiler's selection of the LDS-DMA intrinsic only produces 64-bit vector addresses
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(voff[i]), "s"(base) : "memory", "m0");
     };
 
     f32x16 acc[2][2];
@@ -402,22 +431,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
                                                        : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): slab 0 (and the residual prefetch) landed
     __syncthreads();
     // Main loop.  Each K step is four groups of 16 MFMAs on one register set of fragments; the other set is
     // read from LDS four MFMAs into the group, so its latency sits under the remaining twelve.  The next
     // slab's DMA is requested during groups 0 and 1 into the other buffer (free since the previous step's
     // barrier); the step's barrier sits inside group 3, after this wave's last read of the current buffer,
     // and is followed by the first fragment read of the next buffer.
+#ifdef VH_TILE_PROBE
+    long long* tp = (long long*)&lds[w >> 1][w & 1][4096];   // 256 stamps per wave
+    if (lane == 0) { tp[192] = clock64(); tp[193] = wall_clock64(); }
+#endif
     const int swz = (r >> 1) & 7;
     f32x4 fa[2][2], fw[2][2];
-    auto fload = [&](int set, int buf, int t) {
-        const int off = (((2 * t + h) ^ swz) << 2);
-        const float* As = &lds[buf][0][(wm * 64 + r) * 32 + off];
-        const float* Ws = &lds[buf][1][(wn * 64 + r) * 32 + off];
-        fa[set][0] = ld4(As);
-        fa[set][1] = ld4(As + 32 * 32);
-        fw[set][0] = ld4(Ws);
-        fw[set][1] = ld4(Ws + 32 * 32);
+    const float* fA[4];                                   // per-lane fragment addresses in buffer 0, one per k-quad pair t
+    const float* fW[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        fA[t] = &lds[0][0][(wm * 64 + r) * 32 + (((2 * t + h) ^ swz) << 2)];
+        fW[t] = &lds[0][1][(wn * 64 + r) * 32 + (((2 * t + h) ^ swz) << 2)];
+    }
+    auto fload = [&](int set, int buf, int t) {           // buf is a compile-time constant at every call site
+        fa[set][0] = ld4(fA[t] + buf * 2 * TM * LDS_LD);
+        fa[set][1] = ld4(fA[t] + buf * 2 * TM * LDS_LD + 32 * 32);
+        fw[set][0] = ld4(fW[t] + buf * 2 * TM * LDS_LD);
+        fw[set][1] = ld4(fW[t] + buf * 2 * TM * LDS_LD + 32 * 32);
     };
     auto mfma4 = [&](int set, int j) {
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][j], fw[set][0][j], acc[0][0], 0, 0, 0);
@@ -425,10 +463,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][0][j], acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][1][j], acc[1][1], 0, 0, 0);
     };
+    __builtin_amdgcn_s_setprio(0);
     fload(0, 0, 0);
-    auto kstep = [&](int kt, auto pf) {
+    auto kstep = [&](int kt, auto cur_c, auto pf) {       // cur_c: buffer holding slab kt (compile-time)
         constexpr bool PF = decltype(pf)::value;
-        const int cur = kt & 1;
+        constexpr int cur = decltype(cur_c)::value;
+        VH_TP(0, kt);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             mfma4(t & 1, 0);
@@ -442,7 +482,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
             if (t < 3) {
                 fload((t + 1) & 1, cur, t + 1);
             } else if constexpr (PF) {
+                VH_TP(1, kt);
+                __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's DMA pieces (issued from asm) have landed
                 __syncthreads();
+                VH_TP(2, kt);
                 fload(0, cur ^ 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -452,10 +495,36 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
-    kstep(nk - 1, std::false_type{});
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    int kt = 0;
+    for (; kt + 2 < nk; kt += 2) {
+        kstep(kt, B0{}, std::true_type{});
+        kstep(kt + 1, B1{}, std::true_type{});
+    }
+    if (kt + 2 == nk) {
+        kstep(kt, B0{}, std::true_type{});
+        kstep(kt + 1, B1{}, std::false_type{});
+    } else {
+        kstep(kt, B0{}, std::false_type{});
+    }
     __syncthreads();
+#ifdef VH_TILE_PROBE
+    if (lane == 0) { tp[194] = clock64(); tp[195] = wall_clock64(); tp[196] = t_entry; }
+    if (blockIdx.x < 8192) {
+        for (int i = lane; i < 100; i += 64)                                  // 200 stamps = 100 x 16 B
+            *(f32x4*)((float*)&vh_tile_probe[(blockIdx.x * 4 + w) * 200] + 4 * i) = ld4((const float*)tp + 4 * i);
+    }
+    if (tid == 0 && blockIdx.x < 8192) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        vh_tile_hwid[blockIdx.x * 2] = hw; vh_tile_hwid[blockIdx.x * 2 + 1] = xcc;
+    }
+    __syncthreads();
+#endif
 
+    __builtin_amdgcn_s_setprio(3);
     // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
     // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
     constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
@@ -515,6 +584,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
             }
         }
     }
+#ifdef VH_TILE_PROBE
+    if (lane == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + w) * 200 + 197] = clock64();
+#endif
 }
 
 // =============================================================================================
