@@ -56,6 +56,23 @@ def test_gelu_forward_backward():
     close(xd.grad, x.grad)
 
 
+def test_gelu_dense_grid_matches_exact_erf():
+    """The device erf is a two-branch polynomial / exp2 form (vh_common.h vh_erf), not libm's: check GELU against
+    the float64 erf form on a dense grid, including the branch point |x|/sqrt(2) = 1 and the saturated tails.
+    Tolerance: 1.2e-7 on erf -> 0.6e-7 * |x| on GELU, plus two fp32 roundings of the result."""
+    from valle2_amd import autograd as A
+    x = torch.linspace(-9.0, 9.0, 1 << 20)
+    x = torch.cat([x, torch.tensor([0.0, -0.0, 2 ** 0.5, -2 ** 0.5, 1e-20, -1e-20, 30.0, -30.0])])
+    x = torch.cat([x, torch.zeros((-len(x)) % 64)]).view(-1, 64)
+    y = A.GeluFn.apply(x.to(DEV)).cpu().double()
+    xd = x.double()
+    ref = 0.5 * xd * (1.0 + torch.erf(xd * 0.5 ** 0.5))
+    err = (y - ref).abs()
+    bound = 1.0e-7 * xd.abs() + 2.0 ** -23 * ref.abs() + 1e-30
+    assert bool((err <= bound).all()), float((err / bound).max())
+    assert float(A.GeluFn.apply(torch.full((1, 64), -30.0, device=DEV)).abs().max()) == 0.0
+
+
 def test_cross_entropy_forward_backward():
     from valle2_amd import autograd as A
     logits = (2 * torch.randn(45, 1025, generator=g(9))).requires_grad_()

@@ -195,6 +195,13 @@ def bench_tile():
             line += f'  library: {us:7.1f} us {2 * M * N * Kk / us / 1e6:6.1f} TF'
             print(line, flush=True)
     M = B * T
+    a = torch.randn(M, 512, device=DEV)
+    w = 0.02 * torch.randn(2048, 512, device=DEV)
+    bias = torch.randn(2048, device=DEV)
+    o = torch.empty(M, 2048, device=DEV)
+    for act in (0, 1):
+        us = statistics.median(timeit(lambda: K.linear(a, w, bias, None, out=o, act=act), iters=10, warm=2) for _ in range(3))
+        print(f'tile ffn1 bias{" + GELU" if act else ""}: {us:7.1f} us {2 * M * 2048 * 512 / us / 1e6:6.1f} TF', flush=True)
     x = torch.randn(M, 512, device=DEV)
     w = 0.02 * torch.randn(1536, 512, device=DEV)
     q = torch.zeros(M, 512, device=DEV)

@@ -142,6 +142,167 @@ __device__ __forceinline__ void store1(const GemmArgs& a, int m, int n, float s)
 #define TK 32
 #define LDS_LD 36
 
+// =============================================================================================
+// Epilogue of the tile kernels (shared by the register-staged and the LDS-DMA kernel).
+//
+// The accumulators are transposed through LDS so that a lane owns 4 consecutive columns of one row: thread tid
+// handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.  A wave then stores (and reads the residual as)
+// two whole 512-B rows per instruction, a quarter of the memory instructions of the accumulator layout (lane =
+// column, 4 B per lane).  That count is what matters: the CU's memory pipeline is shared with the other
+// workgroup's operand loads, and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the
+// residual loads.  Residual and bias are fetched before the main loop, so the epilogue waits for nothing.
+//
+// Every vector instruction here also competes with the MFMA stream of the CU's other workgroup for the same
+// issue port, so the interior-tile path is written to need almost none: addresses are a wave-uniform base
+// (scalar adds per row group) plus one per-lane 32-bit offset computed once, there are no per-row bounds checks,
+// and the K/V scatter walks (batch row, position) incrementally instead of dividing by T per row.
+// =============================================================================================
+struct TileEpi {
+    f32x4 resv[16];
+    f32x4 bias4;
+};
+
+template <int EPI>
+__device__ __forceinline__ void tile_prefetch(const GemmArgs& a, int m0, int n0, int tid, TileEpi& e) {
+    const int ec4 = tid & 31, erow = tid >> 5;
+    const int en = n0 + 4 * ec4;
+    e.bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_PLAIN) return;
+    const bool interior = m0 + TM <= a.M && n0 + TN <= a.N;         // wave-uniform
+    if (interior) {
+        if (a.bias) e.bias4 = ld4(a.bias + en);
+        if (a.res) {
+            const char* base = (const char*)(a.res + (int64_t)m0 * a.ldr + n0);
+            const uint32_t voff = (uint32_t)(erow * a.ldr + 4 * ec4) * 4u;
+#pragma unroll
+            for (int it = 0; it < 16; ++it)
+                e.resv[it] = ld4((const float*)(base + (int64_t)it * 8 * a.ldr * 4 + voff));
+        } else {
+#pragma unroll
+            for (int it = 0; it < 16; ++it) e.resv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else {
+        const bool ecol_full = en + 3 < a.N;
+        if (a.bias && ecol_full) e.bias4 = ld4(a.bias + en);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int m = m0 + erow + 8 * it;
+            e.resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
+                                                         : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// ct: 128 x 132 floats of LDS, free (the main loop ended on a barrier).  D reg e of tile (mt,nt) holds row
+// (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
+template <int EPI>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&acc)[2][2], float* ct, int m0, int n0,
+                                              int tid, const TileEpi& e) {
+    constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
+    const int lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5, wm = w >> 1, wn = w & 1;
+    float* cw = ct + (wm * 64 + 4 * h) * LDC + wn * 64 + r;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int x = 0; x < 16; ++x)
+                cw[(mt * 32 + (x & 3) + 8 * (x >> 2)) * LDC + nt * 32] = acc[mt][nt][x];
+    __syncthreads();
+    const int ec4 = tid & 31, erow = tid >> 5;
+    const int en = n0 + 4 * ec4;
+    const float* cr = ct + erow * LDC + 4 * ec4;
+    const bool interior = m0 + TM <= a.M && n0 + TN <= a.N;         // wave-uniform
+    // QKV: a tile lies inside one of q / k / v when d_model is a multiple of the tile width
+    const bool qkv_tile = EPI == EPI_QKV && a.d_model % TN == 0;
+    if (interior && (EPI == EPI_PLAIN || EPI == EPI_PARTIAL || (qkv_tile && n0 < a.d_model))) {
+        // rows of `out`: base + it * (8 rows) + per-lane offset
+        const int64_t row0 = EPI == EPI_PARTIAL ? (int64_t)blockIdx.y * a.M + m0 : m0;
+        char* base = (char*)(a.out + row0 * a.ldo + n0);
+        const uint32_t voff = (uint32_t)(erow * a.ldo + 4 * ec4) * 4u;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            f32x4 v = ld4(cr + it * 8 * LDC);
+            if (EPI == EPI_PLAIN) {
+                v += e.bias4;
+                if (a.act == VH_ACT_GELU_ERF) {
+                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                }
+                v += e.resv[it];
+            }
+            st4((float*)(base + (int64_t)it * 8 * a.ldo * 4 + voff), v);
+        }
+        return;
+    }
+    if (interior && qkv_tile) {                        // a K or V tile: scatter rows into cache[b][head][pos][64]
+        const int which = n0 >= 2 * a.d_model ? 2 : 1;
+        const int c = en - which * a.d_model;
+        float* cache = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
+        const int m = m0 + erow;
+        int b = m / a.T, t = m - b * a.T;
+        int cl = a.cache_len ? a.cache_len[b] : 0;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const f32x4 v = ld4(cr + it * 8 * LDC);
+            st4(cache + ((int64_t)b * a.n_heads * a.S_max + cl + t) * VH_HEAD_DIM, v);
+            t += 8;
+            if (t >= a.T) {                           // next batch row (several at once only when T < 8)
+                do { t -= a.T; ++b; } while (t >= a.T);
+                if (it < 15 && a.cache_len) cl = a.cache_len[b];
+            }
+        }
+        return;
+    }
+    // ---- edge tiles (ragged M or N) and QKV with d_model not a multiple of 128: guarded general form
+    if (en >= a.N) return;
+    const bool ecol_full = en + 3 < a.N;
+    float* qdst = nullptr;
+    bool qcache = false;
+    if (EPI == EPI_QKV) {
+        const int which = en >= 2 * a.d_model ? 2 : (en >= a.d_model ? 1 : 0);
+        const int c = en - which * a.d_model;
+        if (which == 0) {
+            qdst = a.out + c;
+        } else {
+            qdst = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
+            qcache = true;
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int row = erow + 8 * it, m = m0 + row;
+        if (m >= a.M) break;
+        f32x4 v = ld4(cr + it * 8 * LDC);
+        if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y -> slab [split][M][ldo]
+            float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
+            if (ecol_full) st4(dst, v);
+            else
+                for (int j = 0; j < 4 && en + j < a.N; ++j) dst[j] = v[j];
+        } else if (EPI == EPI_QKV) {                   // N = 3 d_model, a multiple of 4: groups are whole
+            if (qcache) {
+                const int b = m / a.T, t = m - b * a.T;
+                const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
+                st4(qdst + ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM, v);
+            } else {
+                st4(qdst + (int64_t)m * a.ldo, v);
+            }
+        } else if (ecol_full) {
+            v += e.bias4;
+            if (a.act == VH_ACT_GELU_ERF) {
+                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            }
+            st4(a.out + (int64_t)m * a.ldo + en, v + e.resv[it]);
+        } else {                                       // ragged last column group (e.g. N = 1025 logits)
+            for (int j = 0; j < 4 && en + j < a.N; ++j) {
+                float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
+                if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
+                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
+                a.out[(int64_t)m * a.ldo + en + j] = sv;
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];  // [buf][A|W][row][k]
@@ -205,28 +366,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     gload(0);
     lstore(0, 0);
 
-    // Epilogue layout: the accumulators are transposed through LDS so that a lane owns 4 consecutive
-    // columns of one row: thread tid handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.
-    // A wave then stores (and reads the residual as) two whole 512-B rows per instruction, a quarter
-    // of the memory instructions of the accumulator layout (lane = column, 4 B per lane).  That count
-    // is what matters: the CU's memory pipeline is shared with the other workgroup's operand loads,
-    // and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the residual loads
-    // (stores / residual loads switched off in a diagnostic build).  Residual and bias are fetched NOW, so
-    // the epilogue waits for nothing.
-    const int ec4 = tid & 31, erow = tid >> 5;
-    const int en = n0 + 4 * ec4;
-    const bool ecol_full = en + 3 < a.N;
-    f32x4 resv[16];
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_PLAIN) {
-        if (a.bias && ecol_full) bias4 = ld4(a.bias + en);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = m0 + erow + 8 * it;
-            resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
-                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
+    TileEpi epi;                                          // residual and bias, fetched now (see tile_epilogue)
+    tile_prefetch<EPI>(a, m0, n0, tid, epi);
     __syncthreads();
     // Main loop, software-pipelined by hand: the operand fragments of k-sub-step t+1 are read from LDS
     // while the 16 MFMAs of sub-step t run (two register sets), and the first fragments of the next
@@ -270,65 +411,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
     kstep(nk - 1, std::false_type{});
 
-    // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
-    // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
-    constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
-    float* ct = &lds[0][0][0];                        // 128 x 132 floats = 66 KB of the 72 KB
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                ct[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
-    __syncthreads();
-    if (en >= a.N) return;
-    // column part of the destination, once per thread
-    float* qdst = nullptr;
-    bool qcache = false;
-    if (EPI == EPI_QKV) {
-        const int which = en >= 2 * a.d_model ? 2 : (en >= a.d_model ? 1 : 0);
-        const int c = en - which * a.d_model;
-        if (which == 0) {
-            qdst = a.out + c;
-        } else {
-            qdst = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
-            qcache = true;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int row = erow + 8 * it, m = m0 + row;
-        if (m >= a.M) break;
-        f32x4 v = ld4(ct + row * LDC + 4 * ec4);
-        if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y → slab [split][M][ldo]
-            float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
-            if (ecol_full) st4(dst, v);
-            else
-                for (int j = 0; j < 4 && en + j < a.N; ++j) dst[j] = v[j];
-        } else if (EPI == EPI_QKV) {                   // N = 3 d_model, a multiple of 4: groups are whole
-            if (qcache) {
-                const int b = m / a.T, t = m - b * a.T;
-                const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
-                st4(qdst + ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM, v);
-            } else {
-                st4(qdst + (int64_t)m * a.ldo, v);
-            }
-        } else if (ecol_full) {
-            v += bias4;
-            if (a.act == VH_ACT_GELU_ERF) {
-                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-            }
-            st4(a.out + (int64_t)m * a.ldo + en, v + resv[it]);
-        } else {                                       // ragged last column group (e.g. N = 1025 logits)
-            for (int j = 0; j < 4 && en + j < a.N; ++j) {
-                float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
-                if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
-                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
-                a.out[(int64_t)m * a.ldo + en + j] = sv;
-            }
-        }
-    }
+    tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
 }
 
 #ifdef VH_TILE_PROBE
@@ -409,28 +492,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
 
-    // Epilogue layout: the accumulators are transposed through LDS so that a lane owns 4 consecutive
-    // columns of one row: thread tid handles column group c4 = tid & 31 of rows (tid >> 5) + 8*it.
-    // A wave then stores (and reads the residual as) two whole 512-B rows per instruction, a quarter
-    // of the memory instructions of the accumulator layout (lane = column, 4 B per lane).  That count
-    // is what matters: the CU's memory pipeline is shared with the other workgroup's operand loads,
-    // and with dword stores the K = 512 shapes lost 16 % to the stores and 11 % to the residual loads
-    // (stores / residual loads switched off in a diagnostic build).  Residual and bias are fetched NOW, so
-    // the epilogue waits for nothing.
-    const int ec4 = tid & 31, erow = tid >> 5;
-    const int en = n0 + 4 * ec4;
-    const bool ecol_full = en + 3 < a.N;
-    f32x4 resv[16];
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (EPI == EPI_PLAIN) {
-        if (a.bias && ecol_full) bias4 = ld4(a.bias + en);
-#pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int m = m0 + erow + 8 * it;
-            resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
-                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    }
+    TileEpi epi;                                          // residual and bias, fetched now (see tile_epilogue)
+    tile_prefetch<EPI>(a, m0, n0, tid, epi);
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): slab 0 (and the residual prefetch) landed
     __syncthreads();
     // Main loop.  Each K step is four groups of 16 MFMAs on one register set of fragments; the other set is
@@ -525,67 +588,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 #endif
 
     __builtin_amdgcn_s_setprio(3);
-    // ---- epilogue.  The loop ended on a barrier: LDS is free.  D reg e of tile (mt,nt) holds row
-    // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
-    constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
-    float* ct = &lds[0][0][0];                        // 128 x 132 floats = 66 KB of the 72 KB
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                ct[(wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * 64 + nt * 32 + r] = acc[mt][nt][e];
-    __syncthreads();
-    if (en >= a.N) return;
-    // column part of the destination, once per thread
-    float* qdst = nullptr;
-    bool qcache = false;
-    if (EPI == EPI_QKV) {
-        const int which = en >= 2 * a.d_model ? 2 : (en >= a.d_model ? 1 : 0);
-        const int c = en - which * a.d_model;
-        if (which == 0) {
-            qdst = a.out + c;
-        } else {
-            qdst = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
-            qcache = true;
-        }
-    }
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int row = erow + 8 * it, m = m0 + row;
-        if (m >= a.M) break;
-        f32x4 v = ld4(ct + row * LDC + 4 * ec4);
-        if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y → slab [split][M][ldo]
-            float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
-            if (ecol_full) st4(dst, v);
-            else
-                for (int j = 0; j < 4 && en + j < a.N; ++j) dst[j] = v[j];
-        } else if (EPI == EPI_QKV) {                   // N = 3 d_model, a multiple of 4: groups are whole
-            if (qcache) {
-                const int b = m / a.T, t = m - b * a.T;
-                const int pos = (a.cache_len ? a.cache_len[b] : 0) + t;
-                st4(qdst + ((int64_t)b * a.n_heads * a.S_max + pos) * VH_HEAD_DIM, v);
-            } else {
-                st4(qdst + (int64_t)m * a.ldo, v);
-            }
-        } else if (ecol_full) {
-            v += bias4;
-            if (a.act == VH_ACT_GELU_ERF) {
-                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
-            }
-            st4(a.out + (int64_t)m * a.ldo + en, v + resv[it]);
-        } else {                                       // ragged last column group (e.g. N = 1025 logits)
-            for (int j = 0; j < 4 && en + j < a.N; ++j) {
-                float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
-                if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
-                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
-                a.out[(int64_t)m * a.ldo + en + j] = sv;
-            }
-        }
-    }
+    tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
 #ifdef VH_TILE_PROBE
-    if (lane == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + w) * 200 + 197] = clock64();
+    if ((tid & 63) == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + (tid >> 6)) * 200 + 197] = clock64();
 #endif
 }
 

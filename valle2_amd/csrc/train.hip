@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float* __restrict__ pre
             const f32x4 g = ld4(dh + 4 * i);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float cdf = 0.5f * (1.0f + erff(x[j] * 0.70710678118654752440f));
+                const float cdf = 0.5f * (1.0f + vh_erf(x[j] * 0.70710678118654752440f));
                 const float pdf = 0.39894228040143267794f * expf(-0.5f * x[j] * x[j]);
                 r[j] = g[j] * (cdf + x[j] * pdf);
             }

@@ -83,9 +83,38 @@ __device__ __forceinline__ f32x4 ld4_stream(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// erf(x) to 1.2e-7 absolute (about one ulp of the result near 1) in ~20 vector instructions, a third of the
+// library erff: the GEMM epilogues evaluate it 64 times per lane and per tile, and every one of those instructions
+// is a bubble in the MFMA stream of the CU's other workgroup.  |x| < 1: x * P5(x^2).  Otherwise
+// 1 - 2^(R7(t) - log2(e) t^2) with t = min(|x|, 4) and R7 ~ log2(erfcx(t)) (erf(4) rounds to 1 in fp32).
+// Coefficients: Chebyshev fits of the two branches, rounded to fp32 (tests/test_kernels_gpu.py checks the
+// function against torch.erf on a dense grid).
+__device__ __forceinline__ float vh_erf(float x) {
+    const float s = x * x;
+    float p = -5.654105917e-04f;
+    p = fmaf(p, s, 4.923277535e-03f);
+    p = fmaf(p, s, -2.671638504e-02f);
+    p = fmaf(p, s, 1.128036454e-01f);
+    p = fmaf(p, s, -3.761234879e-01f);
+    p = fmaf(p, s, 1.128379107e+00f);
+    const float small = p * x;
+    const float t = fminf(fabsf(x), 4.0f);
+    float q = -1.920139221e-05f;
+    q = fmaf(q, t, 4.581596004e-04f);
+    q = fmaf(q, t, -4.958351608e-03f);
+    q = fmaf(q, t, 3.263662755e-02f);
+    q = fmaf(q, t, -1.490577757e-01f);
+    q = fmaf(q, t, 5.206782818e-01f);
+    q = fmaf(q, t, -1.624367833e+00f);
+    q = fmaf(q, t, -1.092074905e-03f);
+    q = fmaf(-1.4426950408889634f * t, t, q);
+    const float large = copysignf(1.0f - __builtin_amdgcn_exp2f(q), x);   // v_exp_f32; q >= -26, no denormals
+    return fabsf(x) < 1.0f ? small : large;
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // nn.GELU() default = exact erf form (valle/models/modules.py:216)
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + vh_erf(x * 0.70710678118654752440f));
 }
 
 // LayerNorm parameters that may be fused into an operand load
