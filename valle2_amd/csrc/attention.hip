@@ -76,12 +76,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
         const float m_new = fmaxf(m, cmax);  // finite: chunk c < nchunks holds >= 1 valid key
-        const float alpha = exp2f(m - m_new);
+        const float alpha = vh_exp2(m - m_new);
         o *= alpha;
         l *= alpha;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float p = exp2f(s[i] - m_new);
+            const float p = vh_exp2(s[i] - m_new);
             l += p;
             o += vf[i] * p;
         }
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
         float L = 0.f, O = 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const float wgt = s_m[k] == NEG_INF ? 0.f : exp2f(s_m[k] - M);
+            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
             L += s_l[k] * wgt;
             O += s_o[k][tid] * wgt;
         }
@@ -169,12 +169,12 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
         const float m_new = fmaxf(m, cmax);
-        const float alpha = exp2f(m - m_new);
+        const float alpha = vh_exp2(m - m_new);
         o *= alpha;
         l *= alpha;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float p = exp2f(s[i] - m_new);
+            const float p = vh_exp2(s[i] - m_new);
             l += p;
             o += vf[i] * p;
         }
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
         float L = 0.f, O = 0.f;
 #pragma unroll
         for (int k = 0; k < NW; ++k) {
-            const float wgt = s_m[k] == NEG_INF ? 0.f : exp2f(s_m[k] - M);
+            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
             L += s_l[k] * wgt;
             O += s_o[k][tid] * wgt;
         }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(
     float L = 0.f, O = 0.f;
     for (int s = 0; s < n_split; ++s) {
         const float ms = pr[s * PART_LD + HD];
-        const float wgt = ms == NEG_INF ? 0.f : exp2f(ms - M);
+        const float wgt = ms == NEG_INF ? 0.f : vh_exp2(ms - M);
         L += pr[s * PART_LD + HD + 1] * wgt;
         O += pr[s * PART_LD + tid] * wgt;
     }
@@ -340,13 +340,15 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
     const float* vb = a.vc + (int64_t)bh * a.S_max * HD;
     const int skey = tid >> 4, squad = (tid & 15) * 4;  // staging: 2 keys per thread per operand
     f32x4 rk[2], rv[2];
+    // Keys beyond Tk are clamped to the last written row (rows < Tk were all written by this forward's QKV GEMM):
+    // their scores are masked to -inf, so their (finite) values meet p = 0.  Address = wave-uniform head base +
+    // one 32-bit per-lane byte offset: no 64-bit vector arithmetic in the loop (VALU slots are MFMA slots).
     auto gload = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int key = k0 + skey + 16 * i;
-            const bool in = key < a.Tk;  // rows < Tk were all written by this forward's QKV GEMM
-            rk[i] = in ? ld4(kb + (int64_t)key * HD + squad) : f32x4{0.f, 0.f, 0.f, 0.f};
-            rv[i] = in ? ld4(vb + (int64_t)key * HD + squad) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const uint32_t off = (uint32_t)(min(k0 + skey + 16 * i, a.Tk - 1) * HD + squad) * 4u;
+            rk[i] = ld4((const float*)((const char*)kb + off));
+            rv[i] = ld4((const float*)((const char*)vb + off));
         }
     };
     auto lstore = [&](int buf) {
@@ -420,11 +422,11 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
             tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
             const float m_new = fmaxf(m, tmax);
             const float m_use = m_new == NEG_INF ? 0.f : m_new;  // fully masked so far: p = 0
-            const float alpha = exp2f(m - m_use);
+            const float alpha = vh_exp2(m - m_use);
             float psum = 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                S[e] = exp2f(S[e] - m_use);
+                S[e] = vh_exp2(S[e] - m_use);
                 psum += S[e];
             }
             l = l * alpha + psum;
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
             for (int e = 0; e < 16; ++e) {
                 const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const bool vis = qin && bwd_visible(a, b, qi, key, kvl, xl);
-                const float p = vis ? exp2f(S[e] - lse) : 0.f;
+                const float p = vis ? vh_exp2(S[e] - lse) : 0.f;
                 S[e] = p * (P[e] - dsum);                                                   // dSᵀ[key][q]
             }
 #pragma unroll
@@ -755,7 +757,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
                     const int e = 4 * g4 + j;
                     const int qi = q0t + 8 * g4 + 4 * h + j;
                     const bool vis = kin && qi < a.T && bwd_visible(a, b, qi, kj, kvl, xl);
-                    const float p = vis ? exp2f(S[e] - lse4[j]) : 0.f;
+                    const float p = vis ? vh_exp2(S[e] - lse4[j]) : 0.f;
                     S[e] = p;                                   // P[q][key]
                     P[e] = p * (P[e] - d4[j]);                  // dS[q][key]
                 }

@@ -83,6 +83,12 @@ __device__ __forceinline__ f32x4 ld4_stream(const float* p) {
 }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// 2^x as the bare v_exp_f32 (1 ulp; results below 2^-126 flush to zero, -inf -> 0): exp2f() wraps the same
+// instruction in a denormal-range fix-up (compare, select, add, ldexp — five instructions), which the softmax
+// kernels do not need: their arguments are score - running max <= 0 and a flushed tail weight is exactly what
+// the sum would round away.
+__device__ __forceinline__ float vh_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // erf(x) to 1.2e-7 absolute (about one ulp of the result near 1) in ~20 vector instructions, a third of the
 // library erff: the GEMM epilogues evaluate it 64 times per lane and per tile, and every one of those instructions
 // is a bubble in the MFMA stream of the CU's other workgroup.  |x| < 1: x * P5(x^2).  Otherwise
