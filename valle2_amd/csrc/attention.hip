@@ -391,13 +391,11 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
             // ---- Sᵀ[key][q] = sum_d K[key][d] Q[q][d]
             f32x16 S;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) S[e] = 0.f;
-#pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 kf = ld4(ks + r * KLD + 8 * t + 4 * h);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], S, 0, 0, 0);
+                for (int j = 0; j < 4; ++j)        // the first product starts from the constant-zero C operand
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], (t | j) ? S : f32x16{}, 0, 0, 0);
             }
             // ---- mask: reg e ↔ key k0 + (e&3) + 8(e>>2) + 4h ; lane ↔ query qi
             if (!all) {
@@ -431,8 +429,10 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
             }
             l = l * alpha + psum;
             m = m_new;
+            if (__any(alpha != 1.0f)) {                // no query of this wave raised its maximum: nothing to rescale
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { O0[e] *= alpha; O1[e] *= alpha; }
+                for (int e = 0; e < 16; ++e) { O0[e] *= alpha; O1[e] *= alpha; }
+            }
             // ---- Oᵀ[d][q] += sum_key V[key][d] P[key][q]; k-step e covers keys (e,h=0),(e,h=1)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
