@@ -99,6 +99,24 @@ def test_linear_qkv_scatter_large_m(K, tile_staging):
         assert float(kc[b, :, :p0].abs().sum()) == 0 and float(kc[b, :, p0 + T:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize('M,N,K_', [(384, 256, 64), (300, 260, 96), (1000, 512, 512)])
+def test_linear_tile_strided_operands(K, M, N, K_, tile_staging):
+    """A, the residual and the output as column slices of wider buffers (row strides != K, N), interior and edge
+    tiles: the tile kernels address rows as base + row * stride with 32-bit per-lane offsets."""
+    abig = torch.randn(M, K_ + 24, generator=g(310)).to(DEV)
+    a = abig[:, 8:8 + K_]                                   # 32-byte offset, stride K + 24
+    w = (0.05 * torch.randn(N, K_, generator=g(311))).to(DEV)
+    bias = torch.randn(N, generator=g(312)).to(DEV)
+    rbig = torch.randn(M, N + 12, generator=g(313)).to(DEV)
+    res = rbig[:, 4:4 + N]
+    obig = torch.full((M, N + 20), 7.0, device=DEV)
+    out = obig[:, 16:16 + N]
+    K.linear(a, w, bias, res, out=out, act=1)
+    ref = F.gelu(F.linear(a.cpu(), w.cpu(), bias.cpu())) + res.cpu()
+    close(out, ref, atol=5e-5)
+    assert float((obig[:, :16] - 7.0).abs().max()) == 0 and float((obig[:, 16 + N:] - 7.0).abs().max()) == 0
+
+
 @pytest.mark.parametrize('M,N,K_', [(257, 1536, 512), (1000, 100, 2048), (6144, 2048, 64), (130, 132, 96)])
 def test_linear_tile_staging_kernels_bit_identical(K, M, N, K_):
     """The register-staged and the LDS-DMA tile kernels accumulate K in the same order: same bits.  (6144 x 2048

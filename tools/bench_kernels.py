@@ -211,6 +211,43 @@ def bench_tile():
     print(f'tile qkv-scatter: {us:7.1f} us {2 * M * 1536 * 512 / us / 1e6:6.1f} TF', flush=True)
 
 
+def bench_gemm_big():
+    """Decode GEMMs of configs[4] (24L / 1024d / dff 4096, 8 rows): weight-streaming regime (50 MB per layer)."""
+    B, d, dff, L = 8, 1024, 4096, 24
+    x = torch.randn(B, d, device=DEV)
+    hid = torch.randn(B, dff, device=DEV)
+    g, b = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    wqkv = [0.02 * torch.randn(3 * d, d, device=DEV) for _ in range(L)]
+    wo = [0.02 * torch.randn(d, d, device=DEV) for _ in range(L)]
+    w1 = [0.02 * torch.randn(dff, d, device=DEV) for _ in range(L)]
+    w2 = [0.02 * torch.randn(d, dff, device=DEV) for _ in range(L)]
+    bo, b1 = torch.zeros(d, device=DEV), torch.zeros(dff, device=DEV)
+    kc = torch.zeros(B, 16, 64, 64, device=DEV)
+    vc = torch.zeros_like(kc)
+    q = torch.empty(B, d, device=DEV)
+    o1 = torch.empty(B, d, device=DEV)
+    o2 = torch.empty(B, dff, device=DEV)
+    cl = torch.zeros(B, device=DEV, dtype=torch.int32)
+    fq = [K.ln_fold(wqkv[l], g, b) for l in range(L)]
+    f1 = [K.ln_fold(w1[l], g, b, b1) for l in range(L)]
+    ws2 = torch.empty(max(1, _lib.lib().vh_linear_ws_bytes(B, d, dff) // 4), device=DEV)
+    wso = torch.empty(max(1, _lib.lib().vh_linear_ws_bytes(B, d, d) // 4), device=DEV)
+    i = [0]
+
+    def nxt():
+        i[0] += 1
+        return i[0] % L
+    cases = {
+        'qkv fold   (3072 x 1024)': (lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 16, cache_len=cl), 3 * d * d * 4),
+        'out-proj   (1024 x 1024)': (lambda: K.linear_ws(x, wo[nxt()], bo, o1, out=o1, workspace=wso), d * d * 4),
+        'ffn1 fold  (4096 x 1024)': (lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1), dff * d * 4),
+        'ffn2       (1024 x 4096)': (lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2), dff * d * 4),
+    }
+    for name, (fn, nbytes) in cases.items():
+        us = statistics.median(timeit(fn, iters=96, warm=24) for _ in range(5))
+        print(f'{name}: {us:7.2f} us  {nbytes / us / 1e3:7.1f} GB/s of weights', flush=True)
+
+
 def bench_tilesweep():
     """Staged vs LDS-DMA tile kernel over tile counts around multiples of the 512 resident workgroups."""
     for N, Kk in ((2048, 512), (512, 2048)):
@@ -232,6 +269,8 @@ if __name__ == '__main__':
     what = sys.argv[1:] or ['attn', 'gemm', 'rows']
     if 'tilesweep' in what:
         bench_tilesweep()
+    if 'gemmbig' in what:
+        bench_gemm_big()
     if 'tile' in what:
         bench_tile()
     if 'gemm' in what:
