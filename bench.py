@@ -199,34 +199,35 @@ def main():
 
     l_pl = 4 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.dim_feedforward   # matmul weights per layer
     if rank == 0 and not args.no_roofline:
-        # dominant kernel: decode attention (KV streaming).  HIP events on the launch stream around
+        # dominant kernel: decode attention (KV streaming).  HIP events on the launch stream for
         # every launch of an eager (non-graph) pass over the same 511 steps.
         log('roofline: event-timed eager pass')
         model.generate_batch(texts, firsts, profile_attn=True)
         torch.cuda.synchronize()
         st = model.last_generate_stats
         bytes_per_launch, mean_s = attn_algorithmic_bytes(rows, cfg.d_model, st['s0'], new)
-        # `achieved` is priced on the whole bracket (conservative: it includes event/dispatch overhead).
-        # An event pair with nothing between its records reads `floor` on this stream; bracket - floor
-        # under-estimates the launch (back-to-back event records serialise), so the kernel's own duration
-        # — what rocprofv3 reports, profiles/r1_bench_kernel_stats.md — lies between the two.
+        # Duration of a launch = elapsed time between the start and stop events attached to the kernel's own
+        # dispatch packet (hipExtLaunchKernelGGL on the launch stream): the kernel's begin/end timestamps, which is
+        # also what rocprofv3 --kernel-trace reports (profiles/r1_bench_kernel_stats.md).  Kept beside it for
+        # reference: a bracket of two marker events recorded around the launch (upper bound, it carries event +
+        # dispatch overhead) and the same bracket with nothing inside (its floor).
         raw_s, floor_s = st['attn_mean_ms'] * 1e-3, (st.get('attn_floor_ms') or 0.0) * 1e-3
-        dur_s = raw_s
+        kern_s = (st.get('attn_kernel_ms') or 0.0) * 1e-3
+        dur_s = kern_s if kern_s > 0 else raw_s
         achieved = bytes_per_launch / dur_s / 1e9
         result['roofline'] = {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_unit': 'bytes/launch',
             'kernel': 'attn_decode_kernel', 'launches': (new - 1) * cfg.num_layers,
-            'avg_launch_us': dur_s * 1e6, 'event_floor_us': floor_s * 1e6,
-            'avg_launch_us_minus_floor': (raw_s - floor_s) * 1e6,
-            'frac_minus_floor': bytes_per_launch / max(raw_s - floor_s, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            'avg_launch_us': dur_s * 1e6,
+            'timing': 'kernel start/stop events' if kern_s > 0 else 'marker-event bracket',
+            'marker_bracket_us': raw_s * 1e6, 'marker_floor_us': floor_s * 1e6,
             'algorithmic_bytes_per_launch': bytes_per_launch, 'mean_context': mean_s,
-            'note': 'duration = HIP-event bracket around each launch of an eager pass on the launch stream '
-                    '(upper bound of the kernel time: it includes event + dispatch overhead); event_floor_us = the '
-                    'same bracket with nothing inside; rocprofv3 kernel duration lies between bracket and '
-                    'bracket - floor; '
-                    'traffic = PMC FETCH_SIZE/WRITE_SIZE from separate rocprofv3 --pmc passes of this '
-                    'workload, committed under profiles/ (null when absent)'}
+            'note': 'duration = mean over every decode-attention launch of an eager pass of the elapsed time between '
+                    'the HIP start/stop events attached to that kernel dispatch on the launch stream; '
+                    'marker_bracket_us = two marker events recorded around the same launch (event + dispatch overhead '
+                    'included; not used), marker_floor_us = that bracket with nothing inside; traffic = PMC FETCH_SIZE/WRITE_SIZE from separate '
+                    'rocprofv3 --pmc passes of this workload, committed under profiles/ (null when absent)'}
         pmc = REPO / 'profiles' / 'attn_decode_traffic.json'
         if pmc.exists() and not args.small:
             t = json.loads(pmc.read_text())

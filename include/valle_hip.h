@@ -281,12 +281,13 @@ int vh_ar_decoder_step(vh_ar_decoder* dec, void* stream);
 int vh_ar_decoder_capture(vh_ar_decoder* dec, void* stream);
 /* replay the captured step n_steps times on `stream` */
 int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream);
-/* eager steps with hipEvents around every decode-attention launch; returns the mean event-to-event
- * time in milliseconds of those brackets via *mean_ms and, via *floor_ms (optional), the mean time
- * of the same bracket with nothing inside it (recorded once per step): the measurement floor of an
- * event pair on this stream.  Synchronises the stream; measurement only. */
+/* eager steps with hipEvents on every decode-attention launch.  *kernel_ms (optional): mean elapsed time between
+ * the start and stop events attached to the kernel's own dispatch (hipExtLaunchKernelGGL) — the kernel's duration
+ * as the profiler sees it.  *mean_ms: mean event-to-event time of marker events recorded before and after the
+ * launch (an upper bound: it carries event + dispatch overhead); *floor_ms (optional): the same marker bracket
+ * with nothing inside it, once per step.  All in milliseconds.  Synchronises the stream; measurement only. */
 int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream, float* mean_ms,
-                               float* floor_ms);
+                               float* floor_ms, float* kernel_ms);
 
 /* ---- training path: backward of the row ops (loss.backward() of valle/models/valle_ar.py:86) -----
  * The plain backward GEMMs (dX = dY.W, dW = dY^T.X and the five attention products) are library

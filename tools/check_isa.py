@@ -1,0 +1,71 @@
+"""Static checks on the compiled gfx950 code of the LDS-DMA tile GEMM (no GPU needed; hipcc cross-compiles).
+
+The kernel issues its DMA from inline assembly that writes M0, a reserved register the compiler does not track
+through a clobber list, and relies on its main loop holding no vector ALU instruction besides the MFMAs.  Both are
+properties of the generated code, so they are asserted on the generated code:
+  * every reference to m0 in gemm_tile_dma_kernel<*> is one of our `s_mov_b32 m0, ...`;
+  * the K loop (the inner loop with the MFMAs) contains no VALU instruction other than v_mfma_*, no scratch
+    access, and the expected DMA / LDS-read counts per two K steps.
+usage: python tools/check_isa.py   (exit code 0 = ok)
+"""
+import re
+import subprocess
+import sys
+import tempfile
+from pathlib import Path
+
+REPO = Path(__file__).resolve().parent.parent
+HIPCC = '/opt/rocm/bin/hipcc'
+
+
+def compile_asm():
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / 'gemm.s'
+        subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+                        f'-I{REPO / "include"}', str(REPO / 'valle2_amd/csrc/gemm.hip'), '-o', str(out)],
+                       check=True, capture_output=True)
+        return out.read_text()
+
+
+def check(asm):
+    problems = []
+    kernels = re.findall(r'^(_Z20gemm_tile_dma_kernelILi\dE\w*):[^\n]*\n(.*?)s_endpgm', asm, re.S | re.M)
+    if len(kernels) < 3:
+        problems.append(f'expected >= 3 instantiations of gemm_tile_dma_kernel, found {len(kernels)}')
+    for name, body in kernels:
+        lines = [l.strip() for l in body.splitlines()]
+        code = [l for l in lines if l and not l.startswith(';')]
+        for l in code:
+            if re.search(r'\bm0\b', l) and not l.startswith('s_mov_b32 m0,'):
+                problems.append(f'{name}: m0 used outside the DMA sequence: {l}')
+        heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
+        loop = None
+        for hi in heads:                       # the loop that holds the MFMAs
+            label = lines[hi].split(':')[0]
+            ends = [i for i in range(hi, len(lines)) if lines[i].startswith('s_cbranch') and lines[i].endswith(label)]
+            if ends and any(x.startswith('v_mfma') for x in lines[hi:ends[-1]]):
+                loop = [x for x in lines[hi:ends[-1] + 1] if x and not x.startswith(';') and not x.endswith(':')]
+        if loop is None:
+            problems.append(f'{name}: K loop not found')
+            continue
+        ops = [x.split()[0] for x in loop]
+        valu = [o for o in ops if o.startswith('v_') and not o.startswith('v_mfma')]
+        if valu:
+            problems.append(f'{name}: vector ALU instructions in the K loop: {sorted(set(valu))}')
+        if any(o.startswith('scratch_') for o in ops):
+            problems.append(f'{name}: scratch access in the K loop')
+        n_mfma = sum(o.startswith('v_mfma') for o in ops)
+        n_dma = sum(o.startswith('global_load_lds') for o in ops)
+        n_lds = sum(o.startswith('ds_read') for o in ops)
+        if (n_mfma, n_dma, n_lds) != (128, 16, 32):
+            problems.append(f'{name}: K loop (two steps) has {n_mfma} MFMA / {n_dma} DMA / {n_lds} ds_read, '
+                            f'expected 128 / 16 / 32')
+    return problems
+
+
+if __name__ == '__main__':
+    probs = check(compile_asm())
+    for p in probs:
+        print('ISA check:', p)
+    print('ISA check:', 'FAILED' if probs else 'ok')
+    sys.exit(1 if probs else 0)

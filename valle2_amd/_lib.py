@@ -117,7 +117,7 @@ SIGNATURES = {
     'vh_ar_decoder_capture': (C.c_int, [C.c_void_p, C.c_void_p]),
     'vh_ar_decoder_replay': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     'vh_ar_decoder_profile_attn': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
-                                             C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+                                             C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'vh_layernorm_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                    c_f32p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'vh_gelu': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),

@@ -13,6 +13,7 @@
 //                       dot products reduce over the 16 lanes of a DPP row; online softmax per
 //                       32-key chunk; waves combine through LDS, key splits through a small
 //                       workspace.   HBM-bound (algorithmic bytes = 2·len·64·4 per (b,head)).
+#include <hip/hip_ext.h>
 #include "vh_common.h"
 
 #define HD VH_HEAD_DIM
@@ -243,6 +244,9 @@ extern "C" size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split) {
     return (size_t)B * n_heads * n_split * PART_LD * sizeof(float);
 }
 
+static thread_local hipEvent_t g_attn_ev[2] = {nullptr, nullptr};
+void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop) { g_attn_ev[0] = start; g_attn_ev[1] = stop; }
+
 extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache,
                               float* out, int ldo, const int32_t* cache_len, int len_bias, int B,
                               int n_heads, int S_max, int n_split, void* partial, void* stream) {
@@ -259,9 +263,11 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
     dim3 grid(n_split, B * n_heads);
     // few workgroups → 16 waves each (one (b,head) can own a whole CU); many → 4 waves each
     const bool big = (int64_t)B * n_heads * n_split < 1024;
+    // g_attn_ev (set only by vh_ar_decoder_profile_attn): start/stop events attached to the kernel's own dispatch
+    // packet (hipExtLaunchKernelGGL), i.e. the kernel's begin/end timestamps rather than a marker bracket.
 #define AD(KERN, ...)                                                                              \
-    hipLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, q, ldq, kcache, vcache, out, ldo, \
-                       cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
+    hipExtLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, q, ldq, \
+                          kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
     const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
     const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
     const int waves = nw ? nw : (big ? 16 : 4);

@@ -476,8 +476,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
         const char* base = (q < 16 ? baseA : baseW) + (int64_t)k0 * 4;
         const uint32_t dst = (uint32_t)(uintptr_t)&lds[buf][q >> 4][(q & 15) * 8 * 32];   // low half of the flat address = LDS offset
         // scalar-base form by hand: the compiler's selection of the LDS-DMA intrinsic only produces 64-bit vector addresses
+        // (M0 holds the LDS destination.  It is a reserved register the compiler does not track through a clobber
+        // list; on gfx9 it has no other reader in this kernel — LDS instructions do not need it and nothing here
+        // indexes registers dynamically — which tools/check_isa.py asserts on the compiled code.)
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(dst), "v"(voff[i]), "s"(base) : "memory", "m0");
+                     :: "s"(dst), "v"(voff[i]), "s"(base) : "memory");
     };
 
     f32x16 acc[2][2];

@@ -86,7 +86,10 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
 
 // One decode step for every row: x (B,d) holds the new token's embedding on entry and the NEXT
 // token's embedding on exit.  `ev` (optional) brackets each decode-attention launch.
-static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEvent_t>* ev) {
+void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop);   // attention.hip
+
+static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEvent_t>* ev,
+                           std::vector<hipEvent_t>* kev = nullptr) {
     const vh_ar_decoder_desc& d = dec->d;
     const int B = d.B, D = d.d_model;
     for (int i = 0; i < d.n_layers; ++i) {
@@ -107,12 +110,20 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                 vh_set_error("vh_ar_decoder: hipEventCreate failed");
                 return VH_ELAUNCH;
             }
+            hipEvent_t k0 = nullptr, k1 = nullptr;
+            if (kev && hipEventCreate(&k0) == hipSuccess && hipEventCreate(&k1) == hipSuccess) {
+                vh_internal_attn_decode_events(k0, k1);
+                kev->push_back(k0);
+                kev->push_back(k1);
+            }
             (void)hipEventRecord(e0, s);
-            TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
-                               d.S_max, d.n_split, d.attn_partial, s));
+            const int arc = vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
+                                           d.S_max, d.n_split, d.attn_partial, s);
             (void)hipEventRecord(e1, s);
+            vh_internal_attn_decode_events(nullptr, nullptr);
             ev->push_back(e0);
             ev->push_back(e1);
+            if (arc != VH_OK) return arc;
         } else {
             TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
                                d.S_max, d.n_split, d.attn_partial, s));
@@ -189,14 +200,26 @@ extern "C" int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* strea
     return VH_OK;
 }
 
+static float mean_event_pairs(std::vector<hipEvent_t>& ev) {
+    double total = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) { total += ms; ++n; }
+    }
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    return n ? (float)(total / n) : 0.f;
+}
+
 extern "C" int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream,
-                                          float* mean_ms, float* floor_ms) {
+                                          float* mean_ms, float* floor_ms, float* kernel_ms) {
     VH_REQUIRE(dec && mean_ms && n_steps > 0, VH_EINVAL, "vh_ar_decoder_profile_attn: bad args");
     hipStream_t s = (hipStream_t)stream;
-    std::vector<hipEvent_t> ev, fl;
+    std::vector<hipEvent_t> ev, fl, kev;
     int rc = VH_OK;
     for (int i = 0; i < n_steps && rc == VH_OK; ++i) {
-        rc = decoder_enqueue(dec, s, &ev);
+        rc = decoder_enqueue(dec, s, &ev, kernel_ms ? &kev : nullptr);
         // measurement floor: the same bracket with nothing inside, once per step
         hipEvent_t f0, f1;
         if (floor_ms && hipEventCreate(&f0) == hipSuccess && hipEventCreate(&f1) == hipSuccess) {
@@ -207,24 +230,9 @@ extern "C" int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void*
         }
     }
     (void)hipStreamSynchronize(s);
-    if (floor_ms) {
-        double ft = 0.0;
-        int fn = 0;
-        for (size_t i = 0; i + 1 < fl.size(); i += 2) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, fl[i], fl[i + 1]) == hipSuccess) { ft += ms; ++fn; }
-        }
-        for (hipEvent_t e : fl) (void)hipEventDestroy(e);
-        *floor_ms = fn ? (float)(ft / fn) : 0.f;
-    }
-    double total = 0.0;
-    int n = 0;
-    for (size_t i = 0; i + 1 < ev.size(); i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) { total += ms; ++n; }
-    }
-    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
-    *mean_ms = n ? (float)(total / n) : 0.f;
+    if (floor_ms) *floor_ms = mean_event_pairs(fl);
+    if (kernel_ms) *kernel_ms = mean_event_pairs(kev);
+    *mean_ms = mean_event_pairs(ev);
     return rc;
 }
 

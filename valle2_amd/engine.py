@@ -266,10 +266,10 @@ class ArDecoder:
                 check(L.vh_ar_decoder_step(self._h, s), 'vh_ar_decoder_step')
 
     def profile_attn(self, n_steps):
-        """(bracket_ms, floor_ms): mean event-to-event time of the HIP-event brackets around the
-        decode-attention launches over n_steps eager steps, and the mean time of an empty bracket on the
-        same stream (advances the decode state by n_steps)."""
-        ms, floor = C.c_float(0), C.c_float(0)
-        check(_lib.lib().vh_ar_decoder_profile_attn(self._h, n_steps, stream(), C.byref(ms), C.byref(floor)),
-              'vh_ar_decoder_profile_attn')
-        return ms.value, floor.value
+        """(bracket_ms, floor_ms, kernel_ms) over n_steps eager steps: mean event-to-event time of marker events
+        around the decode-attention launches, the same bracket with nothing inside, and the mean time between the
+        start/stop events attached to the kernel dispatch itself (advances the decode state by n_steps)."""
+        ms, floor, kern = C.c_float(0), C.c_float(0), C.c_float(0)
+        check(_lib.lib().vh_ar_decoder_profile_attn(self._h, n_steps, stream(), C.byref(ms), C.byref(floor),
+                                                    C.byref(kern)), 'vh_ar_decoder_profile_attn')
+        return ms.value, floor.value, kern.value

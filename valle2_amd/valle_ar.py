@@ -221,9 +221,9 @@ class ValleAR(_Base):
             del x, last
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
             done, stop = 1, None
-            attn_ms = attn_floor_ms = None
+            attn_ms = attn_floor_ms = attn_kernel_ms = None
             if profile_attn and max_new > 1:
-                attn_ms, attn_floor_ms = dec.profile_attn(max_new - 1)
+                attn_ms, attn_floor_ms, attn_kernel_ms = dec.profile_attn(max_new - 1)
                 done = max_new
             while done < max_new:
                 n = min(EOS_POLL, max_new - done)
@@ -238,7 +238,8 @@ class ValleAR(_Base):
                 stop = int(full[0]) if full.numel() else None
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms, 's0': s0,
+                                        'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
+                                        'attn_kernel_ms': attn_kernel_ms, 's0': s0,
                                         'prompt_lens': pls,
                                         'sum_logprobs': dec.sum_logprobs.clone()}
             return codes[:, : pl_max + n_new].clone()
