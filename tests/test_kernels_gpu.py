@@ -119,8 +119,7 @@ def test_linear_tile_strided_operands(K, M, N, K_, tile_staging):
 
 @pytest.mark.parametrize('M,N,K_', [(257, 1536, 512), (1000, 100, 2048), (6144, 2048, 64), (130, 132, 96)])
 def test_linear_tile_staging_kernels_bit_identical(K, M, N, K_):
-    """The register-staged and the LDS-DMA tile kernels accumulate K in the same order: same bits.  (6144 x 2048
-    is the 768-tile shape the default routes to the staged kernel.)"""
+    """The register-staged and the LDS-DMA tile kernels accumulate K in the same order: same bits."""
     from valle2_amd import _lib
     a = torch.randn(M, K_, generator=g(300)).to(DEV)
     w = (0.05 * torch.randn(N, K_, generator=g(301))).to(DEV)

@@ -1146,14 +1146,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
 #undef SK
     } else {
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
-        // The LDS-DMA variant needs whole 32-wide K slabs.  One launch shape goes to the staged kernel by
-        // measurement: when the last round of workgroups is exactly one per CU (tiles % 512 in (192, 256], one and a
-        // half rounds in all) the dispatcher pairs the DMA kernel's second-round workgroups on half the CUs (138 us
-        // vs 115 us at 768 tiles, tools/bench_kernels.py tilesweep); the staged kernel's finish order spreads them.
-        const int tune_dma = vh_tuning(VH_TUNE_TILE_DMA);
-        const int tiles = tm * tn, tail = tiles % 512;
-        const bool half_round = tiles > 512 && tiles < 1024 && tail > 192 && tail <= 256;
-        if (a.k_len % TK == 0 && tune_dma != 1 && (tune_dma == 2 || !half_round))
+        // The LDS-DMA kernel needs whole 32-wide K slabs; a ragged K goes to the register-staged kernel.
+        if (a.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1)
             hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
         else
             hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
