@@ -51,7 +51,7 @@ def test_linear_skinny_integer_exact(K, M, N, K_):
 
 
 @pytest.mark.parametrize('M,N,K_', [(65, 16, 16), (128, 128, 32), (300, 1025, 128), (257, 1536, 512),
-                                    (1000, 100, 2048)])
+                                    (1000, 100, 2048), (65, 16, 32), (100, 300, 64), (129, 4, 96)])
 def test_linear_tile_integer_exact(K, M, N, K_, tile_staging):
     a = torch.randint(-3, 4, (M, K_), generator=g(3)).float()
     w = torch.randint(-3, 4, (N, K_), generator=g(4)).float()
