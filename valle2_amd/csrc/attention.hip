@@ -427,12 +427,20 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
             const float m_new = fmaxf(m, tmax);
             const float m_use = m_new == NEG_INF ? 0.f : m_new;  // fully masked so far: p = 0
             const float alpha = vh_exp2(m - m_use);
-            float psum = 0.f;
+            // subtract and sum two scores per instruction (v_pk_add_f32); the exponentials stay scalar
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 psum2 = {0.f, 0.f};
+            const f32x2 nm2 = {-m_use, -m_use};
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                S[e] = vh_exp2(S[e] - m_use);
-                psum += S[e];
+            for (int e = 0; e < 16; e += 2) {
+                f32x2 d = f32x2{S[e], S[e + 1]} + nm2;
+                d.x = vh_exp2(d.x);
+                d.y = vh_exp2(d.y);
+                psum2 += d;
+                S[e] = d.x;
+                S[e + 1] = d.y;
             }
+            const float psum = psum2.x + psum2.y;
             l = l * alpha + psum;
             m = m_new;
             if (__any(alpha != 1.0f)) {                // no query of this wave raised its maximum: nothing to rescale
