@@ -632,23 +632,31 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
             const float* vs = ks + KT * KLD;
             f32x16 S, P;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { S[e] = 0.f; P[e] = 0.f; }
-#pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 kf = ld4(ks + r * KLD + 8 * t + 4 * h);
                 const f32x4 vf = ld4(vs + r * KLD + 8 * t + 4 * h);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], S, 0, 0, 0);   // Sᵀ[key][q]
-                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], df[t][j], P, 0, 0, 0);   // dPᵀ[key][q]
+                for (int j = 0; j < 4; ++j) {      // the first products start from the constant-zero C operand
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j], qf[t][j], (t | j) ? S : f32x16{}, 0, 0, 0);   // Sᵀ[key][q]
+                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[j], df[t][j], (t | j) ? P : f32x16{}, 0, 0, 0);   // dPᵀ[key][q]
                 }
             }
+            // whole tile visible to every query of this wave: no per-element mask (vector compares and selects
+            // are MFMA issue slots)
+            bool all = wpos_max < a.T && k0 + KT <= kvl;
+            if (a.mode == VH_MASK_PREFIX) all = all && (k0 + KT <= xl || (wpos_min >= xl && k0 + KT - 1 <= wpos_min));
+            else if (a.mode == VH_MASK_EXPLICIT) all = false;
+            if (all) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const bool vis = qin && bwd_visible(a, b, qi, key, kvl, xl);
-                const float p = vis ? vh_exp2(S[e] - lse) : 0.f;
-                S[e] = p * (P[e] - dsum);                                                   // dSᵀ[key][q]
+                for (int e = 0; e < 16; ++e) S[e] = vh_exp2(S[e] - lse) * (P[e] - dsum);   // dSᵀ[key][q]
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const bool vis = qin && bwd_visible(a, b, qi, key, kvl, xl);
+                    const float p = vis ? vh_exp2(S[e] - lse) : 0.f;
+                    S[e] = p * (P[e] - dsum);
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -751,29 +759,47 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
             const float* ds = qs + KT * KLD;
             f32x16 S, P;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { S[e] = 0.f; P[e] = 0.f; }
-#pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 qv = ld4(qs + r * KLD + 8 * t + 4 * h);
                 const f32x4 dv = ld4(ds + r * KLD + 8 * t + 4 * h);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[j], kf[t][j], S, 0, 0, 0);   // S[q][key]
-                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[j], vf[t][j], P, 0, 0, 0);   // dP[q][key]
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[j], kf[t][j], (t | j) ? S : f32x16{}, 0, 0, 0);   // S[q][key]
+                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[j], vf[t][j], (t | j) ? P : f32x16{}, 0, 0, 0);   // dP[q][key]
                 }
             }
+            // every (query of the tile, key of this wave) pair visible: no per-element mask
+            const int wk_max = wk_min + 31;
+            bool all = wk_max < kvl && q0t + KT <= a.T;
+            if (a.mode == VH_MASK_PREFIX) all = all && (wk_max < xl || (q0t >= xl && wk_max <= q0t));
+            else if (a.mode == VH_MASK_EXPLICIT) all = false;
+            if (all) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const f32x4 lse4 = ld4(&stat[cur][0][8 * g4 + 4 * h]);
-                const f32x4 d4 = ld4(&stat[cur][1][8 * g4 + 4 * h]);
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 lse4 = ld4(&stat[cur][0][8 * g4 + 4 * h]);
+                    const f32x4 d4 = ld4(&stat[cur][1][8 * g4 + 4 * h]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = 4 * g4 + j;
-                    const int qi = q0t + 8 * g4 + 4 * h + j;
-                    const bool vis = kin && qi < a.T && bwd_visible(a, b, qi, kj, kvl, xl);
-                    const float p = vis ? vh_exp2(S[e] - lse4[j]) : 0.f;
-                    S[e] = p;                                   // P[q][key]
-                    P[e] = p * (P[e] - d4[j]);                  // dS[q][key]
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const float p = vh_exp2(S[e] - lse4[j]);
+                        S[e] = p;                                   // P[q][key]
+                        P[e] = p * (P[e] - d4[j]);                  // dS[q][key]
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 lse4 = ld4(&stat[cur][0][8 * g4 + 4 * h]);
+                    const f32x4 d4 = ld4(&stat[cur][1][8 * g4 + 4 * h]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const int qi = q0t + 8 * g4 + 4 * h + j;
+                        const bool vis = kin && qi < a.T && bwd_visible(a, b, qi, kj, kvl, xl);
+                        const float p = vis ? vh_exp2(S[e] - lse4[j]) : 0.f;
+                        S[e] = p;
+                        P[e] = p * (P[e] - d4[j]);
+                    }
                 }
             }
 #pragma unroll
