@@ -597,10 +597,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(BwdArgs a) {
     f32x4 rk[2], rv[2];
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = min(k0 + skey + 16 * i, a.T - 1);   // clamped: masked anyway
-            rk[i] = ld4(kb + (int64_t)key * HD + squad);
-            rv[i] = ld4(vb + (int64_t)key * HD + squad);
+        for (int i = 0; i < 2; ++i) {                          // keys clamped (masked anyway); uniform base + 32-bit lane offset
+            const uint32_t off = (uint32_t)(min(k0 + skey + 16 * i, a.T - 1) * HD + squad) * 4u;
+            rk[i] = ld4((const float*)((const char*)kb + off));
+            rv[i] = ld4((const float*)((const char*)vb + off));
         }
     };
     auto lstore = [&](int buf) {
@@ -717,12 +717,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     const int sq = tid >> 4, squad = (tid & 15) * 4;   // staging: 2 query rows per thread per operand
     f32x4 rq[2], rd[2];
     float rstat = 0.f;
+    const float* qbase = a.q + (int64_t)b * a.T * a.ldq + head * HD;
+    const float* dbase = a.dout + (int64_t)b * a.T * a.lddo + head * HD;
     auto gload = [&](int q0t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int64_t row = (int64_t)b * a.T + min(q0t + sq + 16 * i, a.T - 1);
-            rq[i] = ld4(a.q + row * a.ldq + head * HD + squad);
-            rd[i] = ld4(a.dout + row * a.lddo + head * HD + squad);
+        for (int i = 0; i < 2; ++i) {                          // uniform (batch row, head) base + 32-bit lane offset
+            const int qrow = min(q0t + sq + 16 * i, a.T - 1);
+            rq[i] = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
+            rd[i] = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
         }
         if (tid < 2 * KT) {
             const int qq = min(q0t + (tid & 31), a.T - 1);
