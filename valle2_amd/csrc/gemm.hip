@@ -225,8 +225,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             f32x4 v = ld4(cr + it * 8 * LDC);
             if (EPI == EPI_PLAIN) {
                 v += e.bias4;
-                if (a.act == VH_ACT_GELU_ERF) {
-                    v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                if (a.act == VH_ACT_GELU_ERF) {                 // two per instruction (packed fp32)
+                    const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
+                    v = f32x4{g0.x, g0.y, g1.x, g1.y};
                 }
                 v += e.resv[it];
             }

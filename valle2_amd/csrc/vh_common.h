@@ -118,6 +118,37 @@ __device__ __forceinline__ float vh_erf(float x) {
     return fabsf(x) < 1.0f ? small : large;
 }
 
+// Two GELUs at once: the polynomial work of vh_erf on packed pairs (v_pk_mul_f32 / v_pk_fma_f32 / v_pk_add_f32
+// process two fp32 per instruction), the two exponentials and the selects scalar.  Same formulas and coefficients
+// as vh_erf / gelu_erf, so a pair gives bit-identical results to two scalar calls (fma is fma either way).
+typedef float vh_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ vh_f32x2 vh_splat2(float v) { return vh_f32x2{v, v}; }
+__device__ __forceinline__ vh_f32x2 gelu_erf2(vh_f32x2 x) {
+    const vh_f32x2 z = x * vh_splat2(0.70710678118654752440f);
+    const vh_f32x2 s = z * z;
+    vh_f32x2 p = vh_splat2(-5.654105917e-04f);
+    p = __builtin_elementwise_fma(p, s, vh_splat2(4.923277535e-03f));
+    p = __builtin_elementwise_fma(p, s, vh_splat2(-2.671638504e-02f));
+    p = __builtin_elementwise_fma(p, s, vh_splat2(1.128036454e-01f));
+    p = __builtin_elementwise_fma(p, s, vh_splat2(-3.761234879e-01f));
+    p = __builtin_elementwise_fma(p, s, vh_splat2(1.128379107e+00f));
+    const vh_f32x2 small = p * z;
+    const vh_f32x2 t = {fminf(fabsf(z.x), 4.0f), fminf(fabsf(z.y), 4.0f)};
+    vh_f32x2 q = vh_splat2(-1.920139221e-05f);
+    q = __builtin_elementwise_fma(q, t, vh_splat2(4.581596004e-04f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(-4.958351608e-03f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(3.263662755e-02f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(-1.490577757e-01f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(5.206782818e-01f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(-1.624367833e+00f));
+    q = __builtin_elementwise_fma(q, t, vh_splat2(-1.092074905e-03f));
+    q = __builtin_elementwise_fma(vh_splat2(-1.4426950408889634f) * t, t, q);
+    vh_f32x2 e;
+    e.x = fabsf(z.x) < 1.0f ? small.x : copysignf(1.0f - __builtin_amdgcn_exp2f(q.x), z.x);
+    e.y = fabsf(z.y) < 1.0f ? small.y : copysignf(1.0f - __builtin_amdgcn_exp2f(q.y), z.y);
+    return vh_splat2(0.5f) * x * (vh_splat2(1.0f) + e);
+}
+
 __device__ __forceinline__ float gelu_erf(float x) {
     // nn.GELU() default = exact erf form (valle/models/modules.py:216)
     return 0.5f * x * (1.0f + vh_erf(x * 0.70710678118654752440f));
