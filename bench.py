@@ -13,17 +13,28 @@ Multi-GPU: the utterance batch shards across ranks (32 rows per GPU, weights rep
 data-path collective: SURVEY.md §8e "inference: replicas only"); ranks meet at a barrier before and
 after the timed region and the slowest rank's time is used (RCCL all-reduce MAX).
 
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts the N ranks itself (one child
+process per GPU, RCCL rendezvous on 127.0.0.1) BEFORE this process touches the GPU — the parent never
+initialises HIP and never execs; under `torch.distributed.run` the environment's ranks are used as is.
+
 Extra objects on the same JSON line: `roofline` (decode-attention kernel, HIP-event timed, HBM
-bound), `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample; rank 0,
-N=1 only), `nar` (one NAR stage forward of configs[2], secondary metric).
+bound), `prefill` (event-timed prompt pass against the fp32 MFMA peak), `decode_step` (one replayed
+decode step against the HBM peak, all algorithmic bytes of the step), `train` (configs[3] forward +
+backward + gradient all-reduce + clip/AdamW step time, AR and NAR, on every rank: the RCCL leg),
+`cpu_baseline` (the oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only),
+`nar` (one NAR stage forward of configs[2], secondary metric).  The optional legs run under a
+deadline: if one stalls, the line is printed with what was measured and the process exits.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import tempfile
+import threading
 import time
 from pathlib import Path
 
@@ -47,6 +58,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-nar', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-train', action='store_true')
+    ap.add_argument('--extras-deadline', type=float, default=420.0,
+                    help='seconds the optional legs (roofline, nar, train, cpu_baseline) may take in total')
     ap.add_argument('--small', action='store_true', help='tiny shapes for a functional check')
     return ap.parse_args()
 
@@ -123,11 +137,94 @@ def cpu_baseline(cfg_kw, sd, utt, rows, new, gpu_tokens=None):
                       f'({t_step * 1e3:.1f} ms/step at S~{TEXT + FRAMES + 1}), extrapolated to {new} tokens'}
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU.  Runs before
+    anything in this process has touched the GPU (torch is not even imported here); the parent only
+    waits, forwards the exit code and — if a rank dies — ends the others (by PID, not by pattern)."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env))
+    rc = 0
+    while procs:
+        time.sleep(0.2)
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0:
+                rc = rc or code
+                log(f'rank process {p.pid} exited with {code}: stopping the other ranks')
+                for q in procs:
+                    q.terminate()
+    return rc
+
+
+def train_leg(dev, world, rank, small):
+    """configs[3]: 12L/512d AR and NAR forward + backward + gradient all-reduce (RCCL when world > 1,
+    overlapped with backward) + clip/AdamW, per-GPU batch 16, LibriTTS-shaped ragged synthetic batches."""
+    import torch
+
+    from valle2_amd import ConfigValle, dp, get_model_class, synth
+    out = {'config': 'configs[3]: 12L/512d fwd+bwd, per-GPU batch 16, tokens 40..120, codes 225..900, fp32 grads, '
+                     f'DP x{world}' + (' (RCCL flat-bucket all-reduce overlapped with backward)' if world > 1 else '')}
+    kw = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, batch_size=16)
+    if small:
+        kw.update(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, batch_size=4)
+    for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
+        cfg = ConfigValle(**kw, norm=norm)
+        torch.manual_seed(0)
+        model = get_model_class(name)(cfg).to(dev).train()
+        opt = model.configure_optimizers()['optimizer']
+        reducer = dp.GradReducer(opt.flat_grad, opt.slots)
+        warm, timed = 3, 5
+        rows = 0
+        for i in range(warm + timed):
+            if name == 'ValleAR':
+                batch = synth.synth_ar_batch(cfg, cfg.batch_size, seed=100 + i + 1000 * rank)
+            else:
+                batch = synth.synth_nar_batch(cfg, cfg.batch_size, n_tokens=80, n_frames=560, seed=100 + i + 1000 * rank)
+            batch = {k: (v if k.endswith('_lens') else v.to(dev)) for k, v in batch.items()}   # resident in HBM
+            if i == warm:
+                torch.cuda.synchronize()
+                if world > 1:
+                    torch.distributed.barrier()
+                t0 = time.perf_counter()
+            loss = model.training_step(batch, **({'stage': 1 + i % 7} if name == 'ValleNAR' else {}))
+            loss.backward()
+            reducer.finish()
+            opt.step(grad_scale=1.0 / world, max_norm=cfg.gradient_clip_val, zero_grad=True)
+            if i >= warm:
+                rows += batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])
+        torch.cuda.synchronize()
+        dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
+        key = 'ar' if name == 'ValleAR' else 'nar'
+        out[f'{key}_ms_per_step'] = dt / timed * 1e3
+        out[f'{key}_positions_per_s'] = world * rows / dt          # rank 0's rows x world (shapes are seeded per rank)
+        out[f'{key}_allreduce_bytes'] = 4 * opt.numel if world > 1 else 0
+        out[f'{key}_loss'] = float(loss.detach())
+        reducer.remove()
+        del model, opt, reducer
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('VALLE2_BENCH_SPAWN_PROBE'):     # test hook: show what a spawned rank was given, no GPU
+        print(json.dumps({'rank': rank, 'local': local, 'world': world, 'addr': os.environ.get('MASTER_ADDR'),
+                          'port': os.environ.get('MASTER_PORT'), 'argv': sys.argv[1:]}), flush=True)
+        return
     os.chdir(tempfile.mkdtemp(prefix='vh_bench_'))
     import torch
     import torch.distributed as dist
@@ -136,6 +233,8 @@ def main():
 
     # rehearsal knobs (a one-GPU box, several ranks on `gloo`): VALLE2_FORCE_DEVICE, VALLE2_DIST_BACKEND
     local = int(os.environ.get('VALLE2_FORCE_DEVICE', local))
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f'bench.py: rank {rank} wants GPU {local} but this node shows {torch.cuda.device_count()}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     backend = os.environ.get('VALLE2_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; no-op at N=1
@@ -197,7 +296,48 @@ def main():
                    'timed_region': 'embed + prefill + (new-1) hipGraph-replayed decode steps'},
     }
 
+    # ---- optional legs under a deadline: the line is printed exactly once, by whoever gets there first
+    emitted = threading.Lock()
+
+    def emit(note=None):
+        if not emitted.acquire(blocking=False):
+            return
+        if note:
+            result['extras_note'] = note
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+
+    def on_deadline():
+        emit(f'optional legs exceeded {args.extras_deadline:.0f} s: line printed with what was measured')
+        os._exit(0)
+
+    watchdog = threading.Timer(args.extras_deadline, on_deadline)
+    watchdog.daemon = True
+    watchdog.start()
+
     l_pl = 4 * cfg.d_model ** 2 + 2 * cfg.d_model * cfg.dim_feedforward   # matmul weights per layer
+    st = model.last_generate_stats
+    if rank == 0 and 'prefill_ms' in st:
+        # phase split of the LAST timed generate (HIP events on the launch stream, recorded inside generate_batch)
+        x, y = text, frames + 1
+        pairs = x * x + y * x + y * (y + 1) // 2                            # unmasked (query, key) pairs per row
+        flop = 2.0 * cfg.num_layers * l_pl * rows * (x + y) + 4.0 * cfg.d_model * pairs * cfg.num_layers * rows
+        tf = flop / (st['prefill_ms'] * 1e-3) / 1e12
+        result['prefill'] = {'ms': st['prefill_ms'], 'flop': flop, 'tflops': tf, 'peak_tflops': MFMA_F32_PEAK_TF,
+                             'frac': tf / MFMA_F32_PEAK_TF, 'bound': 'mfma', 'dtype': 'f32',
+                             'note': 'embed + 12-layer prompt pass + head + first sample of the last timed generate; '
+                                     'flop = GEMMs over all prompt rows + attention over unmasked pairs only (SURVEY 8d)'}
+        step_elems = [cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
+                      + 2 * cfg.num_layers * rows * (st['s0'] + t) * cfg.d_model
+                      + 2 * cfg.num_layers * rows * cfg.d_model for t in range(1, new)]
+        dec_bytes = 4.0 * sum(step_elems)
+        gbs = dec_bytes / (st['decode_ms'] * 1e-3) / 1e9
+        result['decode_step'] = {'ms_per_step': st['decode_ms'] / max(1, new - 1), 'steps': new - 1,
+                                 'algorithmic_bytes_total': dec_bytes, 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                                 'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
+                                 'tokens_per_s_decode_only': rows * (new - 1) / (st['decode_ms'] * 1e-3),
+                                 'note': 'all hipGraph-replayed decode steps of the last timed generate (weights + KV '
+                                         'read once per step, SURVEY 8d), EOS polls included'}
     if rank == 0 and not args.no_roofline:
         # dominant kernel: decode attention (KV streaming).  HIP events on the launch stream for
         # every launch of an eager (non-graph) pass over the same 511 steps.
@@ -234,6 +374,8 @@ def main():
             if t.get('rows') == rows and t.get('new_tokens') == new:
                 result['roofline']['traffic'] = t['bytes_per_launch']
                 result['roofline']['traffic_source'] = t['source']
+                result['roofline']['traffic_measured_in_this_run'] = False   # committed-profile data (PMC passes
+                # cannot run inside the timed process: rocprofv3 --pmc serialises kernels)
         # whole-step view of the same roofline: all algorithmic bytes of the decode steps
         step_elems = [cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
                       + 2 * cfg.num_layers * rows * (st['s0'] + t) * cfg.d_model
@@ -266,13 +408,24 @@ def main():
                          'frac_of_mfma_peak': flop / t_stage / 1e12 / MFMA_F32_PEAK_TF}
         del nar, nb
 
+    if not args.no_train:
+        # every rank takes part: this is the path's one real exchange (gradient all-reduce over RCCL/xGMI)
+        log('train: configs[3] AR + NAR steps')
+        try:
+            del model
+            torch.cuda.empty_cache()
+            result['train'] = train_leg(dev, world, rank, args.small)
+        except Exception as e:                      # never lose the headline line to the secondary leg
+            result['train'] = {'error': f'{type(e).__name__}: {e}'}
+            log(f'train leg failed: {e}')
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # same model, same first utterance, all `rows` beams, on the host cores of this box
         result['cpu_baseline'] = cpu_baseline(ar_kw, sd, utts[0], rows, new,
                                               gpu_tokens=out[0, frames + 1:].cpu())
 
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    watchdog.cancel()
+    emit()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

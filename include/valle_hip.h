@@ -71,11 +71,15 @@ int vh_set_tuning(int knob, int value);
  *   out[b*out_bstride + (out_t0 + t)*d + :] =
  *       sum_{j<n_tables} tables[j][ ids[b*ids_bstride + t*ids_tstride + j*ids_jstride] ][:]
  *       + pe[(pos0 + t)*d + :]                      (pe == NULL: no position term)
- * `tables` is a HOST array of n_tables device pointers, each (vocab, d). */
+ * `tables` is a HOST array of n_tables device pointers, each (vocab[j], d); `vocab` is a HOST array of
+ * the n_tables row counts.  An id outside [0, vocab[j]) reads row 0 instead (never out of bounds) and
+ * ORs VH_DEVERR_EMBED_ID into *err_flag (device int32, may be NULL); the reference's nn.Embedding raises
+ * IndexError there — the host side turns the flag into that exception at its next synchronisation. */
+enum { VH_DEVERR_EMBED_ID = 1, VH_DEVERR_TARGET = 2 };
 int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
-                    int64_t ids_jstride, const float* const* tables, int n_tables,
+                    int64_t ids_jstride, const float* const* tables, const int32_t* vocab, int n_tables,
                     const float* pe, int pos0, const int32_t* lens, float* out,
-                    int64_t out_bstride, int out_t0, int B, int T, int d, void* stream);
+                    int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag, void* stream);
 
 /* ---- K3/K4: LayerNorm (eps) with optional adaptive scale/shift ------------------------------
  * replaces nn.LayerNorm (valle/models/modules.py:284) and AdaptiveLayerNorm.forward (:93-99):
@@ -308,14 +312,30 @@ int vh_softmax_rows(float* S, int ld, int B, int n_heads, int Tq, int Tk, float 
 /* dS = scale * P o (dP - rowsum(dP o P)), in place on dP (both with row stride ld) */
 int vh_softmax_bwd(const float* P, float* dP, int ld, int64_t rows, int Tk, float scale, void* stream);
 /* mean cross entropy over `rows` rows of (rows, V) logits (F.cross_entropy, valle_ar.py:86):
- * *loss = mean(lse - logit[target]); dlogits (may be NULL) = (softmax - onehot) / rows */
+ * *loss = mean(lse - logit[target]); dlogits (may be NULL) = (softmax - onehot) / rows.
+ * A target outside [0, V) (this includes torch's ignore_index -100, which the collate format never
+ * emits: it pads with 0, valle/collate.py:35,65) contributes lse only, gets no one-hot term and ORs
+ * VH_DEVERR_TARGET into *err_flag (device int32, may be NULL). */
 int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
-                     float* dlogits, int ldd, int rows, void* stream);
-/* embedding backward: dtable[ids[b,t], :] += dout[b, out_t0 + t, :] */
+                     float* dlogits, int ldd, int rows, int32_t* err_flag, void* stream);
+/* embedding backward: dtable[ids[b,t], :] += dout[b, out_t0 + t, :]; ids outside [0, vocab) are skipped
+ * (and flagged as in vh_embed_sum_pe) */
 int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, const float* dout,
-                 int64_t dout_bstride, int out_t0, float* dtable, int B, int T, int d, void* stream);
+                 int64_t dout_bstride, int out_t0, float* dtable, int vocab, int B, int T, int d,
+                 int32_t* err_flag, void* stream);
 /* bias gradient: out[c] += sum_r x[r, c] */
 int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
+
+/* ---- NAR stage sampler -------------------------------------------------------------------------
+ * replaces `Categorical(logits=logits / temperature).sample()` of ValleNAR.generate
+ * (valle/models/valle_nar.py:160) for `rows` rows of (rows, V) logits (row stride ld):
+ *   tokens[r * tokens_stride] ~ softmax(logits[r] / temperature)     (inverse CDF in index order, counter
+ *   RNG keyed on (seed, r, stream_id): the stream differs from torch's, parity is distributional), or
+ *   the arg-max with the lowest index on ties when greedy != 0 (what the parity tests pin).
+ * logprob (rows floats, may be NULL) receives log p(token) (0 when greedy). */
+int vh_categorical_rows(const float* logits, int ld, int V, int rows, float temperature, int greedy,
+                        uint64_t seed, uint32_t stream_id, int64_t* tokens, int64_t tokens_stride,
+                        float* logprob, void* stream);
 
 /* ---- optimizer step over one flat fp32 buffer ------------------------------------------------
  * replaces optim.AdamW(fused) (valle/models/valle_ar.py:182-194), the global-norm clip

@@ -28,6 +28,18 @@ def cfg_of(kw, cls=ConfigValle):
 AR_TINY = dict(TINY, norm='LayerNorm', num_beams=4, top_k=1, max_audio_len=64)
 AR_MID = dict(MID, norm='LayerNorm', num_beams=2, top_k=1, max_audio_len=48)
 NAR_TINY = dict(TINY, norm='AdaptiveLayerNorm')
+# full BASELINE.json sizes (round 2): configs[1] generate, configs[3] training batch, configs[4] NAR stage
+AR_FULL = dict(MID, norm='LayerNorm', num_beams=32, top_k=1, max_audio_len=128)
+AR_TRAIN_FULL = dict(MID, norm='LayerNorm')
+BIG = dict(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0)
+NAR_BIG = dict(BIG, norm='AdaptiveLayerNorm')
+FULL_TEXT, FULL_FRAMES = 256, 767           # configs[1]: 256 text + BOS + 767 codec tokens = 1024
+TRAIN_FULL_BATCH = 16                       # configs[3]: per-GPU B=16
+
+TRAIN_LOGIT_STRIDE = 61                     # teacher-forced logits kept at every 61st audio position
+NAR_BIG_TEXT, NAR_BIG_FRAMES = 400, 2475    # configs[4]: 400 text + 225 prompt + 2250 target frames
+NAR_BIG_STRIDE = 29
+SAMPLING_FILTERS = [(50, 1.0, 1.0), (5, 0.9, 0.7), (0, 0.8, 1.0), (20, 0.5, 1.3)]   # (top_k, tok_p, temperature)
 MHA_SHAPES = [(512, 8, 4, 5), (256, 4, 8, 10), (128, 2, 16, 20)]  # reference tests/test_modules.py:9-13
 
 
@@ -67,14 +79,44 @@ def ar_train_inputs():
 
 
 def ar_generate_inputs(which):
-    kw = AR_TINY if which == 'tiny' else AR_MID
+    kw = {'tiny': AR_TINY, 'mid': AR_MID, 'full': AR_FULL}[which]
     cfg = cfg_of(kw)
     sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=5, rich=True), cfg)
-    if which == 'tiny':   # BASELINE.json configs[0]: 128 text + 256 EnCodec tokens (255 + BOS)
+    if which == 'full':   # BASELINE.json configs[1] at full size: 32 beams, 256 text + BOS + 767 codec tokens
+        utt = synth.synth_utterance(cfg, FULL_TEXT // 2, FULL_TEXT // 2, FULL_FRAMES, seed=1234)
+    elif which == 'tiny':   # BASELINE.json configs[0]: 128 text + 256 EnCodec tokens (255 + BOS)
         utt = synth.synth_utterance(cfg, 64, 64, 255, seed=1234)
     else:                 # reduced configs[1]: 12L/512d, short prompt so the fixture stays small
         utt = synth.synth_utterance(cfg, 24, 24, 47, seed=1234)
     return kw, sd, utt
+
+
+def ar_prefill_full_inputs():
+    """4 DISTINCT utterances at the configs[1] prompt shape (generate() itself replicates one utterance
+    over its beams, valle_ar.py:136-138, so distinct rows go through the reference's sub-modules)."""
+    kw, sd, _ = ar_generate_inputs('full')
+    cfg = cfg_of(kw)
+    utts = [synth.synth_utterance(cfg, FULL_TEXT // 2, FULL_TEXT // 2, FULL_FRAMES, seed=4321 + i) for i in range(4)]
+    text = torch.stack([torch.cat([u[0], u[2]]) for u in utts])
+    codes = torch.stack([F.pad(u[1][:, 0], (1, 0), value=cfg.bos_token) for u in utts])
+    pos = torch.tensor([0, 1, 100, 333, 500, 640, 766, 767])       # audio positions whose logits are kept
+    return kw, sd, text, codes, pos
+
+
+def ar_train_full_inputs():
+    """configs[3]-shaped AR training batch: 12L/512d, tokens_lens ~U{40..120}, codes_lens ~U{225..900}."""
+    cfg = cfg_of(AR_TRAIN_FULL)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True)
+    batch = synth.synth_ar_batch(cfg, TRAIN_FULL_BATCH, seed=2121)
+    return AR_TRAIN_FULL, sd, batch
+
+
+def nar_big_inputs():
+    """configs[4] NAR leg: 24L/1024d/h16, one utterance, 400 text + 2475 frames (225 prompt + 2250 target)."""
+    cfg = cfg_of(NAR_BIG)
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=17, rich=True)
+    batch = synth.synth_nar_batch(cfg, 1, n_tokens=NAR_BIG_TEXT, n_frames=NAR_BIG_FRAMES, seed=313)
+    return NAR_BIG, sd, batch
 
 
 def ar_eos_inputs(eos_row=None):
@@ -199,6 +241,83 @@ def _ref_generate(ref, which):
             'logits_row0': logits[:, 0][:: max(1, len(rows) // 8)], 'steps': torch.tensor(len(rows))}
 
 
+def _ref_prefill_full(ref):
+    kw, sd, text, codes, pos = ar_prefill_full_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['ar'].ValleAR(cfg).eval()
+    m.load_state_dict(sd)
+    # valle_ar.py:121-158 at step 0, for distinct rows: embed + PE, prefix-LM mask, stack, head
+    tok = m.tokens_position_emb(m.tokens_emb(text))
+    aud = m.audio_position_emb(m.audio_emb(codes))
+    mask = ref['utils'].build_attn_mask(text.shape[1], codes.shape[1], device='cpu')
+    y, _ = m.transformer(torch.cat([tok, aud], dim=1), attn_mask=mask, use_cache=True)
+    logits = m.proj(y[:, text.shape[1]:][:, pos])
+    return {'logits': logits, 'hidden_last': y[:, -1]}
+
+
+def _ref_ar_train_full(ref):
+    kw, sd, batch = ar_train_full_inputs()
+    with torch.enable_grad():
+        cfg = cfg_of(kw, ref['config'].ConfigValle)
+        m = ref['ar'].ValleAR(cfg).eval()
+        m.load_state_dict(sd)
+        rows = []
+        hook = m.proj.register_forward_hook(lambda mod, i, o: rows.append(o.detach()[:, ::TRAIN_LOGIT_STRIDE].clone()))
+        loss = m.training_step({k: v.clone() for k, v in batch.items()})
+        hook.remove()
+        loss.backward()
+        grads = {n: p.grad.norm() for n, p in m.named_parameters()}
+    names = sorted(grads)
+    return {'loss': loss.detach(), 'grad_norms': torch.stack([grads[n] for n in names]).detach(),
+            'logits_sub': rows[0]}
+
+
+def _ref_nar_big(ref):
+    kw, sd, batch = nar_big_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['nar'].ValleNAR(cfg).eval()
+    m.load_state_dict(sd)
+    out = {}
+    tx = int(batch['tokens_lens'].max())
+    tok = m.tokens_position_emb(m.tokens_emb(batch['tokens']))
+    for stage in (2, 7):
+        y, p = m._prepare_audio_codes(batch['codes'], stage)
+        z, _ = m.transformer(torch.cat([tok, m.audio_position_emb(y)], dim=1),
+                             embedding=m.stage_embs[stage - 1].weight)
+        out[f'logits_{stage}'] = m.proj_layers[stage - 1](z[:, tx + p:][:, ::NAR_BIG_STRIDE])
+        out[f'prefix_{stage}'] = torch.tensor(p)
+    return out
+
+
+def _ref_sampling_filter(ref):
+    """The deterministic part of topk_sampling at top_k > 1 / top_p < 1 (valle/models/utils.py:46-68): the
+    filtered scores that top_k_top_p_filtering hands to multinomial (their -inf pattern = the support) and
+    the log_softmax row the returned log-prob is gathered from."""
+    u = ref['utils']
+    logits, _, _ = sampling_inputs()
+    out = {}
+    real = u.top_k_top_p_filtering
+    for i, (k, p, temp) in enumerate(SAMPLING_FILTERS):
+        seen = []
+
+        def spy(lg, **kw):
+            res = real(lg, **kw)
+            seen.append(res.clone())
+            return res
+        u.top_k_top_p_filtering = spy
+        try:
+            torch.manual_seed(i)
+            tok, lp = u.topk_sampling(logits.clone(), top_k=k, tok_p=p, temperature=temp)
+        finally:
+            u.top_k_top_p_filtering = real
+        filt = seen[0]
+        out[f'keep_{i}'] = torch.isfinite(filt)
+        out[f'logprobs_{i}'] = F.log_softmax(filt, dim=-1)
+        out[f'tok_{i}'] = tok
+        out[f'lp_{i}'] = lp
+    return out
+
+
 def _ref_generate_eos(ref):
     kw, sd, utt = ar_eos_inputs()
     cfg = cfg_of(kw, ref['config'].ConfigValle)
@@ -269,4 +388,9 @@ REFERENCE_RUNNERS = {
     'ar_generate_eos': _ref_generate_eos,
     'nar': _ref_nar,
     'sampling': _ref_sampling,
+    'sampling_filter': _ref_sampling_filter,
+    'ar_generate_full': lambda ref: _ref_generate(ref, 'full'),
+    'ar_prefill_full': _ref_prefill_full,
+    'ar_train_full': _ref_ar_train_full,
+    'nar_big': _ref_nar_big,
 }

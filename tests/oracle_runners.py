@@ -120,7 +120,68 @@ def sampling():
             'best_beam_2': O.get_best_beam(x, lp, 1024, 0.0)}
 
 
+def sampling_filter():
+    logits, _, _ = C.sampling_inputs()
+    out = {}
+    for i, (k, p, temp) in enumerate(C.SAMPLING_FILTERS):
+        filt = O._top_k_top_p_filter(logits / temp, top_k=k, top_p=p)
+        out[f'keep_{i}'] = torch.isfinite(filt)
+        out[f'logprobs_{i}'] = torch.log_softmax(filt, dim=-1)
+        torch.manual_seed(i)
+        out[f'tok_{i}'], out[f'lp_{i}'] = O.topk_sampling(logits.clone(), top_k=k, tok_p=p, temperature=temp)
+    return out
+
+
+ORACLE_FULL_STEPS = 20      # the oracle re-runs the first steps of the 128-step full-size golden (CPU time)
+
+
+def ar_generate_full():
+    kw, sd, utt = C.ar_generate_inputs('full')
+    res = _generate(dict(kw, max_audio_len=ORACLE_FULL_STEPS), sd, utt)
+    return {'tokens': res['tokens'], 'margin': res['margin']}
+
+
+def ar_prefill_full():
+    kw, sd, text, codes, pos = C.ar_prefill_full_inputs()
+    cfg = C.cfg_of(kw)
+    tok = O.add_position(O.embed(sd['tokens_emb.word_embeddings.weight'], text), sd['tokens_position_emb.pe'])
+    aud = O.add_position(O.embed(sd['audio_emb.word_embeddings.weight'], codes), sd['audio_position_emb.pe'])
+    mask = O.build_attn_mask(text.shape[1], codes.shape[1])
+    y, _ = O.transformer(sd, 'transformer.', torch.cat([tok, aud], dim=1), cfg, attn_mask=mask, use_cache=True)
+    return {'logits': torch.nn.functional.linear(y[:, text.shape[1]:][:, pos], sd['proj.weight']),
+            'hidden_last': y[:, -1]}
+
+
+def ar_train_full():
+    kw, sd, batch = C.ar_train_full_inputs()
+    cfg = C.cfg_of(kw)
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    with torch.enable_grad():
+        logits = O.ar_logits(params, cfg, batch)                       # (B, V, Ty)
+        loss = torch.nn.functional.cross_entropy(logits, batch['target'])
+        loss.backward()
+    names = sorted(k for k in params if not k.endswith('.pe'))
+    return {'loss': loss.detach(), 'grad_norms': torch.stack([params[n].grad.norm() for n in names]),
+            'logits_sub': logits.detach().permute(0, 2, 1)[:, ::C.TRAIN_LOGIT_STRIDE].contiguous()}
+
+
+def nar_big():
+    kw, sd, batch = C.nar_big_inputs()
+    cfg = C.cfg_of(kw)
+    out = {}
+    for stage in (2, 7):
+        logits, p = O.nar_stage_logits(sd, cfg, batch, stage)
+        out[f'logits_{stage}'] = logits[:, ::C.NAR_BIG_STRIDE].contiguous()
+        out[f'prefix_{stage}'] = torch.tensor(p)
+    return out
+
+
+# golden keys that a runner reproduces only as a prefix (full-size cases trimmed for CPU time)
+PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin')}
+
 ORACLE_RUNNERS = {
+    'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full,
+    'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
     'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
     'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,
     'ar_generate_eos': ar_generate_eos, 'nar': nar, 'sampling': sampling,

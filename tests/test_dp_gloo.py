@@ -69,6 +69,61 @@ def _reducer_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _branch_worker(rank, world, port, out):
+    """Each rank back-propagates through a DIFFERENT head (as NAR ranks that drew different stages would):
+    different parameters receive gradients on each rank, with one small bucket per parameter.  Buckets must
+    still leave in index order on every rank, so the collectives pair up slice by slice."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dp.init_distributed('gloo')
+    from valle2_amd.optim import flat_layout
+    torch.manual_seed(0)
+    trunk = torch.nn.Linear(6, 8)
+    heads = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])   # equal sizes: a swap would go unnoticed
+    params = list(trunk.parameters()) + list(heads.parameters())
+    slots, total = flat_layout(params)
+    flat = torch.zeros(total)
+    for p, off, n in slots:
+        p.grad = flat[off:off + n].view_as(p)
+    red = dp.GradReducer(flat, slots, bucket_bytes=4)       # every parameter its own bucket
+    order = []
+    launch = red._launch
+    red._launch = lambda b: (order.append(b), launch(b))[1]
+    x = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
+    heads[rank](trunk(x)).square().sum().backward()         # rank 0 trains head 0, rank 1 head 1; head 2 nobody
+    red.finish()
+    ref = {}
+    torch.manual_seed(0)
+    trunk2 = torch.nn.Linear(6, 8)
+    heads2 = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])
+    for r in range(world):
+        for p in list(trunk2.parameters()) + list(heads2.parameters()):
+            p.grad = None
+        heads2[r](trunk2(x)).square().sum().backward()
+        for i, p in enumerate(list(trunk2.parameters()) + list(heads2.parameters())):
+            ref[i] = ref.get(i, 0) + (p.grad if p.grad is not None else torch.zeros_like(p))
+    ok = all(torch.allclose(p.grad, ref[i], atol=1e-6) for i, p in enumerate(params))
+    out.put((rank, order, len(red.buckets), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_launches_buckets_in_index_order_when_ranks_train_different_parameters():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_branch_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, order, n_buckets, ok in res:
+        assert order == list(range(n_buckets)) and n_buckets == 8, (rank, order)
+        assert ok, f'rank {rank}: reduced gradients are not the sum over ranks'
+
+
 def test_grad_reducer_overlapped_buckets_two_ranks():
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')

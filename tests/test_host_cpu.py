@@ -196,3 +196,33 @@ def test_flat_adamw_refuses_cpu_parameters():
     from valle2_amd.optim import FlatAdamW
     with pytest.raises(VhError, match='HIP device'):
         FlatAdamW([torch.nn.Parameter(torch.zeros(4, 4))])
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus N` without a launcher must itself start N ranks (RANK/LOCAL_RANK/WORLD_SIZE/
+    MASTER_* set, one process each) before touching the GPU; under a launcher (WORLD_SIZE set) it must not."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env['VALLE2_BENCH_SPAWN_PROBE'] = '1'
+    out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '3', '--steps', '2'], env=env,
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    ranks = sorted((json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')),
+                   key=lambda r: r['rank'])
+    assert [r['rank'] for r in ranks] == [0, 1, 2] and [r['local'] for r in ranks] == [0, 1, 2]
+    assert all(r['world'] == 3 and r['addr'] == '127.0.0.1' for r in ranks)
+    assert len({r['port'] for r in ranks}) == 1 and all(r['argv'] == ['--gpus', '3', '--steps', '2'] for r in ranks)
+    # under a launcher: one process, the launcher's rank
+    env.update(WORLD_SIZE='8', RANK='5', LOCAL_RANK='5')
+    out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '8'], env=env, capture_output=True,
+                         text=True, timeout=120)
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1 and lines[0]['rank'] == 5 and lines[0]['world'] == 8
+    # default: a single rank, no children
+    env = {k: v for k, v in env.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, str(REPO / 'bench.py')], env=env, capture_output=True, text=True, timeout=120)
+    lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')]
+    assert len(lines) == 1 and lines[0]['world'] == 1 and lines[0]['rank'] == 0

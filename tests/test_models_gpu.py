@@ -44,20 +44,101 @@ def build(cls_name, kw, sd):
     return m.to(DEV).eval()
 
 
-# ---- the reference's own tests, on the device (tests/test_modules.py:7-30) ------------------
+# ---- the reference's own tests, as the reference writes them: CPU module, CPU tensors ---------
 @pytest.mark.parametrize('d_model,n_heads,batch_size,seq_len', C.MHA_SHAPES)
-def test_reference_mha_shape_test(d_model, n_heads, batch_size, seq_len):
+def test_reference_mha_shape_test_with_cpu_tensors(d_model, n_heads, batch_size, seq_len):
+    """Restates /root/reference/tests/test_modules.py:7-30: the module is never moved to a device and
+    the inputs are CPU tensors.  The arithmetic must still be the HIP kernels' (device mirror of the
+    parameters, results copied back): outputs are CPU tensors of the reference's shapes, and equal
+    the same module run on the device."""
     from valle.models.modules import MultiHeadAttention
-    attention = MultiHeadAttention(d_model=d_model, n_heads=n_heads).to(DEV)
+    attention = MultiHeadAttention(d_model=d_model, n_heads=n_heads)
     head_dim = d_model // n_heads
     assert attention.head_dim == head_dim
-    x = torch.randn(batch_size, seq_len, d_model, device=DEV)
-    mask = torch.triu(torch.ones(seq_len, seq_len), diagonal=1).to(DEV)
+    x = torch.randn(batch_size, seq_len, d_model)
+    mask = torch.triu(torch.ones(seq_len, seq_len), diagonal=1)
     output, kv = attention(x, attn_mask=mask, use_cache=True)
     k, v = kv
     assert output.shape == (batch_size, seq_len, d_model)
     assert k.shape == (batch_size, n_heads, seq_len, head_dim)
     assert v.shape == (batch_size, n_heads, seq_len, head_dim)
+    assert not output.is_cuda and not k.is_cuda and not v.is_cuda
+    assert all(not p.is_cuda for p in attention.parameters()), 'the CPU module itself must not move'
+    import copy
+    dev = copy.deepcopy(attention).to(DEV)
+    o2, (k2, v2) = dev(x.to(DEV), attn_mask=mask.to(DEV), use_cache=True)
+    assert torch.equal(output, o2.cpu()) and torch.equal(k, k2.cpu()) and torch.equal(v, v2.cpu())
+    # a cached step on the CPU-resident cache the first call returned (foreign cache → adopted)
+    xn = torch.randn(batch_size, 1, d_model)
+    o3, (k3, _) = attention(xn, kv_cache=(k, v), use_cache=True)
+    assert o3.shape == (batch_size, 1, d_model) and k3.shape == (batch_size, n_heads, seq_len + 1, head_dim)
+    assert torch.equal(k3[:, :, :seq_len], k)
+
+
+def test_cpu_resident_modules_match_reference_golden():
+    """The device round trip carries the reference's numbers: MHA and Transformer goldens with the
+    module and every input on the CPU; the mirror follows a parameter update."""
+    from valle2_amd.modules import MultiHeadAttention, Transformer
+    from valle2_amd.utils import build_attn_mask
+    gold = load_golden('mha')
+    d, h, b, t = C.MHA_SHAPES[0]
+    sd, x, causal, pad = C.mha_inputs(d, h, b, t)
+    m = MultiHeadAttention(d, h).eval()
+    m.load_state_dict(sd)
+    o, (k, v) = m(x, attn_mask=causal, use_cache=True)
+    close(o, gold[f'out_{d}']); close(k, gold[f'k_{d}'])
+    o2, _ = m(x, attn_mask=causal, padding_mask=pad)
+    close(o2, gold[f'out_pad_{d}'])
+    with torch.no_grad():
+        m.out.bias.add_(1.0)                      # in-place update → version bump → mirror rebuilt
+    o3, _ = m(x, attn_mask=causal, use_cache=True)
+    close(o3, gold[f'out_{d}'] + 1.0)
+    tg = load_golden('transformer')
+    kw, sd, x, xl, yl, padm, emb = C.transformer_inputs('AdaptiveLayerNorm')
+    tr = Transformer(C.cfg_of(kw)).eval()
+    tr.load_state_dict(sd)
+    y, kv = tr(x, padding_mask=padm, attn_mask=build_attn_mask(xl, yl, 'cpu'), embedding=emb, use_cache=True)
+    assert not y.is_cuda and len(kv) == kw['num_layers']
+    close(y, tg['AdaptiveLayerNorm_y'])
+
+
+def test_cpu_resident_model_generates_on_the_device():
+    from oracle import valle_oracle as O
+    from valle2_amd import get_model_class, synth
+    kw = dict(C.AR_TINY, max_audio_len=12)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=99, rich=True), cfg)
+    utt = synth.synth_utterance(cfg, 9, 11, 33, seed=4321)
+    trace = {}
+    ref = O.ar_generate(sd, cfg, *utt, trace=trace)
+    m = get_model_class('ValleAR')(cfg).eval()
+    m.load_state_dict(sd)
+    out = m.generate(*utt)                        # model and inputs on the CPU
+    assert not out.is_cuda and m.last_generate_stats['tokens_appended'] == 12
+    tokens_match(out, ref, torch.tensor(trace['margin']))
+    with pytest.raises(Exception, match='HIP device'), torch.enable_grad():
+        m.training_step(synth.synth_ar_batch(cfg, 2, tok_range=(5, 9), code_range=(13, 20), seed=1))
+
+
+def test_tagged_masks_take_the_analytic_kernel_path(monkeypatch):
+    """build_attn_mask + build_pad_mask inputs must reach the kernel as MASK_PREFIX + per-row lengths
+    (no u8 mask tensors), and give the explicit path's result."""
+    from valle2_amd import kernels, modules
+    from valle2_amd.utils import build_attn_mask, build_pad_mask
+    d, h, b, xl, yl = 128, 2, 3, 5, 11
+    m = modules.MultiHeadAttention(d, h).to(DEV).eval()
+    x = torch.randn(b, xl + yl, d, device=DEV)
+    lens = torch.tensor([16, 9, 12])
+    am, pm = build_attn_mask(xl, yl, DEV), build_pad_mask(lens, DEV)
+    seen = []
+    real = kernels.attn_rows
+    monkeypatch.setattr(kernels, 'attn_rows', lambda *a, **k: (seen.append(k), real(*a, **k))[1])
+    o1, _ = m(x, attn_mask=am, padding_mask=pm)
+    assert seen[-1]['mode'] == kernels.MASK_PREFIX and seen[-1]['x_len'] == xl
+    assert seen[-1]['kv_len'].dtype == torch.int32 and seen[-1]['kv_len'].tolist() == lens.tolist()
+    o2, _ = m(x, attn_mask=am.clone(), padding_mask=pm.clone())      # untagged copies → explicit masks
+    assert seen[-1]['mode'] == kernels.MASK_EXPLICIT
+    close(o1, o2.cpu(), atol=1e-6, rtol=1e-6)
 
 
 def test_mha_golden():
@@ -260,11 +341,11 @@ def test_module_level_errors_are_loud():
     from valle2_amd import _lib
     from valle2_amd.modules import FeedForward, MultiHeadAttention
     with pytest.raises(_lib.VhError):
-        MultiHeadAttention(128, 2)(torch.randn(1, 3, 128))          # CPU tensor
-    with pytest.raises(_lib.VhError):
-        FeedForward(128, 512).to(DEV)(torch.randn(1, 3, 128))       # CPU input
-    with pytest.raises(_lib.VhError):
         MultiHeadAttention(128, 4).to(DEV)(torch.randn(1, 3, 128, device=DEV))   # head_dim 32
+    with pytest.raises(_lib.VhError):
+        MultiHeadAttention(128, 4)(torch.randn(1, 3, 128))                       # same, through the mirror
+    y = FeedForward(128, 512).to(DEV)(torch.randn(1, 3, 128))                    # CPU input, device module
+    assert not y.is_cuda and y.shape == (1, 3, 128)
 
 
 def test_generate_batch_ragged_rows_vs_oracle():

@@ -65,8 +65,8 @@ SIGNATURES = {
     'vh_last_error': (C.c_char_p, []),
     'vh_set_tuning': (C.c_int, [C.c_int, C.c_int]),
     'vh_embed_sum_pe': (C.c_int, [c_i64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
-                                  C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                  C.POINTER(C.c_int32), C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     'vh_layernorm': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                C.c_float, C.c_void_p]),
     'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
@@ -107,6 +107,8 @@ SIGNATURES = {
     'vh_sample_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
                                  c_i64p, C.c_int64, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p,
                                  c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    'vh_categorical_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32,
+                                      c_i64p, C.c_int64, c_f32p, C.c_void_p]),
     'vh_adamw_ws_bytes': (C.c_size_t, []),
     'vh_adamw_flat': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
@@ -125,9 +127,9 @@ SIGNATURES = {
                                   C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
     'vh_softmax_bwd': (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int64, C.c_int, C.c_float, C.c_void_p]),
     'vh_cross_entropy': (C.c_int, [c_f32p, C.c_int, C.c_int, c_i64p, c_f32p, c_f32p, C.c_int, C.c_int,
-                                   C.c_void_p]),
+                                   c_i32p, C.c_void_p]),
     'vh_embed_bwd': (C.c_int, [c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int,
-                               C.c_int, C.c_int, C.c_void_p]),
+                               C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     'vh_colsum': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_gemm_batched': (C.c_int, [c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64,
                                   C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
@@ -189,3 +191,38 @@ def ptr(t: torch.Tensor | None) -> int | None:
 
 def stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+# ---- device-side index errors ---------------------------------------------------------------------
+# The gather / scatter / cross-entropy kernels range-check token ids and targets themselves (an id
+# outside its table is read as row 0 or skipped — never an out-of-bounds access) and OR a code into a
+# per-device int32 flag.  The flag is read where the host synchronises anyway (end of generate, the
+# optimizer step, or explicitly) and becomes the IndexError the reference's nn.Embedding /
+# F.cross_entropy would have raised.
+DEVERR_EMBED_ID, DEVERR_TARGET = 1, 2
+_err_flags: dict = {}
+
+
+def err_flag(device) -> torch.Tensor:
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _err_flags:
+        _err_flags[idx] = torch.zeros(1, device=torch.device('cuda', idx), dtype=torch.int32)
+    return _err_flags[idx]
+
+
+def raise_device_errors(device=None):
+    """Synchronises, then raises IndexError if a kernel saw an out-of-range id since the last call."""
+    flags = list(_err_flags.values()) if device is None else [err_flag(device)]
+    for f in flags:
+        code = int(f.item())
+        if code:
+            f.zero_()
+            what = []
+            if code & DEVERR_EMBED_ID:
+                what.append('a token / codec id outside its embedding table (nn.Embedding raises IndexError; '
+                            'e.g. EOS/BOS inside NAR `codes`, a text id >= vocab_size)')
+            if code & DEVERR_TARGET:
+                what.append('a cross-entropy target outside [0, V) (ignore_index is not supported: the collate '
+                            'format pads with 0)')
+            raise IndexError('index out of range on the HIP device: ' + '; '.join(what))

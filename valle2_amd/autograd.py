@@ -252,7 +252,8 @@ class EmbedSumPeFn(torch.autograd.Function):
             g = torch.zeros(shp, device=dout.device, dtype=torch.float32)
             col = ids[..., j]
             check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout),
-                                          dout.stride(0), 0, ptr(g), B, T, d, stream()), 'vh_embed_bwd')
+                                          dout.stride(0), 0, ptr(g), int(shp[0]), B, T, d,
+                                          ptr(_lib.err_flag(dout.device)), stream()), 'vh_embed_bwd')
             grads.append(g)
         return (None, None, None, *grads)
 
@@ -268,7 +269,8 @@ class CrossEntropyFn(torch.autograd.Function):
         dl = torch.empty(R, V, device=logits.device, dtype=torch.float32)
         target = target.contiguous()
         check(_lib.lib().vh_cross_entropy(logits.data_ptr(), logits.stride(0), V, ptr(target), ptr(loss),
-                                          ptr(dl), V, R, stream()), 'vh_cross_entropy')
+                                          ptr(dl), V, R, ptr(_lib.err_flag(logits.device)), stream()),
+              'vh_cross_entropy')
         ctx.save_for_backward(dl)
         return loss
 

@@ -4,6 +4,7 @@
 
 struct TablePtrs {
     const float* t[VH_MAX_TABLES];
+    int vocab[VH_MAX_TABLES];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -13,30 +14,42 @@ struct TablePtrs {
 __global__ __launch_bounds__(256) void embed_sum_pe_kernel(
     const int64_t* __restrict__ ids, int64_t ids_bs, int64_t ids_ts, int64_t ids_js, TablePtrs tabs,
     int n_tables, const float* __restrict__ pe, int pos0, const int32_t* __restrict__ lens,
-    float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d) {
+    float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d, int32_t* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (t >= T) return;
     if (lens && t >= lens[b]) return;
     const int64_t* idp = ids + b * ids_bs + t * ids_ts;
+    // ids are range-checked here (the reference's nn.Embedding raises IndexError): an id outside its
+    // table reads row 0 and raises the device flag the host polls at its next synchronisation
+    int64_t row[VH_MAX_TABLES];
+    bool bad = false;
+    for (int j = 0; j < n_tables; ++j) {
+        const int64_t id = idp[j * ids_js];
+        const bool ok = id >= 0 && id < tabs.vocab[j];
+        bad |= !ok;
+        row[j] = ok ? id : 0;
+    }
+    if (bad && err_flag && lane == 0) atomicOr(err_flag, VH_DEVERR_EMBED_ID);
     float* orow = out + b * out_bs + (int64_t)(out_t0 + t) * d;
     const float* prow = pe ? pe + (int64_t)(pos0 + t) * d : nullptr;
     for (int c = lane * 4; c < d; c += 256) {
         f32x4 acc = prow ? ld4(prow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 e = ld4(tabs.t[0] + idp[0] * d + c);
+        f32x4 e = ld4(tabs.t[0] + row[0] * d + c);
         // sum the codebooks first, then add the position row: same order as the reference
         // (emb0 + emb1 + ... then + pe), so fp32 rounding matches op for op.
-        for (int j = 1; j < n_tables; ++j) e += ld4(tabs.t[j] + idp[j * ids_js] * d + c);
+        for (int j = 1; j < n_tables; ++j) e += ld4(tabs.t[j] + row[j] * d + c);
         st4(orow + c, e + acc);
     }
 }
 
 extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
-                               int64_t ids_jstride, const float* const* tables, int n_tables,
-                               const float* pe, int pos0, const int32_t* lens, float* out,
-                               int64_t out_bstride, int out_t0, int B, int T, int d, void* stream) {
-    VH_REQUIRE(ids && tables && out, VH_EINVAL, "vh_embed_sum_pe: null pointer");
+                               int64_t ids_jstride, const float* const* tables, const int32_t* vocab,
+                               int n_tables, const float* pe, int pos0, const int32_t* lens, float* out,
+                               int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
+                               void* stream) {
+    VH_REQUIRE(ids && tables && vocab && out, VH_EINVAL, "vh_embed_sum_pe: null pointer");
     VH_REQUIRE(n_tables >= 1 && n_tables <= VH_MAX_TABLES, VH_EINVAL,
                "vh_embed_sum_pe: n_tables=%d not in 1..%d", n_tables, VH_MAX_TABLES);
     VH_REQUIRE(B >= 0 && T >= 0 && d > 0 && d % 4 == 0, VH_EINVAL,
@@ -48,12 +61,14 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
     for (int j = 0; j < n_tables; ++j) {
         VH_REQUIRE(tables[j] && vh_aligned16(tables[j]), VH_EALIGN,
                    "vh_embed_sum_pe: table %d null or unaligned", j);
+        VH_REQUIRE(vocab[j] > 0, VH_EINVAL, "vh_embed_sum_pe: table %d has %d rows", j, vocab[j]);
         tp.t[j] = tables[j];
+        tp.vocab[j] = vocab[j];
     }
     dim3 grid((T + 3) / 4, B);
     hipLaunchKernelGGL(embed_sum_pe_kernel, grid, dim3(256), 0, (hipStream_t)stream, ids,
                        ids_bstride, ids_tstride, ids_jstride, tp, n_tables, pe, pos0, lens, out,
-                       out_bstride, out_t0, T, d);
+                       out_bstride, out_t0, T, d, err_flag);
     VH_CHECK_LAUNCH("vh_embed_sum_pe");
     return VH_OK;
 }
@@ -472,5 +487,83 @@ extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int 
                        eos, top_k, top_p, 1.0f / temperature, seed, codes, codes_stride, eos_count,
                        pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, x_next64, d, npow2);
     VH_CHECK_LAUNCH("vh_sample_step");
+    return VH_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Categorical(logits / temperature).sample() per row — the NAR stage sampler (valle/models/valle_nar.py:160)
+// — or the arg-max (lowest index on ties) when `greedy`.  One wave per row, 4 rows per workgroup:
+//   lane l owns the contiguous index range [l*chunk, (l+1)*chunk): row maximum by wave reduction, the
+//   lane's sum of exp(x - max), an inclusive scan over the 64 lane sums (DPP-free shuffles: 6 steps),
+//   u = uniform(seed, row, stream_id) * total picks the lane whose range holds the draw, and that lane walks
+//   its range (inverse CDF in index order).  Also returns log p(token) (tests; optional).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void categorical_rows_kernel(
+    const float* __restrict__ logits, int ld, int V, int rows, float inv_temp, int greedy, uint64_t seed,
+    uint32_t stream_id, int64_t* __restrict__ tokens, int64_t tokens_stride, float* __restrict__ logprob) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* lr = logits + (int64_t)row * ld;
+    const int chunk = (V + 63) / 64;
+    const int i0 = min(V, lane * chunk), i1 = min(V, i0 + chunk);
+    float m = -INFINITY;
+    int am = V;                                         // first index of the lane's maximum
+    for (int i = i0; i < i1; ++i) {
+        const float x = lr[i] * inv_temp;
+        if (x > m) { m = x; am = i; }
+    }
+    const float wm = wave_max(m);
+    if (greedy) {
+        // lowest index among the lanes holding the row maximum (torch.argmax's tie rule)
+        int cand = (m == wm) ? am : V;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
+        if (lane == 0) {
+            tokens[(int64_t)row * tokens_stride] = cand;
+            if (logprob) logprob[row] = 0.f;
+        }
+        return;
+    }
+    float s = 0.f;
+    for (int i = i0; i < i1; ++i) s += expf(lr[i] * inv_temp - wm);
+    float incl = s;                                     // inclusive scan over lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const float up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const float total = __shfl(incl, 63);
+    const float u = uniform01(seed, (uint32_t)row, stream_id) * total;
+    // the first lane whose inclusive sum exceeds u holds the draw (a lane with an empty range never does
+    // unless every later lane is empty too: the last non-empty lane is the fallback for u == total rounding)
+    const unsigned long long hit = __ballot(incl > u && i1 > i0);
+    const unsigned long long nonempty = __ballot(i1 > i0);
+    const int owner = hit ? __ffsll((long long)hit) - 1 : 63 - __clzll((long long)nonempty);
+    if (lane == owner) {
+        float acc = incl - s;
+        int pick = i1 - 1;
+        for (int i = i0; i < i1; ++i) {
+            acc += expf(lr[i] * inv_temp - wm);
+            if (acc > u) { pick = i; break; }
+        }
+        tokens[(int64_t)row * tokens_stride] = pick;
+        if (logprob) logprob[row] = (lr[pick] * inv_temp - wm) - logf(total);
+    }
+}
+
+extern "C" int vh_categorical_rows(const float* logits, int ld, int V, int rows, float temperature, int greedy,
+                                   uint64_t seed, uint32_t stream_id, int64_t* tokens, int64_t tokens_stride,
+                                   float* logprob, void* stream) {
+    VH_REQUIRE(logits && tokens && V > 0 && ld >= V && rows >= 0 && tokens_stride >= 1, VH_EINVAL,
+               "vh_categorical_rows: bad args rows=%d V=%d ld=%d", rows, V, ld);
+    VH_REQUIRE(greedy || temperature > 0.f, VH_EINVAL, "vh_categorical_rows: temperature=%g must be > 0",
+               temperature);
+    if (rows == 0) return VH_OK;
+    hipLaunchKernelGGL(categorical_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                       V, rows, greedy ? 1.0f : 1.0f / temperature, greedy, seed, stream_id, tokens, tokens_stride,
+                       logprob);
+    VH_CHECK_LAUNCH("vh_categorical_rows");
     return VH_OK;
 }

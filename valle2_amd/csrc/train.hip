@@ -256,7 +256,8 @@ extern "C" int vh_softmax_bwd(const float* P, float* dP, int ld, int64_t rows, i
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cross_entropy_kernel(
     const float* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
-    float* __restrict__ loss, float* __restrict__ dlogits, int ldd, float inv_rows, int rows) {
+    float* __restrict__ loss, float* __restrict__ dlogits, int ldd, float inv_rows, int rows,
+    int32_t* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -268,8 +269,13 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(
     for (int j = lane; j < V; j += 64) l += expf(lr[j] - m);
     l = wave_sum(l);
     const float lse = m + logf(l);
-    const int tgt = (int)target[row];
-    if (lane == 0) atomicAdd(loss, (lse - lr[tgt]) * inv_rows);
+    const int64_t t64 = target[row];
+    const bool ok = t64 >= 0 && t64 < V;            // F.cross_entropy raises for a class outside [0, V)
+    const int tgt = ok ? (int)t64 : -1;
+    if (lane == 0) {
+        atomicAdd(loss, (lse - (ok ? lr[tgt] : 0.f)) * inv_rows);
+        if (!ok && err_flag) atomicOr(err_flag, VH_DEVERR_TARGET);
+    }
     if (dlogits) {
         float* dr = dlogits + (int64_t)row * ldd;
         for (int j = lane; j < V; j += 64) dr[j] = (expf(lr[j] - lse) - (j == tgt ? 1.f : 0.f)) * inv_rows;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(
 }
 
 extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
-                                float* dlogits, int ldd, int rows, void* stream) {
+                                float* dlogits, int ldd, int rows, int32_t* err_flag, void* stream) {
     VH_REQUIRE(logits && target && loss && rows > 0 && V > 0 && ld >= V && (!dlogits || ldd >= V),
                VH_EINVAL, "vh_cross_entropy: bad args rows=%d V=%d ld=%d", rows, V, ld);
     hipStream_t st = (hipStream_t)stream;
@@ -286,7 +292,7 @@ extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_
         return VH_ELAUNCH;
     }
     hipLaunchKernelGGL(cross_entropy_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, ld, V, target,
-                       loss, dlogits, ldd, 1.0f / (float)rows, rows);
+                       loss, dlogits, ldd, 1.0f / (float)rows, rows, err_flag);
     VH_CHECK_LAUNCH("vh_cross_entropy");
     return VH_OK;
 }
@@ -297,24 +303,30 @@ extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t ids_bs,
                                                         int64_t ids_ts, const float* __restrict__ dout,
                                                         int64_t dout_bs, int t0, float* __restrict__ dtable,
-                                                        int T, int d) {
+                                                        int vocab, int T, int d,
+                                                        int32_t* __restrict__ err_flag) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (t >= T) return;
     const int64_t id = ids[b * ids_bs + t * ids_ts];
+    if (id < 0 || id >= vocab) {                    // never scatter outside the table
+        if (err_flag && lane == 0) atomicOr(err_flag, VH_DEVERR_EMBED_ID);
+        return;
+    }
     const float* src = dout + b * dout_bs + (int64_t)(t0 + t) * d;
     float* dst = dtable + id * d;
     for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c]);
 }
 
 extern "C" int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
-                            const float* dout, int64_t dout_bstride, int out_t0, float* dtable, int B,
-                            int T, int d, void* stream) {
-    VH_REQUIRE(ids && dout && dtable && B >= 0 && T >= 0 && d > 0, VH_EINVAL, "vh_embed_bwd: bad args");
+                            const float* dout, int64_t dout_bstride, int out_t0, float* dtable, int vocab,
+                            int B, int T, int d, int32_t* err_flag, void* stream) {
+    VH_REQUIRE(ids && dout && dtable && vocab > 0 && B >= 0 && T >= 0 && d > 0, VH_EINVAL,
+               "vh_embed_bwd: bad args");
     if (B == 0 || T == 0) return VH_OK;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, ids,
-                       ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, T, d);
+                       ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, vocab, T, d, err_flag);
     VH_CHECK_LAUNCH("vh_embed_bwd");
     return VH_OK;
 }

@@ -85,10 +85,13 @@ class GradReducer:
 
     `slots` = [(param, offset, numel)] laid out in the order backward produces gradients
     (`optim.flat_layout`).  The buffer is cut into buckets of about `bucket_bytes` on parameter
-    boundaries; a post-accumulate hook on every parameter counts arrivals and, when a bucket is
-    complete, starts its all-reduce asynchronously on the communicator's stream while backward keeps
-    computing the earlier layers.  `finish()` starts whatever is left (parameters that received no
-    gradient), waits, and returns; the 1/world mean is left to the optimizer kernel (`grad_scale`).
+    boundaries; a post-accumulate hook on every parameter counts arrivals and starts a bucket's
+    all-reduce asynchronously on the communicator's stream while backward keeps computing the earlier
+    layers.  Buckets are launched STRICTLY IN INDEX ORDER (bucket b only after b-1, as DDP does): which
+    parameters receive a gradient can differ between ranks (NAR trains one randomly drawn stage per
+    step), and collectives issued in different orders on different ranks would pair mismatched slices
+    or hang.  `finish()` starts whatever is left (parameters that received no gradient), in order,
+    waits, and returns; the 1/world mean is left to the optimizer kernel (`grad_scale`).
     Few large messages: xGMI is point-to-point, 7 links per GPU, so a bucket is sized per link
     (64 MB default ≈ 3 buckets for the 156 MB AR model), not for a switch.
     """
@@ -115,6 +118,7 @@ class GradReducer:
             self.buckets[-1] = (s0, flat_grad.numel(), c0)
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._next = 0                 # first bucket not launched yet
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p, _, _ in slots]
 
     @property
@@ -132,22 +136,22 @@ class GradReducer:
         if p.grad is not None and p.grad.data_ptr() != view.data_ptr():   # autograd replaced the view
             view.copy_(p.grad)
             p.grad = view
-        b = self.bucket_of[id(p)]
-        self._arrived[b] += 1
-        if self._arrived[b] == self.buckets[b][2] and self._work[b] is None:
-            self._launch(b)
+        self._arrived[self.bucket_of[id(p)]] += 1
+        while self._next < len(self.buckets) and self._arrived[self._next] == self.buckets[self._next][2]:
+            self._launch(self._next)
+            self._next += 1
 
     def finish(self):
         """Call after backward of the last micro-batch: every bucket reduced when this returns (on
         the current stream for NCCL/RCCL)."""
         if self.active:
-            for b in range(len(self.buckets)):
-                if self._work[b] is None:
-                    self._launch(b)
+            for b in range(self._next, len(self.buckets)):
+                self._launch(b)
             for w in self._work:
                 w.wait()
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._next = 0
 
     def remove(self):
         for h in self._hooks:

@@ -40,12 +40,35 @@ def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None):
         raise _lib.VhError(f'out shape {tuple(out.shape)} does not fit B={B} T={T} d={d} t0={out_t0}')
     if pe is not None and pos0 + T > pe.shape[0]:
         raise _lib.VhError(f'position {pos0 + T} exceeds the table ({pe.shape[0]})')
+    if not ids.is_cuda:
+        raise _lib.VhError('embed_sum_pe: ids must be on the HIP device')
+    if any(t.dim() != 2 or t.shape[1] != d for t in tables):
+        raise _lib.VhError('embed_sum_pe: every table must be (vocab, d)')
     arr = (C.c_void_p * n)(*[ptr(_f32(t, 'table')) for t in tables])
+    vocab = (C.c_int32 * n)(*[int(t.shape[0]) for t in tables])    # ids are range-checked in the kernel
     check(_lib.lib().vh_embed_sum_pe(
-        ids.data_ptr(), ids.stride(0), ids.stride(1), ids.stride(2), arr, n,
+        ids.data_ptr(), ids.stride(0), ids.stride(1), ids.stride(2), arr, vocab, n,
         ptr(_f32(pe, 'pe')), pos0, ptr(lens), ptr(_f32(out, 'out')), out.stride(0), out_t0,
-        B, T, d, stream()), 'vh_embed_sum_pe')
+        B, T, d, ptr(_lib.err_flag(out.device)), stream()), 'vh_embed_sum_pe')
     return out
+
+
+def ids_to_device(ids, device, vocab, what):
+    """Token ids → `device`.  Ids still on the host are range-checked here, before they travel (the
+    reference's nn.Embedding raises IndexError); device-resident ids are checked by the kernels
+    (`_lib.raise_device_errors`)."""
+    if not ids.is_cuda and ids.numel():
+        lo, hi = int(ids.min()), int(ids.max())
+        if lo < 0 or hi >= vocab:
+            raise IndexError(f'{what}: id {lo if lo < 0 else hi} is outside [0, {vocab}) (index out of range)')
+    return ids.to(device)
+
+
+def _dev_f32(t, name):
+    """data_ptr of a row-major fp32 DEVICE tensor (a host pointer handed to a kernel is a fault)."""
+    if not t.is_cuda:
+        raise _lib.VhError(f'{name} is on {t.device}: kernels take HIP device tensors only')
+    return _f32(t, name).data_ptr()
 
 
 def layernorm(x, gamma, beta, out=None, ada_scale=None, ada_shift=None, eps=1e-5):
@@ -84,10 +107,10 @@ def linear(a, w, bias=None, residual=None, out=None, act=ACT_NONE, ln=None):
         raise _lib.VhError('linear: residual shape')
     g, b, sc, sh, eps = _ln_args(ln)
     check(_lib.lib().vh_linear(
-        _f32(a, 'a').data_ptr(), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
-        residual.data_ptr() if residual is not None else None,
+        _dev_f32(a, 'a'), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+        _dev_f32(residual, 'residual') if residual is not None else None,
         residual.stride(0) if residual is not None else 0,
-        _f32(out, 'out').data_ptr(), out.stride(0), M, N, K, act, g, b, sc, sh, eps, stream()),
+        _dev_f32(out, 'out'), out.stride(0), M, N, K, act, g, b, sc, sh, eps, stream()),
         'vh_linear')
     return out
 
@@ -95,17 +118,29 @@ def linear(a, w, bias=None, residual=None, out=None, act=ACT_NONE, ln=None):
 def linear_ws(a, w, bias=None, residual=None, out=None, act=ACT_NONE, workspace=None):
     """vh_linear_ws: split-K path for wide K (see include/valle_hip.h)."""
     M, K = a.shape
-    N = w.shape[0]
+    N, K2 = w.shape
+    if K != K2:
+        raise _lib.VhError(f'linear_ws: K mismatch {K} vs {K2}')
+    if a.stride(1) != 1 or not w.is_contiguous():
+        raise _lib.VhError('linear_ws: operands must be row-major')
     if out is None:
         out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
+    if tuple(out.shape) != (M, N) or out.stride(1) != 1:
+        raise _lib.VhError(f'linear_ws: out must be a row-major ({M},{N}) tensor')
+    if bias is not None and bias.numel() != N:
+        raise _lib.VhError('linear_ws: bias size')
+    if residual is not None and (tuple(residual.shape) != (M, N) or residual.stride(1) != 1):
+        raise _lib.VhError('linear_ws: residual shape')
     need = _lib.lib().vh_linear_ws_bytes(M, N, K)
     if workspace is None and need:
         workspace = torch.empty(need // 4, device=a.device, dtype=torch.float32)
+    if need and workspace.numel() * 4 < need:
+        raise _lib.VhError(f'linear_ws: workspace of {workspace.numel() * 4} B < {need} B')
     check(_lib.lib().vh_linear_ws(
-        _f32(a, 'a').data_ptr(), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
-        residual.data_ptr() if residual is not None else None,
+        _dev_f32(a, 'a'), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+        _dev_f32(residual, 'residual') if residual is not None else None,
         residual.stride(0) if residual is not None else 0,
-        out.data_ptr(), out.stride(0), M, N, K, act, ptr(workspace),
+        _dev_f32(out, 'out'), out.stride(0), M, N, K, act, ptr(workspace),
         workspace.numel() * 4 if workspace is not None else 0, stream()), 'vh_linear_ws')
     return out
 
@@ -217,12 +252,12 @@ def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_d
         if tuple(lse2.shape) != (B, n_heads, Tq) or lse2.dtype != torch.float32:
             raise _lib.VhError('attn_rows: lse2 must be float32 (B, n_heads, Tq)')
         check(_lib.lib().vh_attn_rows_lse(
-            q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0), B,
+            _dev_f32(q, 'q'), q.stride(0), ptr(kcache), ptr(vcache), _dev_f32(out, 'out'), out.stride(0), B,
             n_heads, Tq, Tk, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
             ptr(lse2), stream()), 'vh_attn_rows_lse')
         return out
     check(_lib.lib().vh_attn_rows(
-        q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0), B,
+        _dev_f32(q, 'q'), q.stride(0), ptr(kcache), ptr(vcache), _dev_f32(out, 'out'), out.stride(0), B,
         n_heads, Tq, Tk, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
         stream()), 'vh_attn_rows')
     return out
@@ -291,6 +326,21 @@ def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_coun
         int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
         ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next),
         B, d, stream()), 'vh_sample_step')
+
+
+def categorical_rows(logits, tokens, temperature=1.0, greedy=False, seed=0, stream_id=0, logprob=None):
+    """tokens[r] ~ Categorical(logits[r] / temperature) (valle_nar.py:160) or arg-max when greedy.
+    logits (R, V) row-major (any row stride); tokens: int64 (R,) view with any element stride."""
+    R, V = logits.shape
+    if logits.stride(1) != 1 or tokens.dtype != torch.int64 or tokens.dim() != 1 or tokens.shape[0] != R:
+        raise _lib.VhError(f'categorical_rows: logits {tuple(logits.shape)} / tokens {tuple(tokens.shape)} {tokens.dtype}')
+    if not tokens.is_cuda or (logprob is not None and (logprob.numel() != R or not logprob.is_contiguous())):
+        raise _lib.VhError('categorical_rows: tokens / logprob must be device tensors of R entries')
+    check(_lib.lib().vh_categorical_rows(_dev_f32(logits, 'logits'), logits.stride(0), V, R, float(temperature),
+                                         int(bool(greedy)), int(seed) & (2 ** 64 - 1), int(stream_id) & 0xFFFFFFFF,
+                                         tokens.data_ptr(), tokens.stride(0) if R > 1 else 1, ptr(logprob),
+                                         stream()), 'vh_categorical_rows')
+    return tokens
 
 
 def gemm(a, b, out, a_kmajor=False, b_kmajor=False):

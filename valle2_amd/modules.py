@@ -2,7 +2,10 @@
 keys (valle/models/modules.py:11-352), computing on MI355X through libvalle_hip.so.
 
 These classes are parameter holders plus pointer plumbing: every forward runs HIP kernels on the
-current stream.  CPU tensors are rejected loudly (no CPU fallback; the CPU oracle lives in oracle/
+current stream.  There is no CPU arithmetic: a module that lives on the CPU (as the reference's own
+tests build it, tests/test_modules.py:15-30) keeps a device mirror of its parameters, CPU inputs are
+copied to the HIP device, the same kernels run there and the results are copied back (`_on_device`);
+without a HIP device or the built library the call raises `VhError` (the CPU oracle lives in oracle/
 and is test-only).  Only `merge_masks` — bool/int mask plumbing the reference's own tests call on
 CPU tensors — is device-agnostic host logic.
 
@@ -14,6 +17,9 @@ No (B,h,T,T) tensor is ever built on the compute path.
 """
 from __future__ import annotations
 
+import copy
+import functools
+
 import torch
 import torch.nn as nn
 from einops import rearrange, repeat
@@ -21,14 +27,94 @@ from einops import rearrange, repeat
 from . import _lib, kernels
 from .engine import KVCache, transformer_forward
 from .synth import sinusoid_table
+from .utils import pad_lens_for_kernel
 
 HEAD_DIM = kernels.HEAD_DIM
 
 
-def _need_device(t: torch.Tensor, what: str):
-    if not t.is_cuda:
-        raise _lib.VhError(f'{what}: got a {t.device} tensor. valle2_amd computes on a HIP device only; '
-                           f'move the module and inputs to "cuda" (no CPU fallback exists).')
+_TAGS = ('_vh_prefix', '_vh_lens_host', '_vh_cache')
+
+
+def _move(obj, device, keep_cache_tag):
+    """Tensors (also inside tuples / lists) → `device`; mask tags travel with the copy, the KV
+    bookkeeping tag only between device tensors (a CPU copy of a cache is a foreign cache)."""
+    if isinstance(obj, torch.Tensor):
+        if obj.device == device:
+            return obj
+        new = obj.to(device)
+        for tag in _TAGS[: 3 if keep_cache_tag else 2]:
+            if hasattr(obj, tag):
+                setattr(new, tag, getattr(obj, tag))
+        return new
+    if isinstance(obj, (tuple, list)):
+        return type(obj)(_move(o, device, keep_cache_tag) for o in obj)
+    return obj
+
+
+def _first_tensor(objs):
+    for o in objs:
+        if isinstance(o, torch.Tensor):
+            return o
+        if isinstance(o, (tuple, list)):
+            t = _first_tensor(o)
+            if t is not None:
+                return t
+    return None
+
+
+def compute_device() -> torch.device:
+    """The HIP device every forward runs on; raises when there is none (never a CPU fallback)."""
+    _lib.lib()                                   # VhError without the built library / a HIP device
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def device_mirror(module: nn.Module) -> nn.Module:
+    """`module` itself when it lives on a HIP device, else a copy of it on the HIP device, cached on the
+    module and rebuilt when a parameter, a buffer or the train/eval flag changed."""
+    probe = next(module.parameters(), None)
+    if probe is None:
+        probe = next(module.buffers(), None)
+    if probe is None or probe.is_cuda:           # modules are placed as a whole (nn.Module.to)
+        return module
+    state = list(module.parameters()) + list(module.buffers())
+    key = (module.training,) + tuple((id(t), t._version) for t in state)
+    cached = module.__dict__.get('_vh_mirror')
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    module.__dict__.pop('_vh_mirror', None)
+    mirrors = {}
+    for sub in module.modules():                 # do not deep-copy stale mirrors of sub-modules
+        if '_vh_mirror' in sub.__dict__:
+            mirrors[sub] = sub.__dict__.pop('_vh_mirror')
+    try:
+        dev = copy.deepcopy(module).to(compute_device())
+    finally:
+        for sub, m in mirrors.items():
+            sub.__dict__['_vh_mirror'] = m
+    dev.train(module.training)
+    module.__dict__['_vh_mirror'] = (key, dev)
+    return dev
+
+
+def _on_device(forward):
+    """Run `forward` on the HIP device whatever device the module and its inputs live on: CPU inputs
+    are copied over, a CPU module computes through its device mirror, results return to the device of
+    the first input.  The arithmetic is always the HIP kernels'."""
+    @functools.wraps(forward)
+    def wrapper(self, *args, **kwargs):
+        first = _first_tensor(list(args) + list(kwargs.values()))
+        target = device_mirror(self)
+        if target is self and (first is None or first.is_cuda):
+            return forward(self, *args, **kwargs)
+        dev = compute_device()
+        home = first.device if first is not None else dev
+        args = _move(args, dev, True)
+        kwargs = {k: _move(v, dev, True) for k, v in kwargs.items()}
+        out = forward(target, *args, **kwargs)
+        if target is not self and hasattr(target, 'last_generate_stats'):
+            self.last_generate_stats = target.last_generate_stats
+        return _move(out, home, home.type == 'cuda')
+    return wrapper
 
 
 def _drop(module: nn.Dropout, x):
@@ -53,8 +139,8 @@ class TokenEmbedding(nn.Module):
     def embedding(self, index: int) -> torch.Tensor:
         return self.word_embeddings.weight[index: index + 1]
 
+    @_on_device
     def forward(self, x: torch.Tensor):
-        _need_device(x, 'TokenEmbedding')
         ids = x.reshape(-1, x.shape[-1]) if x.dim() > 1 else x.reshape(1, -1)
         out = torch.empty(*ids.shape, self.dim_model, device=x.device, dtype=torch.float32)
         kernels.embed_sum_pe(ids, [self.weight.detach()], None, 0, out)
@@ -69,8 +155,8 @@ class PositionalEncoding(nn.Module):
         self.dropout = nn.Dropout(p=dropout)
         self.register_buffer('pe', sinusoid_table(d_model, max_len))
 
+    @_on_device
     def forward(self, x):
-        _need_device(x, 'PositionalEncoding')
         b, t, c = x.shape
         if t > self.pe.shape[0]:
             raise _lib.VhError(f'sequence length {t} exceeds max_len {self.pe.shape[0]}')
@@ -97,8 +183,8 @@ class AdaptiveLayerNorm(nn.Module):
         wb = wb.contiguous().view(2, d)
         return wb[0], wb[1]
 
+    @_on_device
     def forward(self, x: torch.Tensor, embedding: torch.Tensor) -> torch.Tensor:
-        _need_device(x, 'AdaptiveLayerNorm')
         sc, sh = self.scale_shift(embedding)
         return kernels.layernorm(x.contiguous(), self.norm.weight.detach(), self.norm.bias.detach(),
                                  ada_scale=sc, ada_shift=sh, eps=self.eps)
@@ -107,8 +193,8 @@ class AdaptiveLayerNorm(nn.Module):
 class _HipLayerNorm(nn.LayerNorm):
     """nn.LayerNorm parameters (same state_dict keys), forward on the HIP kernel."""
 
+    @_on_device
     def forward(self, x):
-        _need_device(x, 'LayerNorm')
         return kernels.layernorm(x.contiguous(), self.weight.detach(), self.bias.detach(), eps=self.eps)
 
 
@@ -132,7 +218,11 @@ def _mask_spec(attn_mask, padding_mask, tq, tk, device):
     if attn_mask is None:
         # reference defect D6: key padding is dropped when no attn_mask is given
         return dict(mode=kernels.MASK_FULL)
-    lens = getattr(padding_mask, '_vh_lens', None) if padding_mask is not None else None
+    # masks from utils.build_attn_mask / build_pad_mask carry their defining lengths: evaluate them
+    # analytically in the kernel (a build_pad_mask of full width T means keys >= lens[b] are masked)
+    lens = None
+    if padding_mask is not None and padding_mask.dim() == 2 and padding_mask.shape[1] == tk:
+        lens = pad_lens_for_kernel(padding_mask, 0, device)
     tag = getattr(attn_mask, '_vh_prefix', None)
     if tag is not None and tag[0] + tag[1] == tq == tk and (padding_mask is None or lens is not None):
         return dict(mode=kernels.MASK_PREFIX, x_len=tag[0], kv_len=lens)
@@ -159,11 +249,11 @@ class MultiHeadAttention(nn.Module):
         self.qkv = nn.Linear(d_model, 3 * d_model, bias=False)
         self.out = nn.Linear(d_model, d_model)
 
+    @_on_device
     def forward(self, x, *, attn_mask=None, padding_mask=None, kv_cache=None, use_cache=False,
                 _ln=None, _residual=None):
         """x (B, n, d) → (out (B, n, d), (k, v) | None) with k, v of shape (B, h, S, hd).
         `_ln` / `_residual` are internal fusion hooks used by EncoderLayer."""
-        _need_device(x, 'MultiHeadAttention')
         if self.head_dim != HEAD_DIM:
             raise _lib.VhError(f'head_dim {self.head_dim} unsupported: the kernels are built for 64')
         b, n, d = x.shape
@@ -240,8 +330,8 @@ class FeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.linear_2 = nn.Linear(d_ff, d_model)
 
+    @_on_device
     def forward(self, x, _ln=None, _residual=None):
-        _need_device(x, 'FeedForward')
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         if not x2.is_contiguous():
@@ -284,9 +374,9 @@ class EncoderLayer(nn.Module):
         sc, sh = norm.scale_shift(embedding)
         return (norm.norm.weight.detach(), norm.norm.bias.detach(), sc, sh, norm.eps)
 
+    @_on_device
     def forward(self, x, *, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
                 use_cache=False):
-        _need_device(x, 'EncoderLayer')
         fuse1 = not (self.dropout1.training and self.dropout1.p > 0)
         fuse2 = not (self.dropout2.training and self.dropout2.p > 0)
         x_attn, next_kv = self.self_attn(x, attn_mask=attn_mask, padding_mask=padding_mask,
@@ -316,9 +406,9 @@ class Transformer(nn.Module):
     def _any_dropout(self):
         return self.training and self.hparams.dropout > 0
 
+    @_on_device
     def forward(self, x, *, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
                 use_cache=False):
-        _need_device(x, 'Transformer')
         new_kv: tuple = ()
         if use_cache and kv_cache is not None:
             x = x[:, -1:]

@@ -91,6 +91,9 @@ class FlatAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise _lib.VhError('FlatAdamW.step: closures are not supported')
         self.gather_grads()
+        # ids / targets already resident on the device are range-checked by the kernels: a bad one must not
+        # reach the parameters (one host read of a 4-byte flag per step; backward has finished by now)
+        _lib.raise_device_errors(self.flat_param.device)
         g = self.param_groups[0]
         lib = _lib.lib()
         if self._ws is None:

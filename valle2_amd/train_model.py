@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import argparse
 import os
+import random
 import time
 from pathlib import Path
 
@@ -42,6 +43,8 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
         torch.cuda.set_device(device)
     rank, world = dp.init_distributed(device=device if device.type == 'cuda' else None)
     torch.manual_seed(config.seed)                       # identical initial weights on every rank
+    random.seed(config.seed)                             # and the same NAR stage draw (valle_nar.py:76) on every rank:
+    #                                                      the reference calls seed_everything (train_model.py:15)
     model = get_model_class(model_name)(config).to(device).train()
     opt = model.configure_optimizers()                   # FlatAdamW + CosineAnnealingWarmRestarts
     optimizer, scheduler = opt['optimizer'], opt['lr_scheduler']
@@ -51,23 +54,32 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
         batches = synthetic_batches(model_name, config, rank, world, config.max_steps * accum)
     step, t0, losses = 0, time.perf_counter(), []
     optimizer.zero_grad()
-    for i, batch in enumerate(batches):
-        last = (i + 1) % accum == 0
-        reducer.enabled = last                           # accumulate locally, exchange once per step
-        loss = model.training_step(batch)
-        (loss / accum).backward()                        # buckets are all-reduced as they complete
-        losses.append(float(loss.detach()))
-        if not last:
-            continue
-        reducer.finish()
-        # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
-        optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
+    one_shot = iter(batches) is batches                  # a generator: a single epoch, then stop
+    while step < config.max_steps:
+        seen = 0
+        for i, batch in enumerate(batches):
+            seen += 1
+            last = (i + 1) % accum == 0
+            reducer.enabled = last                       # accumulate locally, exchange once per step
+            loss = model.training_step(batch)
+            (loss / accum).backward()                    # buckets are all-reduced as they complete
+            losses.append(float(loss.detach()))
+            if not last:
+                continue
+            reducer.finish()
+            # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
+            optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
+            step += 1
+            if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
+                log(f'step {step}: train/loss {sum(losses[-accum:]) / accum:.4f} '
+                    f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
+            if step >= config.max_steps:
+                break
+        # Lightning steps a scheduler returned without an 'interval' once per EPOCH (the reference's
+        # configure_optimizers returns {'optimizer', 'lr_scheduler'} only, valle_ar.py:182-194): T_0 =
+        # lr_warmup counts epochs there, so it does here.
         scheduler.step()
-        step += 1
-        if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
-            log(f'step {step}: train/loss {sum(losses[-accum:]) / accum:.4f} '
-                f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
-        if step >= config.max_steps:
+        if one_shot or seen == 0:
             break
     return model, losses
 

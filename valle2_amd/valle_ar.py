@@ -15,7 +15,7 @@ from torch import optim
 
 from . import _lib, kernels
 from .engine import ArDecoder, ForwardScratch, KVCache, transformer_forward
-from .modules import PositionalEncoding, TokenEmbedding, Transformer
+from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device, device_mirror
 from .utils import get_best_beam
 
 try:  # the reference subclasses lightning.LightningModule; lightning is optional here
@@ -70,14 +70,15 @@ class ValleAR(_Base):
         kernels.embed_sum_pe(codes_ids, [self.audio_emb.weight.detach()], self.audio_position_emb.pe,
                              0, x, out_t0=x_t0 + tx)
 
+    @_on_device
     def forward_logits(self, batch):
         """Teacher-forced logits (B, Ty, V_a+1) of valle_ar.py:54-83 (row-major, before the
-        reference's rearrange to (B, V, Ty))."""
+        reference's rearrange to (B, V, Ty)).  A model that lives on the CPU computes through its
+        device mirror (modules.device_mirror); the logits stay on the HIP device."""
         self._require_layernorm()
         dev = self.device
-        if dev.type != 'cuda':
-            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
-        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        tokens = kernels.ids_to_device(batch['tokens'], dev, self.config.vocab_size, 'tokens')
+        codes = kernels.ids_to_device(batch['codes'], dev, self.config.num_audio_tokens + 2, 'codes')
         codes_lens = batch['codes_lens']
         tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
         b = tokens.shape[0]
@@ -99,8 +100,10 @@ class ValleAR(_Base):
         self._require_layernorm()
         dev = self.device
         if dev.type != 'cuda':
-            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
-        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+            raise _lib.VhError('ValleAR.training_step with gradients needs the model on its HIP device '
+                               '(model.to("cuda")): gradients cannot flow into a CPU copy of the parameters')
+        tokens = kernels.ids_to_device(batch['tokens'], dev, self.config.vocab_size, 'tokens')
+        codes = kernels.ids_to_device(batch['codes'], dev, self.config.num_audio_tokens + 2, 'codes')
         codes_lens = batch['codes_lens']
         tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
         b, d = tokens.shape[0], self.config.d_model
@@ -124,17 +127,18 @@ class ValleAR(_Base):
         row kernels + library GEMMs, valle2_amd/autograd.py); under no_grad it takes the fused
         inference kernels."""
         from . import autograd as A
-        target = batch['target'].to(self.device)
         if torch.is_grad_enabled():
             logits = self._logits_with_graph(batch)
         else:
             logits = self.forward_logits(batch)
+        target = kernels.ids_to_device(batch['target'], logits.device, self.config.num_audio_tokens + 1, 'target')
         rows = logits.shape[0] * logits.shape[1]
         loss = A.CrossEntropyFn.apply(logits.reshape(rows, -1), target[:, : logits.shape[1]].reshape(rows))
         self.log('train/loss', loss)
         return loss
 
     # ------------------------------------------------------------------------------------
+    @_on_device
     @torch.inference_mode()
     def generate(self, prompt_tokens, prompt_codes, target_tokens=None):
         """valle_ar.py:92-180 — one utterance replicated over `num_beams` rows; returns the 1-D
@@ -153,6 +157,7 @@ class ValleAR(_Base):
         best = best[prompt_len:]
         return best[best != self.eos_token]
 
+    @_on_device
     @torch.inference_mode()
     def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False):
         """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
@@ -169,8 +174,6 @@ class ValleAR(_Base):
             raise NotImplementedError('use_kv_cache=False is broken in the reference (D2); '
                                       'the HIP path always uses its in-place cache')
         dev = self.device
-        if dev.type != 'cuda':
-            raise _lib.VhError('ValleAR is on the CPU; move it to a HIP device (no CPU fallback)')
         B = len(texts)
         if B == 0 or len(first_codes) != B:
             raise ValueError('generate_batch: texts and first_codes must be non-empty lists of equal length')
@@ -191,9 +194,13 @@ class ValleAR(_Base):
         # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None).  Row b is laid
         # out [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.
         cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # prefill | decode phase times
+        marks[0].record()
+        texts = [kernels.ids_to_device(t, dev, cfg.vocab_size, 'text ids') for t in texts]
+        first_codes = [kernels.ids_to_device(c, dev, cfg.num_audio_tokens, 'prompt codes') for c in first_codes]
         if not ragged:
-            text_ids = torch.stack([t.to(dev) for t in texts])
-            codes[:, 1:pl_max] = torch.stack([c.to(dev) for c in first_codes])
+            text_ids = torch.stack(texts)
+            codes[:, 1:pl_max] = torch.stack(first_codes)
             x = torch.empty(B, s0, d, device=dev, dtype=torch.float32)
             self._embed_rows(text_ids, codes[:, :pl_max], x)
             fwd = dict(x_len=txs[0])
@@ -201,8 +208,8 @@ class ValleAR(_Base):
         else:
             x = torch.zeros(B, s0, d, device=dev, dtype=torch.float32)
             for b in range(B):
-                codes[b, 1:pls[b]] = first_codes[b].to(dev)
-                self._embed_rows(texts[b].to(dev).unsqueeze(0), codes[b:b + 1, :pls[b]], x[b:b + 1])
+                codes[b, 1:pls[b]] = first_codes[b]
+                self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :pls[b]], x[b:b + 1])
             lens = torch.tensor([t + p for t, p in zip(txs, pls)], **i32)
             fwd = dict(x_len_dev=torch.tensor(txs, **i32), kv_len=lens)
         transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
@@ -218,6 +225,7 @@ class ValleAR(_Base):
                         seed=seed)
         try:
             dec.sample_from(last.contiguous())
+            marks[1].record()
             del x, last
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
             done, stop = 1, None
@@ -233,11 +241,16 @@ class ValleAR(_Base):
                 if full.numel():
                     stop = int(full[0])
                     break
+            marks[2].record()
             if stop is None:
                 full = (dec.eos_count[:done] == B).nonzero()
                 stop = int(full[0]) if full.numel() else None
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
+            marks[2].synchronize()
+            _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
+                                        'prefill_ms': marks[0].elapsed_time(marks[1]),
+                                        'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
                                         'attn_kernel_ms': attn_kernel_ms, 's0': s0,
                                         'prompt_lens': pls,

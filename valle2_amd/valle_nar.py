@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from . import _lib, kernels
 from .engine import ForwardScratch, KVCache, transformer_forward
-from .modules import PositionalEncoding, TokenEmbedding, Transformer
+from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device
 from .valle_ar import _Base
 
 
@@ -43,8 +43,9 @@ class ValleNAR(_Base):
 
     def _dev(self):
         dev = self.device
-        if dev.type != 'cuda':
-            raise _lib.VhError('ValleNAR is on the CPU; move it to a HIP device (no CPU fallback)')
+        if dev.type != 'cuda':     # inference entry points never get here (they run on the device mirror)
+            raise _lib.VhError('ValleNAR.training_step with gradients needs the model on its HIP device '
+                               '(model.to("cuda")): gradients cannot flow into a CPU copy of the parameters')
         return dev
 
     def _tables(self, n):
@@ -66,22 +67,25 @@ class ValleNAR(_Base):
                                  out_t0=out_t0 + p)
         return p
 
+    @_on_device
     def _prepare_audio_codes(self, codes: torch.Tensor, nar_stage: int):
         """valle_nar.py:167-188 → ((B, T, d) embedding sum without position, prefix_len)."""
         dev = self._dev()
-        codes = codes.to(dev)
+        codes = kernels.ids_to_device(codes, dev, self.config.num_audio_tokens, 'codes')
         b, t, _ = codes.shape
         y = torch.empty(b, t, self.config.d_model, device=dev, dtype=torch.float32)
         p = self._embed_audio(codes, nar_stage, y, 0, None)
         return y, p
 
+    @_on_device
     def stage_logits(self, batch, stage: int):
         """Intended forward of valle_nar.py:71-100 for `stage` in 1..Q-1: logits (B, T-prefix, V_a)
         of codebook `stage` for the non-prefix frames.  Full attention; key padding is dropped
         exactly as the reference's Transformer does when attn_mask is None (defect D6)."""
         dev = self._dev()
         cfg = self.config
-        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        tokens = kernels.ids_to_device(batch['tokens'], dev, cfg.vocab_size, 'tokens')
+        codes = kernels.ids_to_device(batch['codes'], dev, cfg.num_audio_tokens, 'codes (EOS/BOS have no codebook row)')
         tx = int(batch['tokens_lens'].max())
         b, t, _ = codes.shape
         d = cfg.d_model
@@ -101,7 +105,8 @@ class ValleNAR(_Base):
         from . import autograd as A
         dev = self._dev()
         cfg = self.config
-        tokens, codes = batch['tokens'].to(dev), batch['codes'].to(dev)
+        tokens = kernels.ids_to_device(batch['tokens'], dev, cfg.vocab_size, 'tokens')
+        codes = kernels.ids_to_device(batch['codes'], dev, cfg.num_audio_tokens, 'codes (EOS/BOS have no codebook row)')
         tx = int(batch['tokens_lens'].max())
         b, t, q = codes.shape
         d = cfg.d_model
@@ -131,7 +136,7 @@ class ValleNAR(_Base):
             logits, p = self._stage_logits_with_graph(batch, stage)
         else:
             logits, p = self.stage_logits(batch, stage)
-        target = batch['codes'][:, p:, stage].to(logits.device)
+        target = kernels.ids_to_device(batch['codes'][:, p:, stage], logits.device, self.config.num_audio_tokens, 'codes')
         rows = logits.shape[0] * logits.shape[1]
         return A.CrossEntropyFn.apply(logits.reshape(rows, -1), target.reshape(rows))
 
@@ -144,36 +149,82 @@ class ValleNAR(_Base):
         scheduler = optim.lr_scheduler.CosineAnnealingWarmRestarts(optimizer, self.config.lr_warmup)
         return {'optimizer': optimizer, 'lr_scheduler': scheduler}
 
+    @_on_device
     @torch.inference_mode()
     def generate(self, prompt_tokens, prompt_codes, target_tokens, target_codes_first_layer,
                  greedy: bool = False):
         """valle_nar.py:107-165 (intended algorithm) → codes (Ty, Q) int64.  The reference samples
         from Categorical(logits / temperature) (:160); greedy=True takes the arg-max instead,
-        which is what the parity tests pin."""
+        which is what the parity tests pin.  One utterance of `generate_batch`."""
+        text = torch.cat([prompt_tokens, target_tokens], dim=0)
+        return self.generate_batch([text], [prompt_codes], [target_codes_first_layer], greedy=greedy)[0]
+
+    @_on_device
+    @torch.inference_mode()
+    def generate_batch(self, texts, prompt_codes, first_layers, greedy: bool = False, seed=None):
+        """Batched NAR decoding of B independent utterances (extension; `generate` is built on it).
+        texts[b]: 1-D int64 text ids (prompt + target text); prompt_codes[b]: (Tc_b, Q) int64 acoustic
+        prompt; first_layers[b]: (Ty_b,) int64 first-codebook codes of the target (the AR model's
+        output).  Rows may differ in every length.  Returns a list of (Ty_b, Q) int64 device tensors.
+
+        Row b is laid out [text_b | prompt_b | target_b | padding]; attention is full over the row's
+        own length (per-row key length in the kernel, nothing materialised).  Per stage n = 1..Q-1
+        (valle_nar.py:142-160): the target frames carry sum_{j<n} codes_embs[j](out[j]) + PE, one stack
+        forward with AdaLN on stage_embs[n-1], head proj_layers[n-1] on the target frames of all rows at
+        once, and codebook n is drawn on the device by `vh_categorical_rows` (Categorical(logits /
+        temperature), or the arg-max when greedy)."""
         dev = self._dev()
         cfg = self.config
-        q = cfg.num_quantizers
-        d = cfg.d_model
-        text = torch.cat([prompt_tokens, target_tokens], dim=0).to(dev).unsqueeze(0)
-        pc = prompt_codes.to(dev).unsqueeze(0)                      # (1, Tc, Q)
-        tx, tc, ty = text.shape[1], pc.shape[1], target_codes_first_layer.shape[0]
-        out = torch.zeros(1, ty, q, device=dev, dtype=torch.int64)
-        out[0, :, 0] = target_codes_first_layer.to(dev)
-        total = tx + tc + ty
-        cache = KVCache(cfg.num_layers, 1, cfg.n_heads, total, dev)
-        scratch = ForwardScratch(total, d, cfg.dim_feedforward, dev)
-        x = torch.empty(1, total, d, device=dev, dtype=torch.float32)
+        q, d = cfg.num_quantizers, cfg.d_model
+        B = len(texts)
+        if B == 0 or len(prompt_codes) != B or len(first_layers) != B:
+            raise ValueError('generate_batch: texts, prompt_codes and first_layers must be non-empty lists of equal length')
+        texts = [kernels.ids_to_device(t, dev, cfg.vocab_size, 'text ids') for t in texts]
+        pcs = [kernels.ids_to_device(c, dev, cfg.num_audio_tokens, 'prompt codes') for c in prompt_codes]
+        firsts = [kernels.ids_to_device(f, dev, cfg.num_audio_tokens, 'first-layer codes') for f in first_layers]
+        for t, c, f in zip(texts, pcs, firsts):
+            if t.dim() != 1 or c.dim() != 2 or c.shape[1] != q or f.dim() != 1:
+                raise ValueError('generate_batch: expected text (Tx,), prompt codes (Tc, Q), first layer (Ty,)')
+        txs, tcs, tys = [t.shape[0] for t in texts], [c.shape[0] for c in pcs], [f.shape[0] for f in firsts]
+        lens = [a + b + c for a, b, c in zip(txs, tcs, tys)]
+        total = max(lens)
         pe_a, pe_t = self.audio_position_emb.pe, self.tokens_position_emb.pe
+        if max(tc + ty for tc, ty in zip(tcs, tys)) > pe_a.shape[0] or max(txs) > pe_t.shape[0]:
+            raise _lib.VhError('sequence exceeds the positional table (max_len 5000)')
+        ty_max = max(tys)
+        out = torch.zeros(B, ty_max, q, device=dev, dtype=torch.int64)
+        for b in range(B):
+            out[b, :tys[b], 0] = firsts[b]
+        # text and acoustic-prompt embeddings do not change from stage to stage: build them once
+        base = torch.zeros(B, total, d, device=dev, dtype=torch.float32)
+        for b in range(B):
+            kernels.embed_sum_pe(texts[b].unsqueeze(0), [self.tokens_emb.weight.detach()], pe_t, 0, base[b:b + 1])
+            if tcs[b]:
+                kernels.embed_sum_pe(pcs[b].unsqueeze(0), self._tables(q), pe_a, 0, base[b:b + 1], out_t0=txs[b])
+        kv_len = torch.tensor(lens, device=dev, dtype=torch.int32) if len(set(lens)) > 1 else None
+        # flat row indices of every target frame, and where each row's run starts in the packed logits
+        idx = torch.cat([torch.arange(tys[b], device=dev) + (b * total + txs[b] + tcs[b]) for b in range(B)])
+        starts = [0]
+        for ty in tys:
+            starts.append(starts[-1] + ty)
+        cache = KVCache(cfg.num_layers, B, cfg.n_heads, total, dev)
+        scratch = ForwardScratch(B * total, d, cfg.dim_feedforward, dev)
+        x = torch.empty_like(base)
+        if seed is None:       # drawn from torch's generator, so torch.manual_seed() makes a run repeatable
+            seed = 0 if greedy else int(torch.randint(0, 2 ** 62, (1,)).item())
+        toks = torch.empty(starts[-1], device=dev, dtype=torch.int64)
         for n in range(1, q):
-            kernels.embed_sum_pe(text, [self.tokens_emb.weight.detach()], pe_t, 0, x)
-            kernels.embed_sum_pe(pc, self._tables(q), pe_a, 0, x, out_t0=tx)
-            kernels.embed_sum_pe(out, self._tables(n), pe_a, tc, x, out_t0=tx + tc)
-            transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL,
+            x.copy_(base)
+            for b in range(B):
+                kernels.embed_sum_pe(out[b:b + 1, :tys[b]], self._tables(n), pe_a, tcs[b], x[b:b + 1],
+                                     out_t0=txs[b] + tcs[b])
+            transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
                                 embedding=self.stage_embs[n - 1].weight.detach(), scratch=scratch)
-            logits = kernels.linear(x[0, tx + tc:], self.proj_layers[n - 1].weight.detach())
-            if greedy:
-                out[0, :, n] = torch.argmax(logits, dim=-1)
-            else:
-                probs = torch.softmax(logits / cfg.temperature, dim=-1)
-                out[0, :, n] = torch.multinomial(probs, 1).squeeze(1)
-        return out[0]
+            z = x.view(B * total, d).index_select(0, idx)                      # target frames of every row
+            logits = kernels.linear(z, self.proj_layers[n - 1].weight.detach())
+            kernels.categorical_rows(logits, toks, temperature=cfg.temperature, greedy=greedy, seed=seed,
+                                     stream_id=n)
+            for b in range(B):
+                out[b, :tys[b], n] = toks[starts[b]:starts[b + 1]]
+        _lib.raise_device_errors(dev)
+        return [out[b, :tys[b]].clone() for b in range(B)]
