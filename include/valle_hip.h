@@ -37,7 +37,8 @@ enum { VH_OK = 0, VH_EINVAL = -1, VH_EALIGN = -2, VH_EUNSUPPORTED = -3, VH_ELAUN
        VH_ESTATE = -5 };
 
 /* activation fused in a GEMM epilogue */
-enum { VH_ACT_NONE = 0, VH_ACT_GELU_ERF = 1 };
+enum { VH_ACT_NONE = 0, VH_ACT_GELU_ERF = 1,
+       VH_ACT_GELU_BWD = 2 /* vh_linear_ex only: out = acc * gelu'(residual) (backward through the activation) */ };
 
 /* attention mask modes (analytic; no (B,h,T,T) tensor is ever materialised) */
 enum {
@@ -351,6 +352,29 @@ size_t vh_adamw_ws_bytes(void);
 int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   float max_norm, int zero_grad, void* workspace, float* norm_out, void* stream);
+
+/* ---- training forward / backward products on the LDS-DMA tile machine --------------------------
+ * vh_linear_ex = vh_linear (same tile kernels, M of any size) with the two epilogues training needs:
+ *   pre_out != NULL : the pre-activation acc + bias is ALSO stored to pre_out (row stride ldp) — the
+ *                     forward of FeedForward.linear_1 keeps it for the GELU backward (modules.py:221);
+ *   act == VH_ACT_GELU_BWD : out = acc * gelu'(residual[m][n]) — the backward through nn.GELU fused into
+ *                     the dX = dY . W product of linear_2 (residual = the saved pre-activation).
+ * The backward's dX = dY . W products run on this NT form with W handed over transposed (vh_transpose),
+ * so K here is the forward's N: pad it to a multiple of 32 with zero columns for the fast kernel. */
+int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
+                 float* out, int ldo, float* pre_out, int ldp, int M, int N, int K, int act, void* stream);
+
+/* out (cols, ldo) = in (rows, cols)^T; out rows are zero-filled from `rows` up to ldo. */
+int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream);
+
+/* Weight gradient dW = dY^T . X of `loss.backward()` (valle/models/valle_ar.py:86):
+ *   C (NI, NJ) = A^T . B,  A (M, NI) row stride lda, B (M, NJ) row stride ldb — both stored with the
+ * contraction index (the token) as the row, read in place (no transposed copies).  The contraction is cut
+ * into slices whose partial tiles are summed in fixed order from `workspace` (vh_gemm_tn_ws_bytes; bitwise
+ * reproducible, no atomics).  lda/ldb/ldc multiples of 4 covering the row padded to 4 floats. */
+size_t vh_gemm_tn_ws_bytes(int M, int NI, int NJ);
+int vh_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int NI, int NJ,
+               void* workspace, size_t workspace_bytes, void* stream);
 
 /* General batched fp32 GEMM of the backward pass: C[b,h] = op(A[b,h]) . op(B[b,h]) on the fp32 matrix
  * cores (128x128x32 tiles).  a_kmajor = 0: A stored (M,K) k contiguous; 1: stored (K,M) m contiguous.

@@ -131,6 +131,12 @@ SIGNATURES = {
     'vh_embed_bwd': (C.c_int, [c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int,
                                C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     'vh_colsum': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    'vh_linear_ex': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_transpose': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
+    'vh_gemm_tn_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_gemm_tn': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                             C.c_void_p, C.c_size_t, C.c_void_p]),
     'vh_gemm_batched': (C.c_int, [c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64,
                                   C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
@@ -207,7 +213,8 @@ def err_flag(device) -> torch.Tensor:
     dev = torch.device(device)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _err_flags:
-        _err_flags[idx] = torch.zeros(1, device=torch.device('cuda', idx), dtype=torch.int32)
+        with torch.inference_mode(False):       # a normal tensor even when first touched inside generate()
+            _err_flags[idx] = torch.zeros(1, device=torch.device('cuda', idx), dtype=torch.int32)
     return _err_flags[idx]
 
 

@@ -1,10 +1,13 @@
 """Autograd wrappers: the training path (`training_step` → `loss.backward()`, valle_ar.py:43-90).
 
-Forward passes run the same HIP kernels as inference.  Backward passes pair hand-written HIP
-kernels for every non-GEMM op (LayerNorm/AdaLN, GELU, softmax, cross entropy, embedding scatter,
-bias column sums — csrc/train.hip) with the plain matrix products (dX = dY·W, dW = dYᵀ·X and the
-attention products on recomputed probabilities), which run either as library GEMMs or on the
-hand-written `vh_gemm_batched` (see BACKWARD_GEMM).  Nothing here runs on the CPU.
+Forward passes run the same HIP kernels as inference.  Backward passes are hand-written HIP throughout:
+  * dX = dY · W          → the NT LDS-DMA tile kernel (`vh_linear_ex`) on Wᵀ (`vh_transpose`, a few MB per layer),
+                           with the GELU backward fused into linear_2's product (`VH_ACT_GELU_BWD`);
+  * dW = dYᵀ · X         → `vh_gemm_tn`: both operands read token-major as they lie, contraction split over the
+                           chip, slabs summed in fixed order (bitwise reproducible);
+  * attention            → `vh_attn_rows_bwd` (flash-style, P recomputed tile by tile);
+  * everything row-wise  → csrc/train.hip (LayerNorm/AdaLN, cross entropy, embedding scatter, bias column sums).
+There is no library GEMM and no CPU arithmetic on this path.
 """
 from __future__ import annotations
 
@@ -15,47 +18,48 @@ from ._lib import check, ptr, stream
 
 HEAD_DIM = kernels.HEAD_DIM
 
-# Engine of the PLAIN backward matrix products (dX = dY·W, dW = dYᵀ·X, the five attention products):
-#   'library' — rocBLAS / hipBLASLt through torch.matmul (default: these are unfused library GEMMs,
-#               measured 105-146 TFLOP/s fp32 on the training shapes);
-#   'hip'     — the hand-written vh_gemm_batched (92-124 TFLOP/s; reads the strided attention views
-#               in place and writes gradients straight into the (B*T, 3d) buffer).
-# Both pass the same gradient-parity tests; tools/bench_gemm_bwd.py holds the A/B.
-BACKWARD_GEMM = 'library'
-
 # Backward of the attention core:
 #   'flash'        — vh_attn_rows_bwd: two hand-written kernels that recompute P tile by tile from the saved
 #                    row log-sum-exp (no (T,T) maps in memory, no atomics);
-#   'materialized' — S, P, dP as (B,h,T,T) tensors through plain GEMMs + row softmax kernels.
+#   'materialized' — S, P, dP as (B,h,T,T) tensors through vh_gemm_batched + row softmax kernels (kept as a
+#                    second, independently written derivation the gradient tests compare against).
 ATTENTION_BACKWARD = 'flash'
 
 
 def _mm(a, b, out, a_kmajor=False, b_kmajor=False):
-    """out = op(a) @ op(b) with the operand-storage convention of kernels.gemm."""
-    if BACKWARD_GEMM == 'hip':
-        return kernels.gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
-    left = a.transpose(-1, -2) if a_kmajor else a
-    right = b if b_kmajor else b.transpose(-1, -2)
-    if out.is_contiguous():
-        torch.matmul(left, right, out=out)      # straight into the result: no temporary, no copy
-    else:
-        out.copy_(torch.matmul(left, right))    # strided gradient views (dq/dk/dv inside dqkv): small
-    return out
+    """out = op(a) @ op(b) on the hand-written batched GEMM (strided attention views read in place)."""
+    return kernels.gemm(a, b, out, a_kmajor=a_kmajor, b_kmajor=b_kmajor)
+
+
+def _kpad(t):
+    """`t` (rows, n) as an operand whose contraction width is a multiple of 32: itself when n already is,
+    else a zero-padded copy (only the 1025-wide logit gradients of the AR head)."""
+    rows, n = t.shape
+    if n % 32 == 0 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t, n
+    kp = kernels.pad32(n)
+    buf = torch.zeros(rows, kp, device=t.device, dtype=torch.float32)
+    buf[:, :n] = t
+    return buf[:, :n], kp
+
+
+def _dx(dy, w, kp, residual=None, act=kernels.ACT_NONE):
+    """dX = dY · W for a forward y = x @ W.T: the NT tile kernel on Wᵀ (K x N, rows zero-padded to kp)."""
+    wt = kernels.transpose(w.detach(), ldo=kp)
+    m, k = dy.shape[0], w.shape[1]
+    out = torch.empty(m, k, device=dy.device, dtype=torch.float32)
+    return kernels.linear_ex(dy, wt, residual=residual, out=out, act=act, K=kp)
+
+
+def _colsum(dy, n):
+    db = torch.zeros(n, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().vh_colsum(ptr(dy) if dy.is_contiguous() else dy.data_ptr(), dy.stride(0), ptr(db), dy.shape[0],
+                               n, stream()), 'vh_colsum')
+    return db
 
 
 def _zeros_like(t):
     return torch.zeros_like(t, memory_format=torch.contiguous_format)
-
-
-def _ld4(t):
-    """A 2-D view of `t` whose row stride is a multiple of 4 floats (16-B loads in vh_gemm_batched);
-    copies into a padded buffer only for ragged widths such as the 1025-wide logits."""
-    if t.stride(-1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
-        return t
-    rows, cols = t.shape
-    buf = torch.zeros(rows, (cols + 3) // 4 * 4, device=t.device, dtype=t.dtype)
-    buf[:, :cols] = t
-    return buf[:, :cols]
 
 
 class LinearFn(torch.autograd.Function):
@@ -76,18 +80,51 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dy = _ld4(dy)
+        dyp, kp = _kpad(dy)
         dx = dw = None
-        if ctx.needs_input_grad[0]:      # dX = dY . W        (W stored (N,K) = (k_gemm, n_gemm): k-major B)
-            dx = _mm(dy, w, torch.empty_like(x), b_kmajor=True)
+        if ctx.needs_input_grad[0]:      # dX = dY . W
+            dx = _dx(dyp, w, kp)
         if ctx.needs_input_grad[1]:      # dW = dY^T . X      (both operands stored with the token index as rows)
-            dw = _mm(dy, x, torch.empty_like(w), a_kmajor=True, b_kmajor=True)
+            dw = torch.empty_like(w)
+            kernels.gemm_tn(dyp, x, out=dw)
         db = None
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = torch.zeros(w.shape[0], device=dy.device, dtype=torch.float32)
-            check(_lib.lib().vh_colsum(ptr(dy), dy.stride(0), ptr(db), dy.shape[0], dy.shape[1], stream()),
-                  'vh_colsum')
+            db = _colsum(dyp, w.shape[0])
         return dx, dw, db, (dy if ctx.has_res else None)
+
+
+class FfnFn(torch.autograd.Function):
+    """out = linear_2(gelu(linear_1(xn))) + residual  (modules.py:215-221,278) with dropout off.
+    Forward: linear_1's epilogue stores the pre-activation and the GELU in one pass.  Backward: the GELU
+    derivative is applied in the epilogue of linear_2's dX product — no separate activation passes."""
+
+    @staticmethod
+    def forward(ctx, xn, w1, b1, w2, b2, residual):
+        xn = xn.contiguous()
+        m, dff = xn.shape[0], w1.shape[0]
+        pre = torch.empty(m, dff, device=xn.device, dtype=torch.float32)
+        hid = torch.empty_like(pre)
+        kernels.linear_ex(xn, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU)
+        out = torch.empty(m, w2.shape[0], device=xn.device, dtype=torch.float32)
+        kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=residual, out=out)
+        ctx.save_for_backward(xn, w1, w2, pre, hid)
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xn, w1, w2, pre, hid = ctx.saved_tensors
+        dy = dy.contiguous()
+        d, dff = w2.shape
+        dw2 = torch.empty_like(w2)
+        kernels.gemm_tn(dy, hid, out=dw2)                                   # dW2 = dY^T . hid
+        db2 = _colsum(dy, d)
+        dpre = _dx(dy, w2, kernels.pad32(d), residual=pre, act=kernels.ACT_GELU_BWD)   # (dY . W2) * gelu'(pre)
+        dw1 = torch.empty_like(w1)
+        kernels.gemm_tn(dpre, xn, out=dw1)
+        db1 = _colsum(dpre, dff)
+        dxn = _dx(dpre, w1, kernels.pad32(dff)) if ctx.needs_input_grad[0] else None
+        return dxn, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
 
 class GeluFn(torch.autograd.Function):
@@ -173,9 +210,10 @@ class QkvAttentionFn(torch.autograd.Function):
                                   dqkv[:, 2 * d:], B, h, T, **spec)
             dx = dw = None
             if ctx.needs_input_grad[0]:
-                dx = _mm(dqkv, wqkv, torch.empty_like(x), b_kmajor=True)
+                dx = _dx(dqkv, wqkv, 3 * d)
             if ctx.needs_input_grad[1]:
-                dw = _mm(dqkv, x, torch.empty_like(wqkv), a_kmajor=True, b_kmajor=True)
+                dw = torch.empty_like(wqkv)
+                kernels.gemm_tn(dqkv, x, out=dw)
             return dx, dw, None, None, None, None
         scale = HEAD_DIM ** -0.5
         L = _lib.lib()
@@ -184,44 +222,23 @@ class QkvAttentionFn(torch.autograd.Function):
         do = dout.contiguous().view(B, T, h, HEAD_DIM).permute(0, 2, 1, 3)
         dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
         dq, dk, dv = (dqkv.view(B, T, 3, h, HEAD_DIM)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-        if BACKWARD_GEMM == 'library' and tp != T:
-            # the (T,T) maps keep a 16-byte row stride: give K and V tp - T zero rows, so the library
-            # GEMMs write whole dense (T,tp) maps (their pad columns are exact zeros) instead of
-            # producing a temporary that is then copied into a strided view — 1 GB per layer at T = 1000
-            kp = torch.zeros(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
-            vp = torch.zeros_like(kp)
-            kp[:, :, :T] = k
-            vp[:, :, :T] = v
-            k, v = kp, vp
-            P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)
-            dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)
-        else:
-            P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
-            dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        P = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
         _mm(qh, k, P)                                                     # S = Q K^T (raw scores)
         check(L.vh_softmax_rows(P.data_ptr(), tp, B, h, T, T, scale, spec['mode'], spec.get('x_len', 0),
                                 ptr(spec.get('x_len_dev')), ptr(spec.get('kv_len')), ptr(spec.get('mask')),
                                 ptr(spec.get('pad')), stream()), 'vh_softmax_rows')
-        if P.shape[-1] != T:
-            dvp = torch.empty(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
-            _mm(P, do, dvp, a_kmajor=True, b_kmajor=True)
-            dv.copy_(dvp[:, :, :T])
-        else:
-            _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                  # dV = P^T dO   → dqkv[:, 2d:]
+        _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                      # dV = P^T dO   → dqkv[:, 2d:]
         _mm(do, v, dP)                                                    # dP = dO V^T
         check(L.vh_softmax_bwd(P.data_ptr(), dP.data_ptr(), tp, B * h * T, T, scale, stream()), 'vh_softmax_bwd')
         _mm(dP, k, dq, b_kmajor=True)                                     # dQ = dS K     → dqkv[:, :d]
-        if P.shape[-1] != T:                                              # padded maps: dK/dV rows >= T are zeros
-            dkp = torch.empty(B, h, tp, HEAD_DIM, device=x.device, dtype=torch.float32)
-            _mm(dP, qh, dkp, a_kmajor=True, b_kmajor=True)
-            dk.copy_(dkp[:, :, :T])
-        else:
-            _mm(dP, qh, dk, a_kmajor=True, b_kmajor=True)                 # dK = dS^T Q   → dqkv[:, d:2d]
+        _mm(dP, qh, dk, a_kmajor=True, b_kmajor=True)                     # dK = dS^T Q   → dqkv[:, d:2d]
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = _mm(dqkv, wqkv, torch.empty_like(x), b_kmajor=True)
+            dx = _dx(dqkv, wqkv, 3 * d)
         if ctx.needs_input_grad[1]:
-            dw = _mm(dqkv, x, torch.empty_like(wqkv), a_kmajor=True, b_kmajor=True)
+            dw = torch.empty_like(wqkv)
+            kernels.gemm_tn(dqkv, x, out=dw)
         return dx, dw, None, None, None, None
 
 
@@ -306,10 +323,15 @@ def encoder_layer_train(layer, x, B, T, spec, embedding=None):
         x = x + d1(linear(a, at.out.weight, at.out.bias))
     else:
         x = linear(a, at.out.weight, at.out.bias, residual=x)
+    ffn_drop = ff.dropout.training and ff.dropout.p > 0
+    res_drop = d2.training and d2.p > 0
+    if not ffn_drop and not res_drop and cfg.dim_feedforward % 32 == 0:
+        return FfnFn.apply(norm(layer.norm2, x), ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight,
+                           ff.linear_2.bias, x)
     hid = GeluFn.apply(linear(norm(layer.norm2, x), ff.linear_1.weight, ff.linear_1.bias))
-    if ff.dropout.training and ff.dropout.p > 0:
+    if ffn_drop:
         hid = ff.dropout(hid)
-    if d2.training and d2.p > 0:
+    if res_drop:
         x = x + d2(linear(hid, ff.linear_2.weight, ff.linear_2.bias))
     else:
         x = linear(hid, ff.linear_2.weight, ff.linear_2.bias, residual=x)

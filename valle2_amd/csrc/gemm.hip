@@ -38,6 +38,8 @@ struct GemmArgs {
     float* vc;
     const int32_t* cache_len;
     int T, S_max, d_model, n_heads;
+    float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
+    int ldx;
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
 #ifdef VH_STAMPS
@@ -220,16 +222,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         const int64_t row0 = EPI == EPI_PARTIAL ? (int64_t)blockIdx.y * a.M + m0 : m0;
         char* base = (char*)(a.out + row0 * a.ldo + n0);
         const uint32_t voff = (uint32_t)(erow * a.ldo + 4 * ec4) * 4u;
+        char* xbase = (EPI == EPI_PLAIN && a.aux) ? (char*)(a.aux + (int64_t)m0 * a.ldx + n0) : nullptr;
+        const uint32_t xoff = (uint32_t)(erow * a.ldx + 4 * ec4) * 4u;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             f32x4 v = ld4(cr + it * 8 * LDC);
             if (EPI == EPI_PLAIN) {
                 v += e.bias4;
+                if (xbase) st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), v);   // pre-activation
                 if (a.act == VH_ACT_GELU_ERF) {                 // two per instruction (packed fp32)
                     const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
                     v = f32x4{g0.x, g0.y, g1.x, g1.y};
                 }
-                v += e.resv[it];
+                if (a.act == VH_ACT_GELU_BWD) {                 // dY through the activation: acc * gelu'(pre)
+                    const f32x4 p = e.resv[it];
+                    v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+                } else {
+                    v += e.resv[it];
+                }
             }
             st4((float*)(base + (int64_t)it * 8 * a.ldo * 4 + voff), v);
         }
@@ -289,15 +299,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             }
         } else if (ecol_full) {
             v += e.bias4;
+            if (a.aux) st4(a.aux + (int64_t)m * a.ldx + en, v);
             if (a.act == VH_ACT_GELU_ERF) {
                 v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
             }
-            st4(a.out + (int64_t)m * a.ldo + en, v + e.resv[it]);
+            if (a.act == VH_ACT_GELU_BWD) {
+                const f32x4 p = e.resv[it];
+                v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+                st4(a.out + (int64_t)m * a.ldo + en, v);
+            } else {
+                st4(a.out + (int64_t)m * a.ldo + en, v + e.resv[it]);
+            }
         } else {                                       // ragged last column group (e.g. N = 1025 logits)
             for (int j = 0; j < 4 && en + j < a.N; ++j) {
                 float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
+                if (a.aux) a.aux[(int64_t)m * a.ldx + en + j] = sv;
                 if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
-                if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
+                if (a.act == VH_ACT_GELU_BWD) sv *= gelu_grad(a.res[(int64_t)m * a.ldr + en + j]);
+                else if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
                 a.out[(int64_t)m * a.ldo + en + j] = sv;
             }
         }
@@ -1054,7 +1073,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
     VH_REQUIRE(x64 == 0 || (a.M <= 64 && a.K <= 1024 && a.K % 128 == 0), VH_EUNSUPPORTED,
                "%s: the fp64 accumulator form is the decode path: M <= 64, K <= 1024, K %% 128 == 0 "
                "(M=%d K=%d)", name, a.M, a.K);
-    if (a.M <= 64) {
+    const bool train_epi = a.aux != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
+    if (a.M <= 64 && !train_epi) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
         const bool wide = a.K > 1024;
@@ -1170,6 +1190,23 @@ extern "C" int vh_linear(const float* A, int lda, const float* W, const float* b
     VH_REQUIRE(ldo >= N && (!residual || ldr >= N), VH_EINVAL, "vh_linear: ldo/ldr < N");
     if (int rc = check_gemm("vh_linear", a, ln)) return rc;
     return launch_gemm<EPI_PLAIN>("vh_linear", a, ln, (hipStream_t)stream);
+}
+
+extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual,
+                            int ldr, float* out, int ldo, float* pre_out, int ldp, int M, int N, int K, int act,
+                            void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
+    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K; a.aux = pre_out; a.ldx = ldp;
+    LnFuse ln{};
+    VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF || act == VH_ACT_GELU_BWD, VH_EINVAL,
+               "vh_linear_ex: act=%d", act);
+    VH_REQUIRE(act != VH_ACT_GELU_BWD || (residual && !bias && !pre_out), VH_EINVAL,
+               "vh_linear_ex: VH_ACT_GELU_BWD takes the saved pre-activation as `residual`, no bias, no pre_out");
+    VH_REQUIRE(ldo >= N && (!residual || ldr >= N) && (!pre_out || (ldp >= N && ldp % 4 == 0 && vh_aligned16(pre_out))),
+               VH_EINVAL, "vh_linear_ex: ldo/ldr/ldp");
+    if (int rc = check_gemm("vh_linear_ex", a, ln)) return rc;
+    return launch_gemm<EPI_PLAIN>("vh_linear_ex", a, ln, (hipStream_t)stream);
 }
 
 extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int ldq,
@@ -1379,5 +1416,302 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items + rb - 1) / rb), dim3(rb), 0, s,
                        (const float*)workspace, splits, fin, lds_);
     VH_CHECK_LAUNCH("vh_linear_ws");
+    return VH_OK;
+}
+
+// =============================================================================================
+// Weight-gradient GEMM of the training backward:  C (NI, NJ) = Aᵀ · B,  A (M, NI), B (M, NJ), both stored
+// with the CONTRACTION index m as the row (dW = dYᵀ · X: A = dY, B = X; valle_ar.py:86 loss.backward()).
+//
+// Same machine as gemm_tile_dma_kernel (128x128 output tile, 4 waves x 2x2 v_mfma_f32_32x32x2_f32, LDS-DMA
+// double buffer, two workgroups per CU, pinned schedule, no vector ALU in the K loop), with the operand
+// image in LDS being what lies in memory: a K slab is 32 contraction rows x 128 tile columns = 32 rows of
+// 512 B per operand, DMA'd as they are (one wave-instruction = 2 whole rows, perfectly coalesced, LDS
+// written lane-linearly: [k][128], no padding, no swizzle).  The MFMA wants A[i = lane&31][k = lane>>5]:
+// lane (r, h) reads LDS[k = 2j + h][tile column r] — the 32 lanes of a half read 32 consecutive dwords
+// (ds_read_b32 banks are (a/4) % 32 per half: conflict-free), one ds_read_b32 per operand register, all
+// addressed as one per-lane base + 16-bit immediate offsets.  64 ds_read_b32 + 64 MFMAs per wave and slab.
+//
+// Few output tiles (NI x NJ is a weight: 16..64 tiles) against a long contraction (every token of the
+// batch): the contraction is cut into gridDim.y slices, each slice leaves its partial tile in a slab of
+// the workspace (tile_epilogue<EPI_PARTIAL>) and tn_reduce_kernel adds the slabs in slice order — bitwise
+// reproducible, no atomics.  One slice writes straight into C.
+// =============================================================================================
+#define TN_OPSZ 4224            // floats per operand buffer: a 32 x 128 slab (4096) + the epilogue's 128 x 132 needs 4 x 4224
+
+struct TnArgs {
+    const float* A; int lda;
+    const float* B; int ldb;
+    int M, NI, NJ;
+    int m_chunk;                // contraction rows per slice (multiple of 32)
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_tile_tn_kernel(TnArgs g, GemmArgs a, int tiles_i, int tiles_j) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][TN_OPSZ];   // [buf][A|B][k][128]
+    __builtin_amdgcn_s_setprio(3);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nwg = tiles_i * tiles_j;
+    const int bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int i0 = (tile / tiles_j) * TM, j0 = (tile % tiles_j) * TN;
+    const int mbeg = blockIdx.y * g.m_chunk;
+    const int mend = min(g.M, mbeg + g.m_chunk);
+    const int rows_total = mend - mbeg;                   // > 0 by construction of the grid
+    const int nk = (rows_total + TK - 1) / TK;
+
+    // DMA: wave w issues pieces q = 8w..8w+7 of a slab (16 of A, then 16 of B); piece q covers contraction
+    // rows 2(q&15), 2(q&15)+1; lane L fetches the 16-B chunk L&31 of row (L>>5).  Columns beyond the operand's
+    // padded width are clamped (their products land in output rows/columns that are never stored).
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const char* baseA = (const char*)(g.A + (int64_t)mbeg * g.lda + i0);
+    const char* baseB = (const char*)(g.B + (int64_t)mbeg * g.ldb + j0);
+    const int wa = ((g.NI + 3) & ~3) - i0 - 4, wb = ((g.NJ + 3) & ~3) - j0 - 4;   // last whole chunk of the tile's row
+    uint32_t voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = ws * 8 + i, row = (q & 15) * 2 + (lane >> 5), c4 = 4 * (lane & 31);
+        voff[i] = q < 16 ? (uint32_t)(row * g.lda + min(c4, wa)) * 4u : (uint32_t)(row * g.ldb + min(c4, wb)) * 4u;
+    }
+    const int64_t stepA = (int64_t)TK * g.lda * 4, stepB = (int64_t)TK * g.ldb * 4;   // bytes per K slab
+    auto dma1 = [&](int i, int buf, int kt, auto tail_c) {
+        const int q = ws * 8 + i;
+        const char* base = q < 16 ? baseA + kt * stepA : baseB + kt * stepB;
+        const uint32_t dst = (uint32_t)(uintptr_t)&lds[buf][q >> 4][(q & 15) * 256];
+        uint32_t vo = voff[i];
+        if constexpr (decltype(tail_c)::value) {          // last slab of the slice: rows beyond the end re-read the last row
+            const int row = (q & 15) * 2 + (lane >> 5), last = rows_total - 1 - kt * TK;
+            if (row > last) vo -= (uint32_t)((row - last) * (q < 16 ? g.lda : g.ldb)) * 4u;
+        }
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(vo), "s"(base) : "memory");
+    };
+    const bool ragged = (rows_total % TK) != 0;           // wave-uniform
+    // rows of the A image beyond the slice's end must multiply as zeros (B's re-read rows are finite)
+    auto zero_tail = [&](int buf, int kt) {
+        const int valid = rows_total - kt * TK;           // < 32
+        for (int idx = tid; idx < (TK - valid) * 32; idx += 256)
+            st4(&lds[buf][0][(valid + idx / 32) * 128 + 4 * (idx % 32)], f32x4{0.f, 0.f, 0.f, 0.f});
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (ragged && nk == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(i, 0, 0, std::true_type{});
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(i, 0, 0, std::false_type{});
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (ragged && nk == 1) { zero_tail(0, 0); __syncthreads(); }
+
+    // fragment addresses: per-lane base (k row h of the slab, tile column) + immediates
+    const float* pA = &lds[0][0][h * 128 + wm * 64 + r];
+    const float* pB = &lds[0][1][h * 128 + wn * 64 + r];
+    float fa[2][2][4], fb[2][2][4];                       // [set][tile][k pair of the group]
+    auto fload = [&](int set, int buf, int t) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int o = buf * 2 * TN_OPSZ + (4 * t + jj) * 256;
+            fa[set][0][jj] = pA[o];
+            fa[set][1][jj] = pA[o + 32];
+            fb[set][0][jj] = pB[o];
+            fb[set][1][jj] = pB[o + 32];
+        }
+    };
+    auto mfma4 = [&](int set, int jj) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][jj], fb[set][0][jj], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][jj], fb[set][1][jj], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][jj], fb[set][0][jj], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][jj], fb[set][1][jj], acc[1][1], 0, 0, 0);
+    };
+    __builtin_amdgcn_s_setprio(0);
+    fload(0, 0, 0);
+    // PF: 0 = nothing to prefetch (last slab), 1 = prefetch a whole slab (the steady state: no branch, no vector
+    // ALU besides the MFMAs), 2 = prefetch the slice's last slab, which may be partial
+    auto kstep = [&](int kt, auto cur_c, auto pf) {
+        constexpr int PF = decltype(pf)::value;
+        constexpr int cur = decltype(cur_c)::value;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            mfma4(t & 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PF == 1) {
+                if (t < 2) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, kt + 1, std::false_type{});
+                }
+            }
+            if constexpr (PF == 2) {
+                if (t < 2) {
+                    if (ragged) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, kt + 1, std::true_type{});
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, kt + 1, std::false_type{});
+                    }
+                }
+            }
+            if (t < 3) {
+                fload((t + 1) & 1, cur, t + 1);
+            } else if constexpr (PF != 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                if constexpr (PF == 2) {
+                    if (ragged) {                         // wave-uniform, once per workgroup
+                        zero_tail(cur ^ 1, kt + 1);
+                        __syncthreads();
+                    }
+                }
+                fload(0, cur ^ 1, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma4(t & 1, 1);
+            mfma4(t & 1, 2);
+            mfma4(t & 1, 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {                        // prefetches slabs <= nk - 2: always whole
+        kstep(kt, B0{}, P1{});
+        kstep(kt + 1, B1{}, P1{});
+    }
+    const int rem = nk - kt;                              // 1, 2 or 3 slabs left, the current one in buffer 0
+    if (rem == 3) {
+        kstep(kt, B0{}, P1{});
+        kstep(kt + 1, B1{}, P2{});
+        kstep(kt + 2, B0{}, P0{});
+    } else if (rem == 2) {
+        kstep(kt, B0{}, P2{});
+        kstep(kt + 1, B1{}, P0{});
+    } else {
+        kstep(kt, B0{}, P0{});
+    }
+    __syncthreads();
+    __builtin_amdgcn_s_setprio(3);
+    TileEpi epi;
+    epi.bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    tile_epilogue<EPI_PARTIAL>(a, acc, &lds[0][0][0], i0, j0, tid, epi);   // slab blockIdx.y of a.out (or C itself)
+}
+
+// C[i][j] = sum over slices of slab[s][i][j], in slice order (fixed → reproducible)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slabs, int n_split, int rows, int lds_,
+                                                        int ncols, float* __restrict__ C, int ldc) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int groups = lds_ / 4;
+    const int i = idx / groups, j = (idx - i * groups) * 4;
+    if (i >= rows || j >= ncols) return;
+    const float* p = slabs + (int64_t)i * lds_ + j;
+    const int64_t stride = (int64_t)rows * lds_;
+    f32x4 acc = ld4(p);
+    for (int s0 = 1; s0 < n_split; s0 += 8) {
+        f32x4 part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            part[u] = s0 + u < n_split ? ld4(p + (s0 + u) * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += part[u];
+    }
+    if (j + 3 < ncols) {
+        st4(C + (int64_t)i * ldc + j, acc);
+    } else {
+        for (int u = 0; u < 4 && j + u < ncols; ++u) C[(int64_t)i * ldc + j + u] = acc[u];
+    }
+}
+
+static int tn_plan(int M, int NI, int NJ) {
+    const int tiles = ((NI + TM - 1) / TM) * ((NJ + TN - 1) / TN);
+    const int slabs = (M + TK - 1) / TK;
+    int splits = 512 / tiles;                              // two workgroups per CU
+    if (splits > slabs / 8) splits = slabs / 8;            // at least 8 slabs (256 rows) per slice
+    if (splits > 64) splits = 64;
+    return splits < 1 ? 1 : splits;
+}
+
+extern "C" size_t vh_gemm_tn_ws_bytes(int M, int NI, int NJ) {
+    const int splits = tn_plan(M, NI, NJ);
+    return splits > 1 ? (size_t)splits * NI * ((NJ + 3) / 4 * 4) * sizeof(float) : 0;
+}
+
+extern "C" int vh_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int NI, int NJ,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+    VH_REQUIRE(A && B && C, VH_EINVAL, "vh_gemm_tn: null pointer");
+    VH_REQUIRE(M > 0 && NI > 0 && NJ > 0, VH_EINVAL, "vh_gemm_tn: bad dims M=%d NI=%d NJ=%d", M, NI, NJ);
+    VH_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && ldc % 4 == 0 && lda >= ((NI + 3) & ~3) && ldb >= ((NJ + 3) & ~3) &&
+                   ldc >= NJ,
+               VH_EALIGN, "vh_gemm_tn: leading dimensions must be multiples of 4 and cover the padded row "
+               "(lda=%d ldb=%d ldc=%d)", lda, ldb, ldc);
+    VH_REQUIRE(vh_aligned16(A) && vh_aligned16(B) && vh_aligned16(C) && vh_aligned16(workspace), VH_EALIGN,
+               "vh_gemm_tn: pointers must be 16-byte aligned");
+    const int splits = tn_plan(M, NI, NJ);
+    const int lds_ = (NJ + 3) / 4 * 4;
+    VH_REQUIRE(splits == 1 || (workspace && workspace_bytes >= vh_gemm_tn_ws_bytes(M, NI, NJ)), VH_EINVAL,
+               "vh_gemm_tn: workspace of %zu B needed (vh_gemm_tn_ws_bytes)", vh_gemm_tn_ws_bytes(M, NI, NJ));
+    const int slabs = (M + TK - 1) / TK;
+    const int chunk = (slabs + splits - 1) / splits * TK;
+    const int ny = (M + chunk - 1) / chunk;               // slices that really hold rows
+    TnArgs g{A, lda, B, ldb, M, NI, NJ, chunk};
+    GemmArgs a{};
+    a.M = NI; a.N = NJ; a.K = M; a.k_len = chunk;
+    a.out = ny > 1 ? (float*)workspace : C;
+    a.ldo = ny > 1 ? lds_ : ldc;
+    const int ti = (NI + TM - 1) / TM, tj = (NJ + TN - 1) / TN;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gemm_tile_tn_kernel, dim3(ti * tj, ny), dim3(256), 0, s, g, a, ti, tj);
+    if (ny > 1) {
+        const int n = NI * (lds_ / 4);
+        hipLaunchKernelGGL(tn_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, ny, NI,
+                           lds_, NJ, C, ldc);
+    }
+    VH_CHECK_LAUNCH("vh_gemm_tn");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// out (cols, rows) = in (rows, cols)ᵀ through 32x33 LDS tiles — the weights of the backward's dX = dY · W
+// products are handed to the NT tile kernel as Wᵀ (a few MB per layer and step).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ldi, int rows, int cols,
+                                                        float* __restrict__ out, int ldo) {
+    __shared__ float t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        t[ty + 8 * i][tx] = (rr < rows && cc < cols) ? in[(int64_t)rr * ldi + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ty + 8 * i, rr = r0 + tx;       // out row = in column; zero fill up to ldo (k padding)
+        if (cc < cols && rr < ldo) out[(int64_t)cc * ldo + rr] = t[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream) {
+    VH_REQUIRE(in && out && rows > 0 && cols > 0 && ldi >= cols && ldo >= rows, VH_EINVAL,
+               "vh_transpose: bad args rows=%d cols=%d ldi=%d ldo=%d", rows, cols, ldi, ldo);
+    // the tile grid covers ldo input rows, so out rows are zero-filled to the full ldo (a padded contraction width)
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (ldo + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                       in, ldi, rows, cols, out, ldo);
+    VH_CHECK_LAUNCH("vh_transpose");
     return VH_OK;
 }

@@ -154,6 +154,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + vh_erf(x * 0.70710678118654752440f));
 }
 
+// d/dx of the exact-erf GELU: Phi(x) + x * phi(x)  (the backward of modules.py:216)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + vh_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    return cdf + x * pdf;
+}
+
 // LayerNorm parameters that may be fused into an operand load
 struct LnFuse {
     const float* gamma;  // (K) or nullptr → no fused LN

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import check, ptr, stream
 
 MASK_FULL, MASK_PREFIX, MASK_EXPLICIT = 0, 1, 2
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 HEAD_DIM = 64
 
 
@@ -326,6 +326,74 @@ def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_coun
         int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
         ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next),
         B, d, stream()), 'vh_sample_step')
+
+
+def pad32(n):
+    return (n + 31) // 32 * 32
+
+
+def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None):
+    """vh_linear_ex: out = act(a @ w.T + bias) + residual on the tile kernels whatever M is, with the training
+    epilogues (pre_out: also store the pre-activation; ACT_GELU_BWD: out = (a @ w.T) * gelu'(residual)).
+    `K` overrides the contraction width (operands whose rows are zero-padded to a multiple of 32)."""
+    M = a.shape[0]
+    N = w.shape[0]
+    K = K or a.shape[1]
+    if a.stride(1) != 1 or w.stride(1) != 1 or a.stride(0) < K:
+        raise _lib.VhError('linear_ex: operands must be row-major and cover K')
+    if w.stride(0) != K:
+        raise _lib.VhError(f'linear_ex: the weight rows must be exactly K={K} wide (stride {w.stride(0)})')
+    if out is None:
+        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
+    for t, name in ((residual, 'residual'), (pre_out, 'pre_out'), (out, 'out')):
+        if t is not None and (tuple(t.shape) != (M, N) or t.stride(1) != 1):
+            raise _lib.VhError(f'linear_ex: {name} must be a row-major ({M},{N}) tensor')
+    check(_lib.lib().vh_linear_ex(
+        _dev_f32(a, 'a'), a.stride(0), _dev_f32(w, 'w'), ptr(bias),
+        _dev_f32(residual, 'residual') if residual is not None else None,
+        residual.stride(0) if residual is not None else 0, _dev_f32(out, 'out'), out.stride(0),
+        _dev_f32(pre_out, 'pre_out') if pre_out is not None else None,
+        pre_out.stride(0) if pre_out is not None else 0, M, N, K, act, stream()), 'vh_linear_ex')
+    return out
+
+
+def transpose(w, ldo=None, out=None):
+    """out (cols, ldo) = w (rows, cols)^T, rows zero-padded up to ldo (default: rows rounded up to 32)."""
+    rows, cols = w.shape
+    ldo = ldo or pad32(rows)
+    if out is None:
+        out = torch.empty(cols, ldo, device=w.device, dtype=torch.float32)
+    if w.stride(1) != 1 or tuple(out.shape) != (cols, ldo) or not out.is_contiguous():
+        raise _lib.VhError('transpose: w must be row-major and out a contiguous (cols, ldo) tensor')
+    check(_lib.lib().vh_transpose(_dev_f32(w, 'w'), w.stride(0), rows, cols, _dev_f32(out, 'out'), ldo, stream()),
+          'vh_transpose')
+    return out
+
+
+_tn_ws = {}
+
+
+def gemm_tn(a, b, out=None):
+    """out (NI, NJ) = a.T @ b for a (M, NI), b (M, NJ) stored token-major (dW = dY^T X), read in place."""
+    M, NI = a.shape
+    M2, NJ = b.shape
+    if M != M2 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise _lib.VhError(f'gemm_tn: a {tuple(a.shape)} b {tuple(b.shape)}')
+    if out is None:
+        out = torch.empty(NI, (NJ + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :NJ]
+    if tuple(out.shape) != (NI, NJ) or out.stride(1) != 1:
+        raise _lib.VhError('gemm_tn: out shape')
+    need = _lib.lib().vh_gemm_tn_ws_bytes(M, NI, NJ)
+    ws = None
+    if need:                      # one growing workspace per device: calls are stream-ordered
+        key = a.device.index
+        ws = _tn_ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = _tn_ws[key] = torch.empty(need // 4, device=a.device, dtype=torch.float32)
+    check(_lib.lib().vh_gemm_tn(_dev_f32(a, 'a'), a.stride(0), _dev_f32(b, 'b'), b.stride(0), _dev_f32(out, 'out'),
+                                out.stride(0), M, NI, NJ, ptr(ws), ws.numel() * 4 if ws is not None else 0, stream()),
+          'vh_gemm_tn')
+    return out
 
 
 def categorical_rows(logits, tokens, temperature=1.0, greedy=False, seed=0, stream_id=0, logprob=None):
