@@ -1,5 +1,6 @@
-"""A/B of the backward-pass products at configs[3] training shapes: vh_gemm_batched vs torch.matmul
-(rocBLAS), one process, interleaved (developer tool)."""
+"""The backward-pass weight products at configs[3] training shapes on the hand-written kernels — dX = dY W as
+vh_transpose + vh_linear_ex (NT LDS-DMA tile kernel), dW = dY^T X as vh_gemm_tn — with torch.matmul (rocBLAS /
+hipBLASLt) timed beside them as a yardstick only (developer tool; the product never calls a library GEMM)."""
 import statistics
 import sys
 from pathlib import Path
@@ -32,9 +33,16 @@ def main():
         dy, w, x = torch.randn(M, n, device=DEV), torch.randn(n, k, device=DEV), torch.randn(M, k, device=DEV)
         dx, dw = torch.empty(M, k, device=DEV), torch.empty(n, k, device=DEV)
         flop = 2 * M * n * k
-        cases[name] = (flop, lambda dy=dy, w=w, dx=dx: K.gemm(dy, w, dx, b_kmajor=True), lambda dy=dy, w=w: torch.matmul(dy, w))
-        cases[name.replace('dX', 'dW')] = (flop, lambda dy=dy, x=x, dw=dw: K.gemm(dy, x, dw, a_kmajor=True, b_kmajor=True),
+        cases[name] = (flop, lambda dy=dy, w=w, dx=dx: K.linear_ex(dy, K.transpose(w), out=dx), lambda dy=dy, w=w: torch.matmul(dy, w))
+        cases[name.replace('dX', 'dW')] = (flop, lambda dy=dy, x=x, dw=dw: K.gemm_tn(dy, x, out=dw),
                                            lambda dy=dy, x=x: torch.matmul(dy.t(), x))
+    for name, (flop, mine, lib) in cases.items():
+        a = statistics.median(timeit(mine) for _ in range(3))
+        b = statistics.median(timeit(lib) for _ in range(3))
+        print(f'{name:14s} mine {a:8.1f} us ({flop / a / 1e6:6.1f} TF)   library {b:8.1f} us ({flop / b / 1e6:6.1f} TF)', flush=True)
+    if 'attn' not in sys.argv:
+        return
+    cases = {}
     q = torch.randn(B * T, d, device=DEV)
     qh = q.view(B, T, h, 64).permute(0, 2, 1, 3)
     k_ = torch.randn(B, h, T, 64, device=DEV)
