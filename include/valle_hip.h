@@ -62,6 +62,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16
        VH_TUNE_TILE_DMA = 4,        /* large-M GEMM operand staging: 0 (default) = LDS-DMA when K % 32 == 0,
                                        1 = always through registers, 2 = LDS-DMA whenever eligible */
        VH_TUNE_REDUCE_BLOCK = 3,    /* threads per workgroup of the split-K reduce: 64, 128 (default), 256 */
+       VH_TUNE_SPLITK_FIXUP = 5,    /* wide-K decode GEMM split over K: 0 (default) = slabs + reduce kernel; 2 = one launch,
+                                       the last K slice to arrive sums the slabs (measured slower: three dependent
+                                       memory-side round trips cost more than a kernel boundary) */
        VH_TUNE_COUNT = 8 };
 int vh_set_tuning(int knob, int value);
 
@@ -103,10 +106,15 @@ int vh_linear(const float* A, int lda, const float* W, const float* bias, const 
 
 /* Same contract as vh_linear without the fused LayerNorm, plus a caller-owned workspace of
  * vh_linear_ws_bytes(M,N,K) bytes: for M <= 64 and K > 1024 (linear_2, K = dim_feedforward) the K
- * range is split over ~256 workgroups whose partial sums meet in the workspace and are added in a
- * fixed order by a second small kernel (bitwise reproducible; no atomics).  The same is done for
- * M > 64 when the (M,N) grid has at most 256 tiles of 128x128 and K >= 1024 (one utterance through
- * the NAR stack, a short prefill): K slices in the second grid dimension of the tile kernel.
+ * range is split over ~256 workgroups whose partial sums meet in the workspace and are added in
+ * slice order by a second small kernel (bitwise reproducible; no floating-point atomics).  The same
+ * is done for M > 64 when the (M,N) grid has at most 256 tiles of 128x128 and K >= 1024 (one
+ * utterance through the NAR stack, a short prefill): K slices in the second grid dimension of the
+ * tile kernel.  (vh_set_tuning(VH_TUNE_SPLITK_FIXUP, 2) selects a single-launch form for M <= 64 — a
+ * slice publishes its slab with write-through stores, takes a ticket on its column block's arrival
+ * counter and the last slice to arrive sums the slabs — measured 1 us per layer slower than the two
+ * launches; its counters are the first 4096 bytes of the workspace, so ZERO THE WORKSPACE ONCE before
+ * its first use; every call leaves them zero again.)
  * Falls back to vh_linear when the shape does not split or workspace == NULL. */
 size_t vh_linear_ws_bytes(int M, int N, int K);
 int vh_linear_ws(const float* A, int lda, const float* W, const float* bias, const float* residual,

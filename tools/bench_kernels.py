@@ -83,7 +83,7 @@ def bench_gemm():
     cl = torch.zeros(B, device=DEV, dtype=torch.int32)
     big = torch.zeros(256 * 1024 * 1024 // 4, device=DEV)
     ln = (g, b, None, None, 1e-5)
-    ws2 = torch.empty(_lib.lib().vh_linear_ws_bytes(B, d, dff) // 4, device=DEV)
+    ws2 = torch.zeros(_lib.lib().vh_linear_ws_bytes(B, d, dff) // 4, device=DEV)
     i = [0]
 
     def nxt():
@@ -122,9 +122,11 @@ def bench_gemm():
         'out-proj (N=512,K=512)': lambda: K.linear(x, wo[nxt()], bo, o1, out=o1),
         'ffn1+ln  (N=2048,K=512)': lambda: K.linear(x, w1[nxt()], b1, out=o2, act=1, ln=ln),
         'ffn2     (N=512,K=2048)': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
-        'ffn2-splitk reduce=64thr': tuned(3, 64, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
-        'ffn2-splitk reduce=128thr': tuned(3, 128, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
-        'ffn2-splitk reduce=256thr': tuned(3, 256, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
+        'ffn2-splitk one launch (last slice sums)': tuned(5, 2, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
+        'ffn2-splitk two launches': lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2),
+        'ffn2 no split, 8-row groups x 16 waves': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
+        'ffn2 no split, no row groups': tuned(2, 2, lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1)),
+        'ffn2-splitk reduce=64thr, two launches': tuned(3, 64, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
     }
     # graph-captured so the Python/ctypes launch cost is out of the picture
     for name, fn in cases.items():

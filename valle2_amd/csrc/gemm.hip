@@ -40,6 +40,9 @@ struct GemmArgs {
     int T, S_max, d_model, n_heads;
     float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
     int ldx;
+    float* slab;  // EPI_FIXUP: partial sums [slice][M][lds] and one arrival counter per column block
+    int lds;
+    int* counters;
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
 #ifdef VH_STAMPS
@@ -57,7 +60,8 @@ struct GemmArgs {
 #define STAMP(k)
 #endif
 
-enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2, EPI_ACC64 = 3 };
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2, EPI_ACC64 = 3,
+       EPI_FIXUP = 4 /* split-K slabs + the last-arriving slice of a column block sums them (skinny kernel) */ };
 
 // ---- accumulator form of the residual stream (decode step) ---------------------------------------
 // The split-K slices of linear_2 add their partial sums straight onto an fp64 copy of the residual
@@ -71,6 +75,26 @@ __device__ __forceinline__ f32x4 ld4(const double* p) {
     typedef double d64x2 __attribute__((ext_vector_type(2)));
     const d64x2 lo = *reinterpret_cast<const d64x2*>(p), hi = *reinterpret_cast<const d64x2*>(p + 2);
     return f32x4{(float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y};
+}
+
+// Agent-scope relaxed accesses (global_store / global_load with sc1): written through to / read from the
+// memory side, past the per-XCD L2s, so workgroups on different XCDs exchange data INSIDE one launch without the
+// full-cache fences (__threadfence() = buffer_wbl2 + buffer_inv: measured 24 us per launch here, every wave of
+// 256 workgroups writing back and invalidating a whole L2).  Ordering is by s_waitcnt vmcnt(0) (gfx9 counts
+// stores in vmcnt) + the ticket atomic.
+__device__ __forceinline__ void st4_agent(float* p, f32x4 v) {
+    uint64_t* q = reinterpret_cast<uint64_t*>(p);
+    const uint64_t lo = ((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
+    const uint64_t hi = ((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
+    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
+    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)),
+                 __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32))};
 }
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
@@ -863,7 +887,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         if (LN == 2) {                       // c2 carries the bias
             e_c1 = ld4(ln.c1 + en);
             e_bias = ld4(ln.c2 + en);
-        } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
+        } else if ((EPI == EPI_PLAIN || EPI == EPI_FIXUP) && a.bias) e_bias = ld4(a.bias + en);
+        if (EPI == EPI_FIXUP && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         if (EPI == EPI_PLAIN && a.res) {
             if (X64 & 2) e_res = ld4(reinterpret_cast<const double*>(a.res) + (int64_t)em * a.ldr + en);
             else e_res = ld4(a.res + (int64_t)em * a.ldr + en);
@@ -952,6 +977,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
                     unsafeAtomicAdd(dst + j, (t + VH_GRID_MAGIC) - VH_GRID_MAGIC);
                 }
             }
+        } else if (EPI == EPI_FIXUP) {
+            // raw partial of K slice blockIdx.y (N % 16 == 0 and every row group whole or guarded by fin)
+            if (fin) st4_agent(a.slab + ((int64_t)blockIdx.y * a.M + em) * a.lds + en, sacc);
         } else if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
@@ -977,6 +1005,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
                 float* base = which == 1 ? a.kc : a.vc;
                 st4(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
             }
+        }
+    }
+    if (EPI == EPI_FIXUP) {
+        // Split-K without a second launch: every slice publishes its slab (release), takes a ticket on its
+        // column block's counter, and the LAST slice to arrive adds all slabs IN SLICE ORDER — the sum does not
+        // depend on who is last, so the result is bitwise reproducible — and applies bias + residual.  No slice
+        // waits for another (no spinning): a workgroup that is not last simply ends.
+        __shared__ int s_ticket;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's write-through slab stores are done
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(a.counters + blockIdx.x, 1);
+        __syncthreads();
+        if (s_ticket != (int)gridDim.y - 1) return;
+        if (tid == 0) a.counters[blockIdx.x] = 0;          // ready for the next launch (graph replay)
+        if (tid < MT * 64 && fin) {
+            const float* p = a.slab + (int64_t)em * a.lds + en;
+            const int64_t stride = (int64_t)a.M * a.lds;
+            f32x4 part[16];
+#pragma unroll
+            for (int sidx = 0; sidx < 16; ++sidx)
+                part[sidx] = sidx < (int)gridDim.y ? ld4_agent(p + sidx * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 tot = part[0];
+#pragma unroll
+            for (int sidx = 1; sidx < 16; ++sidx) tot += part[sidx];
+            tot += e_bias;
+            if (a.act == VH_ACT_GELU_ERF) {
+                tot.x = gelu_erf(tot.x); tot.y = gelu_erf(tot.y); tot.z = gelu_erf(tot.z); tot.w = gelu_erf(tot.w);
+            }
+            st4(a.out + (int64_t)em * a.ldo + en, tot + e_res);
         }
     }
     STAMP(5);
@@ -1035,9 +1092,11 @@ static int splitk_plan(int M, int N, int K) {
     return splits >= 2 ? splits : 0;
 }
 
+#define VH_WS_COUNTER_BYTES 4096   // arrival counters of the single-launch split-K (one int per column block)
+
 extern "C" size_t vh_linear_ws_bytes(int M, int N, int K) {
     const int splits = splitk_plan(M, N, K);
-    return splits ? (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
+    return splits ? VH_WS_COUNTER_BYTES + (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
 }
 
 // =============================================================================================
@@ -1081,8 +1140,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool has_ln = ln.gamma != nullptr || ln.c1 != nullptr;
         const bool fold = ln.c1 != nullptr;
         // one workgroup per (16 columns, 16 rows) instead of (16 columns, all rows): see the kernel
-        const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && !wide && EPI != EPI_PARTIAL &&
-                               EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
+        const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && (!wide || a.K % 2048 == 0) &&
+                               EPI != EPI_PARTIAL && EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
         GemmArgs ag = a;                  // groups of 16 rows, or of 8 while that keeps the grid within the CUs
         if (rowgroups) {
             ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) <= 256) ? 8 : 16;
@@ -1143,8 +1202,8 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             if (a.K % 256 == 0) SF_MT(8, 2, 0, 1);
             if (a.K % 128 == 0) SF_MT(8, 1, 0, 1);
         } else {
-            if (a.K % 2048 == 0 && mt <= 2) {
-                if (mt == 1) SF(1, 16, 8, 0, 1); else SF(2, 16, 8, 0, 1);
+            if (a.K % 2048 == 0 && (mt <= 2 || rowgroups)) {
+                if (mt == 1 || rowgroups) SF(1, 16, 8, 0, 1); else SF(2, 16, 8, 0, 1);
                 VH_CHECK_LAUNCH(name);
                 return VH_OK;
             }
@@ -1380,7 +1439,8 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     if (M == 0) return VH_OK;
     const int lds_ = (N + 3) / 4 * 4;
     GemmArgs part{};
-    part.A = A; part.lda = lda; part.W = W; part.out = (float*)workspace; part.ldo = lds_; part.M = M;
+    float* slabs = (float*)((char*)workspace + VH_WS_COUNTER_BYTES);
+    part.A = A; part.lda = lda; part.W = W; part.out = slabs; part.ldo = lds_; part.M = M;
     part.N = N; part.K = K; part.act = VH_ACT_NONE; part.k_len = K / splits;
     LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
     if (int rc = check_gemm("vh_linear_ws", part, none)) return rc;
@@ -1400,12 +1460,26 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
         const int items_t = M * (lds_ / 4);
         const int rbt = 256;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items_t + rbt - 1) / rbt), dim3(rbt), 0, s,
-                           (const float*)workspace, splits, fin, lds_);
+                           (const float*)slabs, splits, fin, lds_);
         VH_CHECK_LAUNCH("vh_linear_ws");
         return VH_OK;
     }
     dim3 grid((N + 15) / 16, splits);
     const int mt = (M + 15) / 16;
+    // one launch: the last slice of a column block to arrive sums the slabs (N % 16 == 0: whole column groups;
+    // the counters live in the first VH_WS_COUNTER_BYTES of the workspace, zero before the first call and
+    // left zero by every call)
+    if (N % 16 == 0 && (int)grid.x * (int)sizeof(int) <= VH_WS_COUNTER_BYTES && splits <= 16 &&
+        vh_tuning(VH_TUNE_SPLITK_FIXUP) == 2) {
+        GemmArgs fx = part;
+        fx.slab = slabs; fx.lds = lds_; fx.counters = (int*)workspace;
+        fx.bias = bias; fx.res = residual; fx.ldr = ldr; fx.out = out; fx.ldo = ldo; fx.act = act;
+        if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
+        else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
+        else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
+        VH_CHECK_LAUNCH("vh_linear_ws");
+        return VH_OK;
+    }
     // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
     if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
     else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
@@ -1414,7 +1488,7 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     // small workgroups: the slabs (splits x 64 KB) are pulled through as many CUs as possible
     const int rb = vh_tuning(VH_TUNE_REDUCE_BLOCK) > 0 ? vh_tuning(VH_TUNE_REDUCE_BLOCK) : 128;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((items + rb - 1) / rb), dim3(rb), 0, s,
-                       (const float*)workspace, splits, fin, lds_);
+                       (const float*)slabs, splits, fin, lds_);
     VH_CHECK_LAUNCH("vh_linear_ws");
     return VH_OK;
 }

@@ -133,7 +133,8 @@ class ForwardScratch:
         L = _lib.lib()
         self.ws_bytes = max(L.vh_linear_ws_bytes(rows, d, d), L.vh_linear_ws_bytes(rows, d, dff),
                             L.vh_linear_ws_bytes(rows, dff, d))
-        self.ws = torch.empty(self.ws_bytes // 4, device=device, dtype=torch.float32) if self.ws_bytes else None
+        # zeroed once: its head holds the arrival counters of the single-launch split-K (include/valle_hip.h)
+        self.ws = torch.zeros(self.ws_bytes // 4, device=device, dtype=torch.float32) if self.ws_bytes else None
 
 
 def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_dev=None,
@@ -190,7 +191,7 @@ class ArDecoder:
         self.logits = torch.zeros(batch, self.ldl, **f32)
         self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
         ws_bytes = _lib.lib().vh_linear_ws_bytes(batch, d, dff)
-        self.gemm_ws = torch.empty(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None
+        self.gemm_ws = torch.zeros(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None   # counters start at zero
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
         self.sum_logprobs = torch.zeros(batch, **f32)
         self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))

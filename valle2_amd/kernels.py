@@ -133,7 +133,7 @@ def linear_ws(a, w, bias=None, residual=None, out=None, act=ACT_NONE, workspace=
         raise _lib.VhError('linear_ws: residual shape')
     need = _lib.lib().vh_linear_ws_bytes(M, N, K)
     if workspace is None and need:
-        workspace = torch.empty(need // 4, device=a.device, dtype=torch.float32)
+        workspace = torch.zeros(need // 4, device=a.device, dtype=torch.float32)   # counters start at zero
     if need and workspace.numel() * 4 < need:
         raise _lib.VhError(f'linear_ws: workspace of {workspace.numel() * 4} B < {need} B')
     check(_lib.lib().vh_linear_ws(
