@@ -146,10 +146,27 @@ int vh_ln_fold(const float* W, const float* gamma, const float* beta, const floa
 int vh_linear_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
                      const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
                      int act, float ln_eps, void* stream);
-int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const float* Wf, const float* c1,
+int vh_linear_qkv_folded(const void* A, int a_form, int lda, const float* Wf, const float* c1,
                          const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
                          const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
-                         float ln_eps, void* stream);
+                         float ln_eps, int64_t a_slab_stride, void* stream);
+/* a_form: 0 = A is fp32 rows; 1 = fp64 accumulator rows (below); 2 = the TWO-SLAB form of the residual
+ * stream: row r = A[r] + A[a_slab_stride + r] (two fp32 slabs, added in the operand load).
+ *
+ * Two-slab residual stream (decode step, the default when dim_feedforward % 2048 == 0): linear_2 — the one
+ * GEMM of a decode step whose K is too long for one workgroup per column block — runs as two K slices that
+ * leave their partial sums in two slabs (slice 0 carries bias + residual) instead of slabs + a reduce
+ * launch; the consumers add the two on load:
+ *   vh_linear_to_x2(A = hidden, W2, b2, residual = x_mid, slabs)            linear_2 → slabs[0], slabs[1]
+ *   vh_linear_qkv_folded(A = slabs, a_form = 2, ...)                         LN1 + QKV of the next layer
+ *   vh_linear_x2(A = attn, a_two = 0, ..., residual = slabs, r_two = 1, ...) out-projection + residual → x_mid
+ *   vh_linear_x2(A = slabs, a_two = 1, ..., residual = NULL, r_two = 0, ...) the head after the last layer
+ * One launch less per layer (modules.py:277-279 residual adds; valle_ar.py:143-158).  Sums are in a fixed
+ * order: bitwise reproducible.  M <= 64, N % 16 == 0; K % 2048 == 0 for vh_linear_to_x2, K <= 1024 else. */
+int vh_linear_to_x2(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
+                    float* slabs, int lds, int64_t slab_stride, int M, int N, int K, void* stream);
+int vh_linear_x2(const float* A, int a_two, int lda, const float* W, const float* bias, const float* residual,
+                 int r_two, int ldr, int64_t slab_stride, float* out, int ldo, int M, int N, int K, void* stream);
 
 /* ---- residual stream in fp64 accumulator form (decode path, M <= 64) -------------------------
  * linear_2 at M <= 64 is split over K (one CU pulls ~25 GB/s, see vh_linear_ws).  Instead of slabs
@@ -160,7 +177,7 @@ int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const float* Wf, con
  * bitwise reproducible, and closer to the real sum than an fp32 reduction.  acc (M,N) ldacc doubles
  * must hold zeros (or an earlier such sum) on entry.  N % 16 == 0, K % 128 == 0.
  * Consumers of the fp64 rows:
- *   vh_linear_qkv_folded(A = acc, a_f64 = 1, ...)                  LN1 + QKV of the next layer
+ *   vh_linear_qkv_folded(A = acc, a_form = 1, ...)                 LN1 + QKV of the next layer
  *   vh_linear_x64(A = acc, a_f64 = 1, ..., residual64 = NULL, ...) plain Linear on the rows (head)
  *   vh_linear_x64(A fp32, a_f64 = 0, ..., residual64 = acc, ...)   out = A W^T + bias + acc, and the
  *       rows of acc are CLEARED as they are read (N % 16 == 0), ready for the next vh_linear_acc64
@@ -283,6 +300,10 @@ typedef struct {
      * the split-K workspace + reduce launch.  On entry of a step the token embedding is in x64 then. */
     double *x64;
     float *xmid;
+    /* optional (default in valle2_amd when dim_feedforward % 2048 == 0 and the weights are folded): the
+     * residual stream between layers in the two-slab form, xs = 2 x (B, d) floats (slab stride B*d) — no
+     * split-K workspace, no reduce launch.  Ignored when x64 is set. */
+    float *xs;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

@@ -39,20 +39,22 @@ def utterances(cfg, n, text, frames, seed0):
 
 
 def test_config2_full_size_properties():
-    m, cfg, _ = build('ValleAR', dict(AR12, num_beams=32, max_audio_len=96), std=0.05)
+    # all 512 new tokens of configs[1] (context 1024 -> 1536), as the bench decodes them
+    m, cfg, _ = build('ValleAR', dict(AR12, num_beams=32, max_audio_len=512), std=0.05)
     texts, firsts = utterances(cfg, 16, 256, 767, 4000)
     texts, firsts = texts + texts, firsts + firsts               # rows 16..31 repeat rows 0..15
-    a = m.generate_batch(texts, firsts, max_new=96)
-    b = m.generate_batch(texts, firsts, max_new=96)
-    e = m.generate_batch(texts, firsts, max_new=96, use_graph=False)
-    assert a.shape == (32, 768 + 96)
+    a = m.generate_batch(texts, firsts, max_new=512)
+    b = m.generate_batch(texts, firsts, max_new=512)
+    e = m.generate_batch(texts, firsts, max_new=512, use_graph=False)
+    assert a.shape == (32, 768 + 512)
+    assert int((a[:, 768:] == cfg.eos_token).sum()) == 0
     assert torch.equal(a, b), 'two graph runs differ: the decode step is not deterministic'
     assert torch.equal(a, e), 'graph replay and eager launches disagree'
     assert torch.equal(a[:16], a[16:]), 'identical rows of one batch decoded differently'
     assert len({tuple(r.tolist()) for r in a[:16, 768:].cpu()}) > 1, 'distinct utterances expected to differ'
     # batch invariance: 4 of the rows alone in a batch of 4 (different kernel shapes: MT=1, split-KV)
     sub = m.generate_batch(texts[:4], firsts[:4], max_new=96)
-    same = (sub[:, 768:] == a[:4, 768:])
+    same = (sub[:, 768:] == a[:4, 768:768 + 96])
     first_diff = (~same).float().argmax(dim=1)
     assert bool(same.all()) or bool((first_diff[~same.all(dim=1)] > 8).all()), \
         'a row diverges from its batched self within the first steps'

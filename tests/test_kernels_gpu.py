@@ -600,3 +600,49 @@ def test_greedy_step(K):
                   dv2['clen'], x64)
     assert torch.equal(x64.cpu(), (emb[exp] + pe[4, 0]).double())
     assert torch.equal(dv2['codes'], dv['codes'])
+
+
+@pytest.mark.parametrize('M', [1, 8, 20, 32, 64])
+def test_two_slab_residual_stream_primitives(K, M):
+    """vh_linear_to_x2 / vh_linear_x2 / vh_linear_qkv_folded(a_form=2): linear_2 as two K slices kept apart, the
+    consumers adding the slabs on load.  Against torch fp32 on the CPU; slab sums reproducible bit for bit."""
+    g = torch.Generator().manual_seed(M)
+    d, dff, h = 512, 2048, 8   # noqa: E741
+    hid = torch.randn(M, dff, generator=g)
+    w2, b2 = 0.05 * torch.randn(d, dff, generator=g), 0.1 * torch.randn(d, generator=g)
+    xmid = torch.randn(M, d, generator=g)
+    slabs = torch.empty(2, M, d, device=DEV)
+    K.linear_to_x2(hid.to(DEV), w2.to(DEV), slabs, bias=b2.to(DEV), residual=xmid.to(DEV))
+    x_ref = F.linear(hid, w2, b2) + xmid
+    close(slabs.sum(0), x_ref, atol=5e-5)
+    close(slabs[1], F.linear(hid[:, dff // 2:], w2[:, dff // 2:]), atol=5e-5)      # slice 1: raw partial
+    again = torch.empty_like(slabs)
+    K.linear_to_x2(hid.to(DEV), w2.to(DEV), again, bias=b2.to(DEV), residual=xmid.to(DEV))
+    assert torch.equal(again, slabs)
+    x = slabs.sum(0)                                                  # what every consumer should see
+    # out-projection with the residual in two-slab form
+    attn, wo, bo = torch.randn(M, d, generator=g), 0.05 * torch.randn(d, d, generator=g), 0.1 * torch.randn(d, generator=g)
+    o = K.linear_x2(attn.to(DEV), wo.to(DEV), bias=bo.to(DEV), residual=slabs)
+    close(o, F.linear(attn, wo, bo) + x.cpu(), atol=5e-5)
+    assert torch.equal(o, K.linear(attn.to(DEV), wo.to(DEV), bo.to(DEV), residual=x.contiguous()))
+    # head on two-slab rows (ragged N = 1025)
+    wh = 0.05 * torch.randn(1025, d, generator=g)
+    lg = K.linear_x2(slabs, wh.to(DEV))
+    close(lg, F.linear(x.cpu(), wh), atol=5e-5)
+    assert torch.equal(lg, K.linear(x.contiguous(), wh.to(DEV)))
+    # folded LayerNorm + QKV on two-slab rows == the same kernel on the summed rows
+    wq = 0.05 * torch.randn(3 * d, d, generator=g)
+    gm, bt = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    folded = K.ln_fold(wq.to(DEV), gm.to(DEV), bt.to(DEV))
+    outs = []
+    for a in (slabs, x.contiguous()):
+        q = torch.empty(M, d, device=DEV)
+        kc, vc = torch.zeros(M, h, 4, 64, device=DEV), torch.zeros(M, h, 4, 64, device=DEV)
+        cl = torch.full((M,), 2, device=DEV, dtype=torch.int32)
+        K.linear_qkv_folded(a, folded, q, kc, vc, M, 1, h, cache_len=cl)
+        outs.append((q, kc, vc))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    ref = F.linear(F.layer_norm(x.cpu(), (d,), gm, bt, 1e-5), wq)
+    close(outs[0][0], ref[:, :d], atol=1e-4)
+    close(outs[0][1][:, :, 2].reshape(M, d), ref[:, d:2 * d], atol=1e-4)

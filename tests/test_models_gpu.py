@@ -235,14 +235,15 @@ def test_ar_generate_golden(which, graph):
     tokens_match(out, gold['tokens'], gold['margin'])
 
 
-@pytest.mark.parametrize('fold,acc64', [(False, False), (True, False), (True, True)])
-def test_ar_generate_golden_every_decode_engine(fold, acc64):
-    """The decode step has three forms of its GEMM chain (LayerNorm in the operand load + split-K
-    reduce; folded LayerNorm; folded + fp64 accumulator residual stream).  Each must reproduce the
-    reference's greedy tokens."""
+@pytest.mark.parametrize('fold,acc64,x2', [(False, False, False), (True, False, False), (True, True, False),
+                                           (True, False, True)])
+def test_ar_generate_golden_every_decode_engine(fold, acc64, x2):
+    """The decode step has four forms of its GEMM chain (LayerNorm in the operand load + split-K
+    reduce; folded LayerNorm; folded + fp64 accumulator residual stream; folded + two-slab residual
+    stream, the default at dim_feedforward % 2048 == 0).  Each must reproduce the reference's greedy tokens."""
     from valle2_amd import engine
-    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL
-    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL = fold, acc64
+    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL
+    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL = fold, acc64, x2
     try:
         for which in ('tiny', 'mid'):
             gold = load_golden(f'ar_generate_{which}')
@@ -250,8 +251,10 @@ def test_ar_generate_golden_every_decode_engine(fold, acc64):
             m = build('ValleAR', kw, sd)
             out = m.generate(*[u.to(DEV) for u in utt])
             tokens_match(out, gold['tokens'], gold['margin'])
+            if which == 'mid':                     # dff = 2048: the two-slab form is available
+                assert m.last_generate_stats['two_slab'] == (x2 and not acc64)
     finally:
-        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL = old
+        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL = old
 
 
 def test_generate_batch_distinct_rows_vs_oracle():

@@ -43,7 +43,7 @@ class VhArDecoderDesc(C.Structure):
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
-        ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p),
+        ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p), ('xs', C.c_void_p),
     ]
 
 
@@ -84,7 +84,11 @@ SIGNATURES = {
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                        c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.c_float, C.c_void_p]),
+                                       C.c_float, C.c_int64, C.c_void_p]),
+    'vh_linear_to_x2': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64,
+                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_linear_x2': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64,
+                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_linear_acc64': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_linear_x64': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,

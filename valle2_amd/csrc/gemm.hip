@@ -40,6 +40,7 @@ struct GemmArgs {
     int T, S_max, d_model, n_heads;
     float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
     int ldx;
+    int64_t s2;   // two-slab form of the residual stream (X64 bits 2/3, EPI_SLAB2): element offset of slab 1
     float* slab;  // EPI_FIXUP: partial sums [slice][M][lds] and one arrival counter per column block
     int lds;
     int* counters;
@@ -61,7 +62,8 @@ struct GemmArgs {
 #endif
 
 enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2, EPI_ACC64 = 3,
-       EPI_FIXUP = 4 /* split-K slabs + the last-arriving slice of a column block sums them (skinny kernel) */ };
+       EPI_FIXUP = 4 /* split-K slabs + the last-arriving slice of a column block sums them (skinny kernel) */,
+       EPI_SLAB2 = 5 /* two K slices, each leaves its partial (slice 0: + bias + residual) in its own slab */ };
 
 // ---- accumulator form of the residual stream (decode step) ---------------------------------------
 // The split-K slices of linear_2 add their partial sums straight onto an fp64 copy of the residual
@@ -798,6 +800,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //      the fp64 accumulator form (ldr in doubles) and is cleared once read, ready for the next
 //      EPI_ACC64 launch.  EPI_ACC64: a.out is that fp64 buffer (ldo in doubles); slice 0 also adds the
 //      fp32 bias and residual.
+//      bit 2 = the A operand is the TWO-SLAB form of the residual stream (row = slab0[row] + slab1[row],
+//      slab 1 at element offset a.s2): linear_2 runs as two K slices whose partials stay apart
+//      (EPI_SLAB2; slice 0 carries bias + residual) and the consumers add the two on load — no reduce
+//      launch in the decode step; bit 3 = the residual is in that form.
 template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
     using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
@@ -834,12 +840,16 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
     const float* bp = LN == 1 ? ln.beta + koff : nullptr;
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
+    f32x4 xf2[(X64 & 4) ? PW : 1][MT];              // slab 1 of a two-slab operand, added before the MFMAs
     auto issue = [&](int kbase) {
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
             wf[c] = ld4(wp + kbase + 16 * c);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
+            for (int mt = 0; mt < MT; ++mt) {
+                xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
+                if (X64 & 4) xf2[c][mt] = ld4(xp[mt] + a.s2 + kbase + 16 * c);
+            }
             if (LN == 1) {
                 gm[c] = ld4(gp + kbase + 16 * c);
                 bt[c] = ld4(bp + kbase + 16 * c);
@@ -856,6 +866,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         const AT* xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
+        if (X64 & 4) {
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) v[jj] += ld4(xr + a.s2 + 64 * jj);
+        }
     };
     auto ln_reduce = [&](int r0) {
         // DPP row g of the wave reduces activation row 4*w + g (two-pass mean / centred variance)
@@ -892,6 +906,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
         if (EPI == EPI_PLAIN && a.res) {
             if (X64 & 2) e_res = ld4(reinterpret_cast<const double*>(a.res) + (int64_t)em * a.ldr + en);
             else e_res = ld4(a.res + (int64_t)em * a.ldr + en);
+            if (X64 & 8) e_res += ld4(a.res + a.s2 + (int64_t)em * a.ldr + en);
+        }
+        if (EPI == EPI_SLAB2 && blockIdx.y == 0) {
+            if (a.bias) e_bias = ld4(a.bias + en);
+            if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         }
         if (EPI == EPI_ACC64 && blockIdx.y == 0) {
             if (a.bias) e_bias = ld4(a.bias + en);
@@ -940,6 +959,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
                                     ld4(ln.ada_shift + koff + kbase + 16 * c);
                 }
         }
+        if (X64 & 4) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[c][mt] += xf2[c][mt];
+        }
 #pragma unroll
         for (int c = 0; c < PW; ++c)
 #pragma unroll
@@ -977,6 +1002,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse l
                     unsafeAtomicAdd(dst + j, (t + VH_GRID_MAGIC) - VH_GRID_MAGIC);
                 }
             }
+        } else if (EPI == EPI_SLAB2) {
+            // slice blockIdx.y's partial into its own slab; slice 0 carries bias + residual (zeros otherwise)
+            if (fin) st4(a.out + (int64_t)blockIdx.y * a.s2 + (int64_t)em * a.ldo + en, (sacc + e_bias) + e_res);
         } else if (EPI == EPI_FIXUP) {
             // raw partial of K slice blockIdx.y (N % 16 == 0 and every row group whole or guarded by fin)
             if (fin) st4_agent(a.slab + ((int64_t)blockIdx.y * a.M + em) * a.lds + en, sacc);
@@ -1130,7 +1158,7 @@ template <int EPI>
 static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, int x64 = 0) {
     if (a.M == 0) return VH_OK;
     VH_REQUIRE(x64 == 0 || (a.M <= 64 && a.K <= 1024 && a.K % 128 == 0), VH_EUNSUPPORTED,
-               "%s: the fp64 accumulator form is the decode path: M <= 64, K <= 1024, K %% 128 == 0 "
+               "%s: the fp64 accumulator / two-slab forms are the decode path: M <= 64, K <= 1024, K %% 128 == 0 "
                "(M=%d K=%d)", name, a.M, a.K);
     const bool train_epi = a.aux != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
@@ -1143,9 +1171,18 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && (!wide || a.K % 2048 == 0) &&
                                EPI != EPI_PARTIAL && EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
         GemmArgs ag = a;                  // groups of 16 rows, or of 8 while that keeps the grid within the CUs
+        const int slices = EPI == EPI_SLAB2 ? 2 : 1;
         if (rowgroups) {
-            ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) <= 256) ? 8 : 16;
+            ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) * slices <= 256) ? 8 : 16;
             grid.z = (a.M + ag.rg_rows - 1) / ag.rg_rows;
+        }
+        if constexpr (EPI == EPI_SLAB2) {   // two K slices of k_len = K / 2 (a multiple of 1024): 16 waves x 4 steps per pass
+            grid.y = 2;
+            if (rowgroups || mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
+            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
+            else hipLaunchKernelGGL((gemm_skinny_fast<4, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
+            VH_CHECK_LAUNCH(name);
+            return VH_OK;
         }
         // ---- compact fast path: K = 16*NW*PW*passes
 #define SFX(MT, NW, PW, LN, NJ, X) \
@@ -1164,22 +1201,32 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         // ---- fp64 accumulator form of the residual stream (x64: 1 = A operand, 2 = consumed residual)
         if (x64) {
             if constexpr (EPI == EPI_QKV) {
-                VH_REQUIRE(x64 == 1 && fold, VH_EUNSUPPORTED, "%s: fp64 rows need the folded LayerNorm", name);
-                if (a.K == 128) SFX_MT(8, 1, 2, 2, 1);
-                if (a.K == 256) SFX_MT(8, 2, 2, 4, 1);
-                if (a.K == 512) SFX_MT(8, 4, 2, 8, 1);
-                if (a.K == 1024) SFX_MT(8, 4, 2, 16, 1);
-            } else if constexpr (EPI == EPI_PLAIN) {
-                VH_REQUIRE(!has_ln, VH_EUNSUPPORTED, "%s: fp64 rows / residual without LayerNorm only", name);
+                VH_REQUIRE((x64 == 1 || x64 == 4) && fold, VH_EUNSUPPORTED,
+                           "%s: fp64 / two-slab rows need the folded LayerNorm", name);
                 if (x64 == 1) {
-                    if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, 1);
-                    if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, 1);
-                    SFX_MT(8, 1, 0, 1, 1);
+                    if (a.K == 128) SFX_MT(8, 1, 2, 2, 1);
+                    if (a.K == 256) SFX_MT(8, 2, 2, 4, 1);
+                    if (a.K == 512) SFX_MT(8, 4, 2, 8, 1);
+                    if (a.K == 1024) SFX_MT(8, 4, 2, 16, 1);
                 } else {
-                    if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, 2);
-                    if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, 2);
-                    SFX_MT(8, 1, 0, 1, 2);
+                    if (a.K == 128) SFX_MT(8, 1, 2, 2, 4);
+                    if (a.K == 256) SFX_MT(8, 2, 2, 4, 4);
+                    if (a.K == 512) SFX_MT(8, 4, 2, 8, 4);
+                    if (a.K == 1024) SFX_MT(8, 4, 2, 16, 4);
                 }
+            } else if constexpr (EPI == EPI_PLAIN) {
+                VH_REQUIRE(!has_ln, VH_EUNSUPPORTED, "%s: fp64 / two-slab rows or residual without LayerNorm only", name);
+#define X_BY_K(X)                                      \
+    do {                                               \
+        if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, X);     \
+        if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, X);     \
+        SFX_MT(8, 1, 0, 1, X);                         \
+    } while (0)
+                if (x64 == 1) X_BY_K(1);
+                else if (x64 == 2) X_BY_K(2);
+                else if (x64 == 4) X_BY_K(4);
+                else if (x64 == 8) X_BY_K(8);
+#undef X_BY_K
             }
             vh_set_error("%s: no fp64-form kernel for K=%d", name, a.K);
             return VH_EUNSUPPORTED;
@@ -1268,6 +1315,38 @@ extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float
     return launch_gemm<EPI_PLAIN>("vh_linear_ex", a, ln, (hipStream_t)stream);
 }
 
+// ---- two-slab form of the residual stream (decode step; see gemm_skinny_fast) ----------------------
+extern "C" int vh_linear_to_x2(const float* A, int lda, const float* W, const float* bias, const float* residual,
+                               int ldr, float* slabs, int lds, int64_t slab_stride, int M, int N, int K,
+                               void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = slabs; a.ldo = lds;
+    a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K / 2; a.s2 = slab_stride;
+    LnFuse none{};
+    VH_REQUIRE(M <= 64 && N % 16 == 0 && K % 2048 == 0, VH_EUNSUPPORTED,
+               "vh_linear_to_x2: decode path only: M <= 64, N %% 16 == 0, K %% 2048 == 0 (M=%d N=%d K=%d)", M, N, K);
+    VH_REQUIRE(lds >= N && (!residual || ldr >= N) && slab_stride >= (int64_t)M * lds && slab_stride % 4 == 0,
+               VH_EINVAL, "vh_linear_to_x2: lds/ldr/slab_stride");
+    if (int rc = check_gemm("vh_linear_to_x2", a, none)) return rc;
+    return launch_gemm<EPI_SLAB2>("vh_linear_to_x2", a, none, (hipStream_t)stream);
+}
+
+extern "C" int vh_linear_x2(const float* A, int a_two, int lda, const float* W, const float* bias,
+                            const float* residual, int r_two, int ldr, int64_t slab_stride, float* out, int ldo,
+                            int M, int N, int K, void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K; a.s2 = slab_stride;
+    LnFuse none{};
+    VH_REQUIRE((a_two != 0) != (r_two != 0), VH_EINVAL,
+               "vh_linear_x2: exactly one of the operand rows and the residual is in the two-slab form");
+    VH_REQUIRE(!r_two || residual, VH_EINVAL, "vh_linear_x2: r_two without a residual");
+    VH_REQUIRE(ldo >= N && (!residual || ldr >= N) && slab_stride % 4 == 0 && slab_stride > 0, VH_EINVAL,
+               "vh_linear_x2: ldo/ldr/slab_stride");
+    if (int rc = check_gemm("vh_linear_x2", a, none)) return rc;
+    return launch_gemm<EPI_PLAIN>("vh_linear_x2", a, none, (hipStream_t)stream, a_two ? 4 : 8);
+}
+
 extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int ldq,
                              float* kcache, float* vcache, const int32_t* cache_len, int B, int T,
                              int d_model, int n_heads, int S_max, const float* ln_gamma,
@@ -1351,10 +1430,13 @@ extern "C" int vh_linear_folded(const float* A, int lda, const float* Wf, const 
     return launch_gemm<EPI_PLAIN>("vh_linear_folded", a, ln, (hipStream_t)stream);
 }
 
-extern "C" int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const float* Wf, const float* c1,
+extern "C" int vh_linear_qkv_folded(const void* A, int a_form, int lda, const float* Wf, const float* c1,
                                     const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
                                     const int32_t* cache_len, int B, int T, int d_model, int n_heads,
-                                    int S_max, float ln_eps, void* stream) {
+                                    int S_max, float ln_eps, int64_t a_slab_stride, void* stream) {
+    VH_REQUIRE(a_form == 0 || a_form == 1 || a_form == 2, VH_EINVAL, "vh_linear_qkv_folded: a_form=%d", a_form);
+    VH_REQUIRE(a_form != 2 || (a_slab_stride > 0 && a_slab_stride % 4 == 0), VH_EINVAL,
+               "vh_linear_qkv_folded: the two-slab form needs a_slab_stride");
     VH_REQUIRE(kcache && vcache, VH_EINVAL, "vh_linear_qkv_folded: null cache");
     VH_REQUIRE(B >= 0 && T >= 0 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
                "vh_linear_qkv_folded: d_model=%d must equal n_heads=%d x %d", d_model, n_heads, VH_HEAD_DIM);
@@ -1368,7 +1450,8 @@ extern "C" int vh_linear_qkv_folded(const void* A, int a_f64, int lda, const flo
     LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
     if (int rc = check_gemm("vh_linear_qkv_folded", a, ln)) return rc;
     if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
-    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream, a_f64 ? 1 : 0);
+    a.s2 = a_slab_stride;
+    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream, a_form == 1 ? 1 : (a_form == 2 ? 4 : 0));
 }
 
 // ---- fp64 accumulator form -----------------------------------------------------------------------

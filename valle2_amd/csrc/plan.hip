@@ -58,10 +58,13 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                VH_EINVAL, "vh_ar_decoder: null buffer in desc");
     VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
     VH_REQUIRE((d->x64 == nullptr) == (d->xmid == nullptr), VH_EINVAL, "vh_ar_decoder: x64 and xmid go together");
-    if (d->x64)
+    if (d->x64 || d->xs)
         for (int i = 0; i < d->n_layers; ++i)
             VH_REQUIRE(d->layers[i].wqkv_f && d->layers[i].w1_f, VH_EINVAL,
-                       "vh_ar_decoder: the fp64 accumulator form needs folded weights (layer %d)", i);
+                       "vh_ar_decoder: the fp64 accumulator / two-slab forms need folded weights (layer %d)", i);
+    VH_REQUIRE(!d->xs || d->x64 || (d->dff % 2048 == 0 && d->d_model <= 1024 && d->d_model % 128 == 0), VH_EUNSUPPORTED,
+               "vh_ar_decoder: the two-slab form needs dim_feedforward %% 2048 == 0 and d_model <= 1024 (dff=%d d=%d)",
+               d->dff, d->d_model);
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
     return VH_OK;
@@ -95,12 +98,17 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
+        const bool x2 = d.xs && !d.x64;              // residual stream between layers in the two-slab form
+        const int64_t ss = (int64_t)B * D;           // slab stride
         if (d.x64)
             TRY(vh_linear_qkv_folded(d.x64, 1, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
-                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
+                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, 0, s));
+        else if (x2 && i > 0)                        // layer 0 reads the token embedding (one tensor)
+            TRY(vh_linear_qkv_folded(d.xs, 2, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
+                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, ss, s));
         else if (L.wqkv_f)
             TRY(vh_linear_qkv_folded(d.x, 0, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
-                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
+                                     d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, 0, s));
         else
             TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
                               d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
@@ -137,6 +145,19 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
             TRY(vh_linear_acc64(d.hidden, d.dff, L.w2, L.b2, d.xmid, D, d.x64, D, B, D, d.dff, s));
             continue;
         }
+        if (x2) {
+            // out-proj + bias + residual (two slabs, or the embedding in layer 0) → x; LN2 + linear_1 + GELU;
+            // linear_2 as two K slices → the two slabs (slice 0 carries bias + residual x)
+            if (i > 0)
+                TRY(vh_linear_x2(d.attn, 0, D, L.wo, L.bo, d.xs, 1, D, ss, d.x, D, B, D, D, s));
+            else
+                TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
+                              nullptr, nullptr, 0.f, s));
+            TRY(vh_linear_folded(d.x, D, L.w1_f, L.w1_c1, L.w1_c2, nullptr, 0, d.hidden, d.dff, B, d.dff, D,
+                                 VH_ACT_GELU_ERF, d.ln_eps, s));
+            TRY(vh_linear_to_x2(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.xs, D, ss, B, D, d.dff, s));
+            continue;
+        }
         // out-proj + bias + residual (modules.py:171,277)
         TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
                       nullptr, nullptr, 0.f, s));
@@ -154,6 +175,8 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
     if (d.x64)
         TRY(vh_linear_x64(d.x64, 1, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, s));
+    else if (d.xs)
+        TRY(vh_linear_x2(d.xs, 1, D, d.proj_w, nullptr, nullptr, 0, 0, (int64_t)B * D, d.logits, dec->ldl, B, d.V, D, s));
     else
         TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
                       nullptr, nullptr, nullptr, nullptr, 0.f, s));

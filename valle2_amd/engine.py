@@ -52,6 +52,11 @@ def _layer_params(layer):
 # Forms of the decode step's GEMM chain (A/B switches; every form is under the same parity tests):
 FOLD_LAYERNORM = os.environ.get('VALLE2_FOLD_LN', '1') != '0'   # LayerNorm folded into the QKV / linear_1
                                                                  # weights (vh_ln_fold)
+TWO_SLAB_RESIDUAL = os.environ.get('VALLE2_X2', '0') == '1'     # residual stream between layers as two fp32 slabs
+                                                                 # (linear_2's two K halves, added on load by the
+                                                                 # consumers: no split-K reduce launch).  Off:
+                                                                 # measured equal within noise (620 vs 617 us per
+                                                                 # step), DESIGN.md §3, kept as an option.
 ACC64_RESIDUAL = os.environ.get('VALLE2_ACC64', '0') == '1'     # residual stream in fp64 accumulator form
                                                                  # (vh_linear_acc64: linear_2's K slices add
                                                                  # onto it with exact atomics, no reduce launch).
@@ -201,6 +206,9 @@ class ArDecoder:
         self.acc64 = bool(ACC64_RESIDUAL and self._folded is not None and d % 128 == 0 and dff % 128 == 0)
         self.x64 = torch.zeros(batch, d, device=dev, dtype=torch.float64) if self.acc64 else None
         self.xmid = torch.empty(batch, d, **f32) if self.acc64 else None
+        self.x2 = bool(TWO_SLAB_RESIDUAL and not self.acc64 and self._folded is not None and dff % 2048 == 0
+                       and d <= 1024 and d % 128 == 0)
+        self.xs = torch.zeros(2, batch, d, **f32) if self.x2 else None
         self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
@@ -214,7 +222,7 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
-            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid))
+            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid), xs=ptr(self.xs))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:

@@ -190,16 +190,62 @@ def linear_folded(a, folded, residual=None, out=None, act=ACT_NONE, eps=1e-5):
 
 
 def linear_qkv_folded(a, folded, q_out, kcache, vcache, B, T, n_heads, cache_len=None, eps=1e-5):
+    """`a`: (M, d) float32 / float64 rows, or a (2, M, d) float32 tensor = the two-slab form of the rows."""
     wf, c1, c2 = folded
+    form, stride = (1 if a.dtype == torch.float64 else 0), 0
+    if a.dim() == 3:
+        if a.shape[0] != 2 or not a.is_contiguous() or a.dtype != torch.float32:
+            raise _lib.VhError('linear_qkv_folded: the two-slab form is a contiguous (2, M, d) float32 tensor')
+        form, stride, a = 2, a.stride(0), a[0]
     M, d = a.shape
     S_max = kcache.shape[2]
     if M != B * T or tuple(wf.shape) != (3 * d, d) or tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM):
         raise _lib.VhError(f'linear_qkv_folded: shapes a={tuple(a.shape)} w={tuple(wf.shape)}')
     check(_lib.lib().vh_linear_qkv_folded(
-        _f32_or_f64(a, 'a').data_ptr(), int(a.dtype == torch.float64), a.stride(0), ptr(wf), ptr(c1), ptr(c2),
+        _f32_or_f64(a, 'a').data_ptr(), form, a.stride(0), ptr(wf), ptr(c1), ptr(c2),
         q_out.data_ptr(), q_out.stride(0), ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max,
-        eps, stream()), 'vh_linear_qkv_folded')
+        eps, stride, stream()), 'vh_linear_qkv_folded')
     return q_out
+
+
+def linear_to_x2(a, w, slabs, bias=None, residual=None):
+    """slabs (2, M, N) <- the two K halves of a @ w.T; slab 0 also carries bias + residual (decode rows)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if tuple(slabs.shape) != (2, M, N) or not slabs.is_contiguous() or w.shape[1] != K or not w.is_contiguous():
+        raise _lib.VhError(f'linear_to_x2: a {tuple(a.shape)} w {tuple(w.shape)} slabs {tuple(slabs.shape)}')
+    if residual is not None and (tuple(residual.shape) != (M, N) or residual.stride(1) != 1):
+        raise _lib.VhError('linear_to_x2: residual shape')
+    check(_lib.lib().vh_linear_to_x2(_dev_f32(a, 'a'), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+                                     _dev_f32(residual, 'residual') if residual is not None else None,
+                                     residual.stride(0) if residual is not None else 0, _dev_f32(slabs, 'slabs'), N,
+                                     slabs.stride(0), M, N, K, stream()), 'vh_linear_to_x2')
+    return slabs
+
+
+def linear_x2(a, w, bias=None, residual=None, out=None):
+    """out = a @ w.T + bias + residual where exactly one of `a` / `residual` is a (2, M, ·) two-slab tensor."""
+    a_two, r_two = a.dim() == 3, residual is not None and residual.dim() == 3
+    if a_two == r_two:
+        raise _lib.VhError('linear_x2: exactly one of a / residual must be in the two-slab form')
+    two = a if a_two else residual
+    if two.shape[0] != 2 or not two.is_contiguous():
+        raise _lib.VhError('linear_x2: the two-slab operand must be a contiguous (2, M, ·) tensor')
+    a2 = a[0] if a_two else a
+    M, K = a2.shape
+    N = w.shape[0]
+    if w.shape[1] != K or not w.is_contiguous():
+        raise _lib.VhError('linear_x2: weight shape')
+    if out is None:
+        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
+    r2 = None if residual is None else (residual[0] if r_two else residual)
+    if r2 is not None and tuple(r2.shape) != (M, N):
+        raise _lib.VhError('linear_x2: residual shape')
+    check(_lib.lib().vh_linear_x2(_dev_f32(a2, 'a'), int(a_two), a2.stride(0), ptr(_f32(w, 'w')), ptr(bias),
+                                  _dev_f32(r2, 'residual') if r2 is not None else None, int(r_two),
+                                  r2.stride(0) if r2 is not None else 0, two.stride(0), _dev_f32(out, 'out'),
+                                  out.stride(0), M, N, K, stream()), 'vh_linear_x2')
+    return out
 
 
 def _f32_or_f64(t, name):
