@@ -805,8 +805,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //      (EPI_SLAB2; slice 0 carries bias + residual) and the consumers add the two on load — no reduce
 //      launch in the decode step; bit 3 = the residual is in that form.
 template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(GemmArgs a, LnFuse ln) {
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
+                                                            int hM, int hN, GemmArgs a, LnFuse ln) {
     using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
+    // The operands every wave needs for its first loads travel as leading scalar arguments: with
+    // -mllvm -amdgpu-kernarg-preload-count the command processor places them in SGPRs at dispatch, so the
+    // weight / activation loads are issued without first waiting for a kernarg s_load round trip (a launch
+    // of this kernel is two or three dependent memory round trips long; that was one of them).
+    a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
     // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
@@ -1154,6 +1160,8 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
     return VH_OK;
 }
 
+#define SKINNY_ARGS(g) (g).A, (g).W, (g).lda, (g).K, (g).k_len, (g).M, (g).N
+
 template <int EPI>
 static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, int x64 = 0) {
     if (a.M == 0) return VH_OK;
@@ -1178,15 +1186,15 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         }
         if constexpr (EPI == EPI_SLAB2) {   // two K slices of k_len = K / 2 (a multiple of 1024): 16 waves x 4 steps per pass
             grid.y = 2;
-            if (rowgroups || mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
-            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
-            else hipLaunchKernelGGL((gemm_skinny_fast<4, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, ag, ln);
+            if (rowgroups || mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
+            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
+            else hipLaunchKernelGGL((gemm_skinny_fast<4, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
             VH_CHECK_LAUNCH(name);
             return VH_OK;
         }
         // ---- compact fast path: K = 16*NW*PW*passes
 #define SFX(MT, NW, PW, LN, NJ, X) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, ag, ln)
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln)
 #define SF(MT, NW, PW, LN, NJ) SFX(MT, NW, PW, LN, NJ, 0)
 #define SFX_MT(NW, PW, LN, NJ, X)                                              \
     do {                                                                       \
@@ -1474,7 +1482,7 @@ extern "C" int vh_linear_acc64(const float* A, int lda, const float* W, const fl
     hipStream_t s = (hipStream_t)stream;
     const int mt = (M + 15) / 16;
 #define ACC(MT, NW, PW) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI_ACC64, PW, 0, 1>), grid, dim3(NW * 64), 0, s, a, none)
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI_ACC64, PW, 0, 1>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(a), a, none)
 #define ACC_MT(NW, PW) do { if (mt == 1) ACC(1, NW, PW); else if (mt == 2) ACC(2, NW, PW); else ACC(4, NW, PW); } while (0)
     if (splits) {           // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
         dim3 grid((N + 15) / 16, splits);
@@ -1557,16 +1565,16 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
         GemmArgs fx = part;
         fx.slab = slabs; fx.lds = lds_; fx.counters = (int*)workspace;
         fx.bias = bias; fx.res = residual; fx.ldr = ldr; fx.out = out; fx.ldo = ldo; fx.act = act;
-        if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
-        else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
-        else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, fx, none);
+        if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
+        else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
+        else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
         VH_CHECK_LAUNCH("vh_linear_ws");
         return VH_OK;
     }
     // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
-    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
-    else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
-    else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, part, none);
+    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
+    else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
     const int items = M * (lds_ / 4);
     // small workgroups: the slabs (splits x 64 KB) are pulled through as many CUs as possible
     const int rb = vh_tuning(VH_TUNE_REDUCE_BLOCK) > 0 ? vh_tuning(VH_TUNE_REDUCE_BLOCK) : 128;
