@@ -198,6 +198,7 @@ def train_leg(dev, world, rank, small):
             loss = model.training_step(batch, **({'stage': 1 + i % 7} if name == 'ValleNAR' else {}))
             loss.backward()
             reducer.finish()
+            opt.sync_touched()
             opt.step(grad_scale=1.0 / world, max_norm=cfg.gradient_clip_val, zero_grad=True)
             if i >= warm:
                 rows += batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])

@@ -376,11 +376,17 @@ int vh_categorical_rows(const float* logits, int ld, int V, int rows, float temp
  *   p *= 1 - lr*wd;  m += (g - m)(1-b1);  v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)       (torch.optim.AdamW, amsgrad off).
  * param/grad/exp_avg/exp_avg_sq: n floats each (n % 4 == 0); zero_grad != 0 clears grad afterwards;
- * norm_out (1 float, optional) receives norm; workspace: vh_adamw_ws_bytes() bytes. */
+ * norm_out (1 float, optional) receives norm; workspace: vh_adamw_ws_bytes() bytes.
+ * block_slot / slot_step (both NULL: every element updates with `step`): torch.optim.AdamW keeps a step
+ * count per parameter and skips parameters whose grad is None (NAR trains one stage per step: the other
+ * stages' heads and embeddings receive nothing, valle_nar.py:76).  block_slot (n / 64 int32, device) maps
+ * each 64-float block to its parameter slot, slot_step (device) holds the slot's own step count for this
+ * update, 0 = skip the slot entirely (no decay, no moments, no move).  Needs n % 64 == 0. */
 size_t vh_adamw_ws_bytes(void);
 int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
-                  float max_norm, int zero_grad, void* workspace, float* norm_out, void* stream);
+                  float max_norm, int zero_grad, void* workspace, float* norm_out, const int32_t* block_slot,
+                  const int32_t* slot_step, void* stream);
 
 /* ---- training forward / backward products on the LDS-DMA tile machine --------------------------
  * vh_linear_ex = vh_linear (same tile kernels, M of any size) with the two epilogues training needs:

@@ -217,7 +217,7 @@ def test_flat_adamw_matches_torch_adamw_and_clip(max_norm, grad_scale):
         opt.param_groups[0]['lr'] = ropt.param_groups[0]['lr'] = lr
         grads = [(10.0 if step == 2 else 1.0) * torch.randn(*s, generator=g0) for s in shapes]
         for p, r, g in zip(mine, ref, grads):
-            p.grad.copy_(g.to(DEV))
+            p.grad = g.to(DEV)                               # assigned (or produced by autograd): counts as present
             r.grad = (g * grad_scale).to(DEV)
         norm = opt.step(grad_scale=grad_scale, max_norm=max_norm, zero_grad=True)
         ref_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm if max_norm > 0 else float('inf'))
@@ -234,7 +234,7 @@ def test_flat_adamw_matches_torch_adamw_and_clip(max_norm, grad_scale):
     for step in range(6):
         opt2.param_groups[0]['lr'] = 3e-3 * (1.0 - 0.1 * step)
         for p, s in zip(again, shapes):
-            p.grad.copy_(((10.0 if step == 2 else 1.0) * torch.randn(*s, generator=g1)).to(DEV))
+            p.grad = ((10.0 if step == 2 else 1.0) * torch.randn(*s, generator=g1)).to(DEV)
         opt2.step(grad_scale=grad_scale, max_norm=max_norm, zero_grad=True)
     assert torch.equal(opt.flat_param, opt2.flat_param)
 
@@ -338,3 +338,34 @@ def test_attention_backward_materialized_engine(mode):
         test_qkv_attention_backward(mode)
     finally:
         A.ATTENTION_BACKWARD = old
+
+
+def test_flat_adamw_skips_parameters_without_gradient_like_torch():
+    """torch.optim.AdamW skips a parameter whose grad is None (no decay, no moment update) and counts `step` per
+    parameter — what happens to the NAR heads / stage embeddings of the 6 stages a step does not train.  FlatAdamW
+    must do the same (per-slot step counts in the kernel), through autograd and through assigned gradients."""
+    from valle2_amd.optim import FlatAdamW
+    g0 = torch.Generator().manual_seed(11)
+    shapes = [(64, 32), (7,), (130, 16), (3, 5)]
+    init = [torch.randn(*s, generator=g0) for s in shapes]
+    mine = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    ref = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    kw = dict(lr=2e-3, betas=(0.9, 0.98), weight_decay=0.1)
+    opt, ropt = FlatAdamW(mine, **kw), torch.optim.AdamW(ref, **kw)
+    used = [(0, 1, 2, 3), (0, 2), (0, 1), (0, 2, 3), (0,), (0, 1, 2, 3)]       # which parameters each step trains
+    for step, idx in enumerate(used):
+        x = torch.randn(4, generator=g0).to(DEV)
+        for params, o in ((mine, opt), (ref, ropt)):
+            o.zero_grad(set_to_none=True) if o is ropt else o.zero_grad()
+            loss = sum((params[i] * (1.0 + x[i])).square().sum() * (0.1 + 0.05 * step) for i in idx)
+            loss.backward()
+            o.step()
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            torch.testing.assert_close(a.detach(), b.detach(), atol=2e-6, rtol=2e-5, msg=lambda s, i=i: f'step {step} param {i}: {s}')
+    assert opt.slot_steps != [len(used)] * 4 and max(opt.slot_steps) == len(used)
+    # an untouched parameter did not move at all in a step that skipped it
+    before = [p.detach().clone() for p in mine]
+    opt.zero_grad()
+    (mine[0] * 2.0).sum().backward()
+    opt.step()
+    assert not torch.equal(mine[0], before[0]) and all(torch.equal(mine[i], before[i]) for i in (1, 2, 3))

@@ -42,6 +42,7 @@ def main(steps=5):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             reducer.finish()                                     # buckets were launched during backward
+            opt.sync_touched()
             opt.step(grad_scale=1.0 / world, max_norm=cfg.gradient_clip_val, zero_grad=True)
             torch.cuda.synchronize()
             t3 = time.perf_counter()

@@ -116,7 +116,7 @@ SIGNATURES = {
     'vh_adamw_ws_bytes': (C.c_size_t, []),
     'vh_adamw_flat': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
-                                c_f32p, C.c_void_p]),
+                                c_f32p, c_i32p, c_i32p, C.c_void_p]),
     'vh_ar_decoder_create': (C.c_void_p, [C.POINTER(VhArDecoderDesc)]),
     'vh_ar_decoder_destroy': (None, [C.c_void_p]),
     'vh_ar_decoder_step': (C.c_int, [C.c_void_p, C.c_void_p]),

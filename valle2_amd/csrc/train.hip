@@ -384,7 +384,9 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          float lr, float beta1, float beta2, float eps,
                                                          float weight_decay, float bc1, float sqrt_bc2,
                                                          float grad_scale, float max_norm, int zero_grad,
-                                                         float* __restrict__ norm_out) {
+                                                         float* __restrict__ norm_out,
+                                                         const int32_t* __restrict__ block_slot,
+                                                         const int32_t* __restrict__ slot_step) {
     // total gradient norm: 1024 partials, 4 per thread, fixed order
     __shared__ double s[4];
     double acc = 0.0;
@@ -399,8 +401,18 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
     const float coef = max_norm > 0.f ? fminf(max_norm / (total_norm + 1e-6f), 1.0f) : 1.0f;
     const float gs = grad_scale * coef;
-    const float decay = 1.0f - lr * weight_decay, step_size = lr / bc1;
+    const float decay = 1.0f - lr * weight_decay;
+    float step_size = lr / bc1;
+    const float lnb1 = logf(beta1), lnb2 = logf(beta2);      // 1 - beta^st = -expm1(st ln beta): accurate for beta -> 1
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        if (block_slot) {
+            // per-parameter step counts (torch.optim.AdamW keeps `step` per parameter and skips a parameter
+            // whose grad is None: no decay, no moment update): 64-float blocks map to parameter slots
+            const int st = slot_step[block_slot[i >> 4]];
+            if (st == 0) continue;                         // this parameter received no gradient this step
+            step_size = lr / -expm1f((float)st * lnb1);
+            sqrt_bc2 = sqrtf(-expm1f((float)st * lnb2));
+        }
         const f32x4 gg = ld4(g + 4 * i) * gs;
         f32x4 pp = ld4(p + 4 * i) * decay;
         f32x4 mm = ld4(m + 4 * i), vv = ld4(v + 4 * i);
@@ -420,7 +432,11 @@ extern "C" size_t vh_adamw_ws_bytes(void) { return VH_SUMSQ_BLOCKS * sizeof(doub
 extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                              float grad_scale, float max_norm, int zero_grad, void* workspace,
-                             float* norm_out, void* stream) {
+                             float* norm_out, const int32_t* block_slot, const int32_t* slot_step,
+                             void* stream) {
+    VH_REQUIRE((block_slot == nullptr) == (slot_step == nullptr), VH_EINVAL,
+               "vh_adamw_flat: block_slot and slot_step go together");
+    VH_REQUIRE(!block_slot || n % 64 == 0, VH_EINVAL, "vh_adamw_flat: per-slot steps need n %% 64 == 0");
     VH_REQUIRE(param && grad && exp_avg && exp_avg_sq && workspace, VH_EINVAL, "vh_adamw_flat: null pointer");
     VH_REQUIRE(n >= 0 && n % 4 == 0, VH_EINVAL, "vh_adamw_flat: n=%lld must be a multiple of 4", (long long)n);
     VH_REQUIRE(step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f,
@@ -438,7 +454,7 @@ extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* e
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n4,
                        partials, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale,
-                       max_norm, zero_grad, norm_out);
+                       max_norm, zero_grad, norm_out, block_slot, slot_step);
     VH_CHECK_LAUNCH("vh_adamw_flat");
     return VH_OK;
 }

@@ -7,6 +7,11 @@ both AdamW moments in ONE flat fp32 buffer each, so that
     valle/train_model.py:31-32) and the 1/world mean of the all-reduce are one elementwise HIP pass
     (`vh_adamw_flat`: one partial-norm launch + one update launch, no host read of the norm).
 
+Parameters that receive no gradient in a step are skipped and keep their own step count, as torch.optim.AdamW
+does for `grad is None` (NAR trains one stage per step, valle_nar.py:76).  "Received a gradient" means: autograd
+accumulated into the parameter's view (post-accumulate hook) or a gradient tensor was assigned to `p.grad`;
+writing into the flat view by hand without either is not seen.
+
 It subclasses `torch.optim.Optimizer` only for the `param_groups` contract the reference's
 `CosineAnnealingWarmRestarts` scheduler drives (`lr` is read from the group at every step).
 """
@@ -17,7 +22,8 @@ import torch
 from . import _lib
 from ._lib import ptr
 
-ALIGN = 4   # floats: every parameter view starts 16-byte aligned (the GEMM kernels require it)
+ALIGN = 64  # floats: every parameter slot starts on a 256-byte boundary (the GEMM kernels need 16 bytes; the
+            # optimizer kernel maps 64-float blocks to slots for per-parameter step counts)
 
 
 def flat_layout(params):
@@ -51,12 +57,41 @@ class FlatAdamW(torch.optim.Optimizer):
         self.grad_norm = torch.zeros(1, **f32)
         self._ws = None
         self.steps = 0
+        # torch.optim.AdamW semantics for parameters that receive no gradient in a step (`grad is None`:
+        # skipped, and `step` is counted per parameter): post-accumulate hooks mark the slots autograd touched
+        self.slot_steps = [0] * len(self.slots)
+        self._touched = [False] * len(self.slots)
+        self._block_slot = None
+        self._slot_step_dev = torch.zeros(len(self.slots), device=dev, dtype=torch.int32)
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touch(i))
+                       for i, (p, _, _) in enumerate(self.slots)]
         with torch.no_grad():
             for p, off, n in self.slots:
                 view = self.flat_param[off:off + n].view_as(p)
                 view.copy_(p)
                 p.data = view                      # the module now computes on the flat buffer
         self._point_grads()
+
+    def _touch(self, i):
+        self._touched[i] = True
+
+    def _block_map(self):
+        if self._block_slot is None:
+            m = torch.empty(self.numel // ALIGN, dtype=torch.int32)
+            for i, (_, off, n) in enumerate(self.slots):
+                m[off // ALIGN:(off + n + ALIGN - 1) // ALIGN] = i
+            self._block_slot = m.to(self.flat_param.device)
+        return self._block_slot
+
+    def sync_touched(self):
+        """Data parallel: a slot is updated iff SOME rank produced a gradient for it (its all-reduced gradient is
+        then the same everywhere), so every rank takes the same decision and the replicas stay identical."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        t = torch.tensor(self._touched, dtype=torch.int32, device=self.flat_param.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self._touched = [bool(v) for v in t.tolist()]
 
     # ---- gradient views -------------------------------------------------------------------------
     def grad_view(self, slot):
@@ -70,12 +105,13 @@ class FlatAdamW(torch.optim.Optimizer):
     def gather_grads(self):
         """Autograd accumulates in place into the views; a gradient that was replaced (set_to_none,
         a foreign zero_grad) is copied back into its slice."""
-        for slot in self.slots:
+        for i, slot in enumerate(self.slots):
             p, view = slot[0], self.grad_view(slot)
             if p.grad is None:
                 view.zero_()
             elif p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
+                self._touched[i] = True            # a gradient assigned from outside counts as present
             p.grad = view
 
     def zero_grad(self, set_to_none: bool = False):
@@ -99,22 +135,36 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._ws is None:
             self._ws = torch.empty(lib.vh_adamw_ws_bytes() // 8, device=self.flat_param.device, dtype=torch.float64)
         self.steps += 1
+        # per-slot step counts: a slot without a gradient this step is skipped (no decay, no moments) and its
+        # count stands still; when every slot has always been updated the kernel takes the uniform fast path
+        now = [(c + 1) if t else 0 for c, t in zip(self.slot_steps, self._touched)]
+        self.slot_steps = [max(c, n) for c, n in zip(self.slot_steps, now)]
+        uniform = all(n == self.steps for n in now)
+        block_slot = slot_step = None
+        if not uniform:
+            block_slot = self._block_map()
+            self._slot_step_dev.copy_(torch.tensor(now, dtype=torch.int32))
+            slot_step = self._slot_step_dev
+        self._touched = [False] * len(self.slots)
         _lib.check(lib.vh_adamw_flat(
             ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
             float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
             float(g['weight_decay']), self.steps, float(grad_scale), float(max_norm), int(zero_grad),
-            ptr(self._ws), ptr(self.grad_norm), torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
+            ptr(self._ws), ptr(self.grad_norm), ptr(block_slot), ptr(slot_step),
+            torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
         from . import engine
         engine.bump_weights_epoch()                # the update bypasses torch's version counters
         return self.grad_norm
 
     # ---- checkpointing: the four flat buffers + the step count ------------------------------------
     def state_dict(self):
-        return {'steps': self.steps, 'exp_avg': self.exp_avg, 'exp_avg_sq': self.exp_avg_sq,
+        return {'steps': self.steps, 'slot_steps': list(self.slot_steps), 'exp_avg': self.exp_avg,
+                'exp_avg_sq': self.exp_avg_sq,
                 'param_groups': [{k: v for k, v in g.items() if k != 'params'} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
         self.steps = int(sd['steps'])
+        self.slot_steps = list(sd.get('slot_steps', [self.steps] * len(self.slots)))
         self.exp_avg.copy_(sd['exp_avg'])
         self.exp_avg_sq.copy_(sd['exp_avg_sq'])
         for g, saved in zip(self.param_groups, sd['param_groups']):

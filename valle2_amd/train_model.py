@@ -67,6 +67,7 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
             if not last:
                 continue
             reducer.finish()
+            optimizer.sync_touched()                     # same update decision per parameter on every rank
             # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
             optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
             step += 1
