@@ -188,6 +188,29 @@ int vh_linear_acc64(const float* A, int lda, const float* W, const float* bias, 
 int vh_linear_x64(const void* A, int a_f64, int lda, const float* W, const float* bias,
                   double* residual64, int ldr, float* out, int ldo, int M, int N, int K, void* stream);
 
+/* ---- persistent decode chain --------------------------------------------------------------------
+ * Everything of a decode step between two attention launches as ONE launch of one workgroup per CU with no
+ * barrier between the stages: a stage's output travels as (value, tag) pairs — one aligned 64-bit agent-scope
+ * access each — and its consumers spin on the data itself (one memory-side hop per hand-over):
+ *   x_mid = x + attn Wo^T + bo ; hid = gelu(LN2(x_mid) W1^T + b1) (folded: w1f, w1c1, w1c2) ;
+ *   x = hid W2^T + b2 + x_mid (K slices of 256 summed in slice order) ;
+ *   then EITHER LN1 + QKV of the next layer (folded: wqf, qc1, qc2; q -> q, K/V rows appended at cache_len[b])
+ *   OR the head: logits = x proj^T (valle/models/modules.py:146-157,171,221,271-279; valle_ar.py:158).
+ * The stages are the code of vh_linear / vh_linear_folded / vh_linear_ws / vh_linear_qkv_folded: results are
+ * bit-identical to those launches.  attn, x (B, d_model) fp32 rows (x is updated in place); workspace of
+ * vh_decode_chain_ws_bytes(), ZEROED ONCE by the caller; `layer` (< 64) and cache_len[0] (which must advance
+ * between decode steps) make the tags unique per launch; sync: 64 + 32 x 256 uint32 zeroed once ([1] error word:
+ * nonzero after a wait timed out — every wait is bounded, a launch whose workgroups are not all resident ends
+ * with the word set instead of hanging; [2] nonzero: every workgroup leaves 6 wall-clock stamps at word
+ * 64 + 32 wg).  B <= 64, d_model = 512, dff % 256 == 0, dff <= 4096. */
+size_t vh_decode_chain_ws_bytes(int B, int d_model, int dff);
+int vh_decode_chain(const float* attn, float* x, float* q, const float* wo, const float* bo, const float* w1f,
+                    const float* w1c1, const float* w1c2, const float* w2, const float* b2, const float* wqf,
+                    const float* qc1, const float* qc2, float* kcache, float* vcache, const int32_t* cache_len,
+                    const float* proj, float* logits, int ldl, int V, int B, int d_model, int dff, int n_heads,
+                    int S_max, int layer, float ln_eps, void* workspace, size_t workspace_bytes, uint32_t* sync,
+                    void* stream);
+
 /* ---- K7+K8a: multi-row attention (prefill / NAR / training forward) -------------------------
  * replaces merge_masks + F.scaled_dot_product_attention (valle/models/modules.py:160-167,
  * 175-207).  q (B,Tq,ldq) heads at columns head*64; K/V from the cache layout (B,h,S_max,64);
@@ -304,6 +327,12 @@ typedef struct {
      * residual stream between layers in the two-slab form, xs = 2 x (B, d) floats (slab stride B*d) — no
      * split-K workspace, no reduce launch.  Ignored when x64 is set. */
     float *xs;
+    /* optional: the GEMM chain of every layer as one persistent launch (vh_decode_chain): workspace of
+     * vh_decode_chain_ws_bytes(B, d_model, dff) and the sync block (both zeroed once).  Needs folded weights.
+     * Takes precedence over x64 / xs. */
+    float *chain_ws;
+    size_t chain_ws_bytes;
+    uint32_t *chain_sync;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

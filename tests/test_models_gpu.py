@@ -235,15 +235,16 @@ def test_ar_generate_golden(which, graph):
     tokens_match(out, gold['tokens'], gold['margin'])
 
 
-@pytest.mark.parametrize('fold,acc64,x2', [(False, False, False), (True, False, False), (True, True, False),
-                                           (True, False, True)])
-def test_ar_generate_golden_every_decode_engine(fold, acc64, x2):
-    """The decode step has four forms of its GEMM chain (LayerNorm in the operand load + split-K
-    reduce; folded LayerNorm; folded + fp64 accumulator residual stream; folded + two-slab residual
-    stream, the default at dim_feedforward % 2048 == 0).  Each must reproduce the reference's greedy tokens."""
+@pytest.mark.parametrize('fold,acc64,x2,chain', [(False, False, False, False), (True, False, False, False),
+                                                 (True, True, False, False), (True, False, True, False),
+                                                 (True, False, False, True)])
+def test_ar_generate_golden_every_decode_engine(fold, acc64, x2, chain):
+    """The decode step has five forms of its GEMM chain (LayerNorm in the operand load + split-K reduce; folded
+    LayerNorm; folded + fp64 accumulator residual stream; folded + two-slab residual stream; folded + the whole
+    chain as one persistent launch with grid barriers).  Each must reproduce the reference's greedy tokens."""
     from valle2_amd import engine
-    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL
-    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL = fold, acc64, x2
+    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN
+    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN = fold, acc64, x2, chain
     try:
         for which in ('tiny', 'mid'):
             gold = load_golden(f'ar_generate_{which}')
@@ -251,10 +252,38 @@ def test_ar_generate_golden_every_decode_engine(fold, acc64, x2):
             m = build('ValleAR', kw, sd)
             out = m.generate(*[u.to(DEV) for u in utt])
             tokens_match(out, gold['tokens'], gold['margin'])
-            if which == 'mid':                     # dff = 2048: the two-slab form is available
+            if which == 'mid':                     # 12L/512d, dff = 2048: every form is available
                 assert m.last_generate_stats['two_slab'] == (x2 and not acc64)
+                assert m.last_generate_stats['chain'] == chain
     finally:
-        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL = old
+        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN = old
+
+
+def test_persistent_chain_is_bit_identical_to_one_launch_per_stage():
+    """vh_decode_chain runs the stages' own code (same fragments, same summation order): the generated tokens AND
+    the last step's logits must equal the launch-per-stage decoder's bit for bit; graph replay == eager; ragged rows."""
+    from valle2_amd import engine, synth
+    kw = dict(C.MID, norm='LayerNorm', num_beams=5, top_k=1, max_audio_len=40)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True), cfg)
+    m = build('ValleAR', kw, sd)
+    g = torch.Generator().manual_seed(8)
+    texts = [torch.randint(0, 256, (n,), generator=g).to(DEV) for n in (30, 17, 44, 30, 9)]
+    firsts = [torch.randint(0, 1024, (n,), generator=g).to(DEV) for n in (50, 61, 20, 50, 33)]
+    old = engine.PERSISTENT_CHAIN
+    outs = {}
+    try:
+        for chain in (False, True):
+            engine.PERSISTENT_CHAIN = chain
+            for graph in (True, False):
+                outs[(chain, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
+                assert m.last_generate_stats['chain'] == chain
+    finally:
+        engine.PERSISTENT_CHAIN = old
+    ref = outs[(False, True)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), f'chain={k[0]} graph={k[1]} differs from the launch-per-stage graph decoder'
+
 
 
 def test_generate_batch_distinct_rows_vs_oracle():

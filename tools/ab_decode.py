@@ -23,8 +23,9 @@ def main(rounds=8):
     utts = [synth.synth_utterance(cfg, 128, 128, 767, seed=1234 + u) for u in range(32)]
     texts = [torch.cat([u[0], u[2]]).cuda() for u in utts]
     firsts = [u[1][:, 0].cuda() for u in utts]
-    forms = {'default': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False),
-             'two-slab': dict(TWO_SLAB_RESIDUAL=True, ACC64_RESIDUAL=False)}
+    forms = {'default': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
+             'two-slab': dict(TWO_SLAB_RESIDUAL=True, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
+             'chain': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=True)}
     res = {k: [] for k in forms}
     outs = {}
     for r in range(rounds + 1):
@@ -38,7 +39,7 @@ def main(rounds=8):
             outs[name] = out
     for name, v in res.items():
         print(f'{name:10s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')
-    print('same tokens:', bool(torch.equal(outs['default'], outs['two-slab'])))
+    print('same tokens:', all(bool(torch.equal(outs['default'], o)) for o in outs.values()))
 
 
 if __name__ == '__main__':

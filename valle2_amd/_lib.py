@@ -44,6 +44,7 @@ class VhArDecoderDesc(C.Structure):
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p), ('xs', C.c_void_p),
+        ('chain_ws', C.c_void_p), ('chain_ws_bytes', C.c_size_t), ('chain_sync', C.c_void_p),
     ]
 
 
@@ -85,6 +86,11 @@ SIGNATURES = {
     'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                        c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_float, C.c_int64, C.c_void_p]),
+    'vh_decode_chain_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_decode_chain': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, C.c_int,
+                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                  C.c_size_t, C.c_void_p, C.c_void_p]),
     'vh_linear_to_x2': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64,
                                   C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_linear_x2': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64,

@@ -40,6 +40,12 @@ struct GemmArgs {
     int T, S_max, d_model, n_heads;
     float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
     int ldx;
+    // flag-in-data ("LL") hand-over between the stages of the persistent decode chain (COH bits of skinny_body):
+    // an LL buffer holds (value, tag) pairs, 8 bytes each, written and read as single 64-bit accesses at agent
+    // scope; logical element p of the fp32 matrix that starts at *_org lives at ll_* + 2 (p - *_org)
+    const float* ll_in; const float* a_org; uint32_t tag_in;
+    float* ll_out; const float* out_org; uint32_t tag_out;
+    uint32_t* err_word;
     int64_t s2;   // two-slab form of the residual stream (X64 bits 2/3, EPI_SLAB2): element offset of slab 1
     float* slab;  // EPI_FIXUP: partial sums [slice][M][lds] and one arrival counter per column block
     int lds;
@@ -98,6 +104,50 @@ __device__ __forceinline__ f32x4 ld4_agent(const float* p) {
     return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)),
                  __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32))};
 }
+
+// (value, tag) pairs: the consumer of a stage output spins on the DATA itself — a pair is one aligned 64-bit access,
+// so a value is never seen without its tag — instead of waiting at a barrier (NCCL's "LL" protocol): one memory-side
+// hop between producer and consumer instead of the three or more of a counter barrier.
+struct LLQuad { uint64_t p[4]; };
+__device__ __forceinline__ LLQuad ll_load4(const float* ll) {
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(ll);
+    LLQuad r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.p[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+// the same quad through the caches (two 16-byte loads).  Safe as a FIRST attempt inside a launch: the caches were
+// invalidated at the kernel boundary and nothing of this launch has read these lines before their producers were
+// seen done, so the lines are fetched fresh — and shared by the workgroups of an XCD, which is what makes the
+// hand-over affordable (128 workgroups read the same 16 rows: agent-scope loads fetch every 8 bytes from the
+// memory side again, 10 us per stage).  A straggler's stale element fails the tag check and is then re-read at
+// agent scope.
+__device__ __forceinline__ LLQuad ll_load4_cached(const float* ll) {
+    const f32x4 a = ld4(ll), b = ld4(ll + 4);
+    LLQuad r;
+    r.p[0] = (uint64_t)__float_as_uint(a.x) | (uint64_t)__float_as_uint(a.y) << 32;
+    r.p[1] = (uint64_t)__float_as_uint(a.z) | (uint64_t)__float_as_uint(a.w) << 32;
+    r.p[2] = (uint64_t)__float_as_uint(b.x) | (uint64_t)__float_as_uint(b.y) << 32;
+    r.p[3] = (uint64_t)__float_as_uint(b.z) | (uint64_t)__float_as_uint(b.w) << 32;
+    return r;
+}
+__device__ __forceinline__ bool ll_ready(const LLQuad& r, uint32_t tag) {
+    return (uint32_t)(r.p[0] >> 32) == tag && (uint32_t)(r.p[1] >> 32) == tag && (uint32_t)(r.p[2] >> 32) == tag &&
+           (uint32_t)(r.p[3] >> 32) == tag;
+}
+__device__ __forceinline__ f32x4 ll_value(const LLQuad& r) {
+    return f32x4{__uint_as_float((uint32_t)r.p[0]), __uint_as_float((uint32_t)r.p[1]), __uint_as_float((uint32_t)r.p[2]),
+                 __uint_as_float((uint32_t)r.p[3])};
+}
+__device__ __forceinline__ void ll_store4(float* ll, f32x4 v, uint32_t tag) {
+    uint64_t* q = reinterpret_cast<uint64_t*>(ll);
+    const uint64_t t = (uint64_t)tag << 32;
+    __hip_atomic_store(q, t | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 1, t | __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 2, t | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(q + 3, t | __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define LL_SPIN_LIMIT 40000
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
 template <int EPI>
@@ -804,20 +854,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //      slab 1 at element offset a.s2): linear_2 runs as two K slices whose partials stay apart
 //      (EPI_SLAB2; slice 0 carries bias + residual) and the consumers add the two on load — no reduce
 //      launch in the decode step; bit 3 = the residual is in that form.
-template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
-                                                            int hM, int hN, GemmArgs a, LnFuse ln) {
+// Virtual block coordinates: the body runs as a kernel of its own (gemm_skinny_fast: the launch grid) or as one
+// stage of the persistent decode-chain kernel (decode_chain_kernel: work items mapped onto resident workgroups).
+struct VB { int x, y, z, ny, nz; };
+
+// COH (decode_chain_kernel): bit 0 = the A operand rows were produced by OTHER workgroups of the SAME launch and
+// are read in the flag-in-data form (spin until every pair carries a.tag_in; the weights are requested first, so
+// their latency hides under the wait); bit 1 = the results go out in that form (a.tag_out) for later stages.
+#define LL_IN(p) (a.ll_in + 2 * (reinterpret_cast<const float*>(p) - a.a_org))
+#define STX(p, v) do { if (COH & 2) ll_store4(a.ll_out + 2 * ((p) - a.out_org), (v), a.tag_out); else st4((p), (v)); } while (0)
+
+template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64, int COH>
+__device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) {
     using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
-    // The operands every wave needs for its first loads travel as leading scalar arguments: with
-    // -mllvm -amdgpu-kernarg-preload-count the command processor places them in SGPRs at dispatch, so the
-    // weight / activation loads are issued without first waiting for a kernarg s_load round trip (a launch
-    // of this kernel is two or three dependent memory round trips long; that was one of them).
-    a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
-    // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
+    // Row groups (vb.nz > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
-    if (gridDim.z > 1) {
-        const int r0 = blockIdx.z * a.rg_rows;
+    if (vb.nz > 1) {
+        const int r0 = vb.z * a.rg_rows;
         a.A = reinterpret_cast<const float*>(reinterpret_cast<const AT*>(a.A) + (int64_t)r0 * a.lda);
         if (a.res) {
             if (X64 & 2) a.res = reinterpret_cast<const float*>(reinterpret_cast<const double*>(a.res) + (int64_t)r0 * a.ldr);
@@ -835,8 +889,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int koff = blockIdx.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
+    const int n0 = vb.x * 16;
+    const int koff = vb.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
     const float* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
     const AT* xp[MT];
 #pragma unroll
@@ -847,13 +901,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
     f32x4 xf2[(X64 & 4) ? PW : 1][MT];              // slab 1 of a two-slab operand, added before the MFMAs
+    LLQuad xraw[(COH & 1) ? PW : 1][MT], vraw[(COH & 1) ? NJ : 1];
+    bool ll_first = true;                           // first attempt through the caches, retries at agent scope
+    auto issue_x_ll = [&](int kbase) {              // COH & 1: the activation fragments as (value, tag) pairs
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xraw[(COH & 1) ? c : 0][mt] = ll_first ? ll_load4_cached(LL_IN(xp[mt] + kbase + 16 * c))
+                                                       : ll_load4(LL_IN(xp[mt] + kbase + 16 * c));
+    };
     auto issue = [&](int kbase) {
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
             wf[c] = ld4(wp + kbase + 16 * c);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
+                if (!(COH & 1)) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
                 if (X64 & 4) xf2[c][mt] = ld4(xp[mt] + a.s2 + kbase + 16 * c);
             }
             if (LN == 1) {
@@ -871,7 +935,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
         const int row = (r0 * NW + w) * 4 + g;
         const AT* xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
+        for (int jj = 0; jj < NJ; ++jj) {
+            if (COH & 1) vraw[(COH & 1) ? jj : 0] = ll_first ? ll_load4_cached(LL_IN(xr + 64 * jj)) : ll_load4(LL_IN(xr + 64 * jj));
+            else v[jj] = ld4(xr + 64 * jj);
+        }
         if (X64 & 4) {
 #pragma unroll
             for (int jj = 0; jj < NJ; ++jj) v[jj] += ld4(xr + a.s2 + 64 * jj);
@@ -894,8 +961,64 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
         if (i == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
     };
     STAMP(0);
-    if (LN) ln_load(0);
-    issue(0);
+    if (COH & 1) {
+        // weights first (no dependence on this launch's producers), then wait for the activation pairs
+        static_assert(!(COH & 1) || ((!LN || (16 * MT + 4 * NW - 1) / (4 * NW) == 1)), "LL inputs: one LayerNorm round");
+        issue(0);
+        // Cheap pre-poll by ONE wave: a sentinel pair per 16-column block of the K range this workgroup reads (the
+        // grain of the producing stage's work items), first and last row — 64 loads per workgroup and iteration
+        // instead of every lane re-reading all of its fragments (that storm, 6 M loads per iteration chip-wide,
+        // starved the producers).  The validated load below still checks every pair it uses.
+        {
+            if (w == 0) {
+                const int k_lo = vb.y * a.k_len, nblk = (LN ? a.K : a.k_len) / 16;     // LN reads whole rows
+                const int blk = lane & 31, rsel = lane >> 5;
+                const float* sp = reinterpret_cast<const float*>(a.A) + (int64_t)(rsel ? a.M - 1 : 0) * a.lda +
+                                  (LN ? 0 : k_lo) + 16 * min(blk, nblk - 1);
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(LL_IN(sp));
+                int spins = 0;
+                for (;;) {
+                    const uint64_t pr = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((uint32_t)(pr >> 32) == a.tag_in)) break;
+                    if (++spins > LL_SPIN_LIMIT) break;             // the validated load below reports the timeout
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
+        int spins = 0;
+        for (;;) {
+            if (LN) ln_load(0);
+            issue_x_ll(0);
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < PW; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) ok = ok && ll_ready(xraw[(COH & 1) ? c : 0][mt], a.tag_in);
+            if (LN) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) ok = ok && ll_ready(vraw[(COH & 1) ? jj : 0], a.tag_in);
+            }
+            if (__all(ok)) break;
+            ll_first = false;
+            if (++spins > LL_SPIN_LIMIT) {              // bounded: flag the error and go on (garbage out, no hang)
+                if (lane == 0) __hip_atomic_store(a.err_word, 0x80000000u | (a.tag_in & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+#pragma unroll
+        for (int c = 0; c < PW; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ll_value(xraw[(COH & 1) ? c : 0][mt]);
+        if (LN) {
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj) v[jj] = ll_value(vraw[(COH & 1) ? jj : 0]);
+        }
+    } else {
+        if (LN) ln_load(0);
+        issue(0);
+    }
     // Epilogue operands (bias / residual / cache position) are fetched NOW by the lanes that will
     // finalise (wave w finalises m-tile w): loaded in the epilogue they would add one more
     // dependent memory round trip to a kernel that is nothing but round trips.
@@ -914,11 +1037,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
             else e_res = ld4(a.res + (int64_t)em * a.ldr + en);
             if (X64 & 8) e_res += ld4(a.res + a.s2 + (int64_t)em * a.ldr + en);
         }
-        if (EPI == EPI_SLAB2 && blockIdx.y == 0) {
+        if (EPI == EPI_SLAB2 && vb.y == 0) {
             if (a.bias) e_bias = ld4(a.bias + en);
             if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         }
-        if (EPI == EPI_ACC64 && blockIdx.y == 0) {
+        if (EPI == EPI_ACC64 && vb.y == 0) {
             if (a.bias) e_bias = ld4(a.bias + en);
             if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         }
@@ -1009,11 +1132,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
                 }
             }
         } else if (EPI == EPI_SLAB2) {
-            // slice blockIdx.y's partial into its own slab; slice 0 carries bias + residual (zeros otherwise)
-            if (fin) st4(a.out + (int64_t)blockIdx.y * a.s2 + (int64_t)em * a.ldo + en, (sacc + e_bias) + e_res);
+            // slice vb.y's partial into its own slab; slice 0 carries bias + residual (zeros otherwise)
+            if (fin) st4(a.out + (int64_t)vb.y * a.s2 + (int64_t)em * a.ldo + en, (sacc + e_bias) + e_res);
         } else if (EPI == EPI_FIXUP) {
-            // raw partial of K slice blockIdx.y (N % 16 == 0 and every row group whole or guarded by fin)
-            if (fin) st4_agent(a.slab + ((int64_t)blockIdx.y * a.M + em) * a.lds + en, sacc);
+            // raw partial of K slice vb.y (N % 16 == 0 and every row group whole or guarded by fin)
+            if (fin) st4_agent(a.slab + ((int64_t)vb.y * a.M + em) * a.lds + en, sacc);
+        } else if (EPI == EPI_PARTIAL && (COH & 2)) {    // slab of K slice vb.y, read back by other workgroups of this launch
+            if (fin) STX(a.out + ((int64_t)vb.y * a.M + em) * a.ldo + en, sacc);
         } else if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
@@ -1022,7 +1147,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
                 sacc.x = gelu_erf(sacc.x); sacc.y = gelu_erf(sacc.y);
                 sacc.z = gelu_erf(sacc.z); sacc.w = gelu_erf(sacc.w);
             }
-            st4(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
+            STX(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
             if ((X64 & 2) && a.res) {        // the accumulator row segment is consumed: clear it
                 typedef double d64x2 __attribute__((ext_vector_type(2)));
                 double* rp = reinterpret_cast<double*>(const_cast<float*>(a.res)) + (int64_t)em * a.ldr + en;
@@ -1032,12 +1157,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
         } else {  // EPI_QKV with the cache position already in a register
             const int which = en / a.d_model, c = en - which * a.d_model;
             if (which == 0) {
-                st4(a.out + (int64_t)em * a.ldo + c, sacc);
+                STX(a.out + (int64_t)em * a.ldo + c, sacc);
             } else {
                 const int head = c / VH_HEAD_DIM, e = c - head * VH_HEAD_DIM;
                 const int b = em / a.T, t = em - b * a.T;
                 float* base = which == 1 ? a.kc : a.vc;
-                st4(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
+                STX(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
             }
         }
     }
@@ -1049,17 +1174,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
         __shared__ int s_ticket;
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's write-through slab stores are done
         __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(a.counters + blockIdx.x, 1);
+        if (tid == 0) s_ticket = atomicAdd(a.counters + vb.x, 1);
         __syncthreads();
-        if (s_ticket != (int)gridDim.y - 1) return;
-        if (tid == 0) a.counters[blockIdx.x] = 0;          // ready for the next launch (graph replay)
+        if (s_ticket != vb.ny - 1) return;
+        if (tid == 0) a.counters[vb.x] = 0;          // ready for the next launch (graph replay)
         if (tid < MT * 64 && fin) {
             const float* p = a.slab + (int64_t)em * a.lds + en;
             const int64_t stride = (int64_t)a.M * a.lds;
             f32x4 part[16];
 #pragma unroll
             for (int sidx = 0; sidx < 16; ++sidx)
-                part[sidx] = sidx < (int)gridDim.y ? ld4_agent(p + sidx * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+                part[sidx] = sidx < vb.ny ? ld4_agent(p + sidx * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 tot = part[0];
 #pragma unroll
             for (int sidx = 1; sidx < 16; ++sidx) tot += part[sidx];
@@ -1071,6 +1196,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
         }
     }
     STAMP(5);
+}
+
+
+template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
+                                                            int hM, int hN, GemmArgs a, LnFuse ln) {
+    // The operands every wave needs for its first loads travel as leading scalar arguments: with
+    // -mllvm -amdgpu-kernarg-preload-count the command processor places them in SGPRs at dispatch, so the
+    // weight / activation loads are issued without first waiting for a kernarg s_load round trip.
+    a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
+    skinny_body<MT, NW, EPI, PW, LN, NJ, X64, 0>(a, ln, VB{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                                                                (int)gridDim.y, (int)gridDim.z});
 }
 
 // =============================================================================================
@@ -1878,5 +2015,232 @@ extern "C" int vh_transpose(const float* in, int ldi, int rows, int cols, float*
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (ldo + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        in, ldi, rows, cols, out, ldo);
     VH_CHECK_LAUNCH("vh_transpose");
+    return VH_OK;
+}
+
+// =============================================================================================
+// Persistent decode-chain kernel: everything of a decode step that lies between two attention launches —
+//   S1 out-projection + bias + residual          x_mid = x + attn Wo^T + bo            (modules.py:171,277)
+//   S2 LN2 (folded) + linear_1 + GELU            hid   = gelu(LN(x_mid) W1^T + b1)     (modules.py:221,278)
+//   S3 linear_2, K split into 256-wide slices    slab_s = hid[:, s] W2[:, s]^T
+//   S4 slab sum + bias + residual                x     = sum_s slab_s + b2 + x_mid     (modules.py:279)
+//   S5 LN1 (folded) + QKV of the NEXT layer with K/V appended in place (modules.py:146-157,271), or the head
+//      (valle_ar.py:158) after the last layer
+// — as ONE launch of one workgroup per CU, with NO barrier between the stages: a stage's output travels in the
+// flag-in-data form ((value, tag) pairs, one aligned 64-bit agent-scope access each) and its consumers spin on the
+// data itself, so the hand-over is one memory-side hop.
+//
+// Why this shape (measured): a dependent launch costs 4.6 us in the replayed decode graph whatever it
+// does; __threadfence() costs 24 us (every wave writes back and invalidates a whole per-XCD L2); a counter barrier
+// among the 256 workgroups with agent-scope accesses costs 3-5 us (publish, arrive, poll, read back: each a
+// memory-side round trip of about a microsecond) — the first version of this kernel, barriers between the stages,
+// took 37 us per layer against 24.6 us for one launch per stage.
+//
+// Progress: every workgroup runs its stage-1 items (which wait for nothing of this launch) before anything else, then
+// stage 2, ...; with one resident workgroup per CU every producer is running, so every wait ends.  All waits are
+// bounded (LL_SPIN_LIMIT): a timeout raises the error word and the workgroup carries on with what it has — the host
+// reads the word at the end of generate() and raises.  A tag is (decode position, layer, stage): unique per launch
+// and buffer, so data of an earlier launch is never mistaken for this one's.
+//
+// The stages are the SAME code as the stand-alone launches (skinny_body: same fragments, same summation order):
+// the chain reproduces the launch-per-stage step bit for bit (test).
+// =============================================================================================
+struct ChainArgs {
+    const float* attn; float* x; float* q;
+    float* xm_ll; float* hid_ll; float* slab_ll; float* x_ll;   // (value, tag) buffers: 2 floats per element
+    const float* wo; const float* bo;
+    const float* w1f; const float* w1c1; const float* w1c2;
+    const float* w2; const float* b2;
+    const float* wqf; const float* qc1; const float* qc2;    // next layer's folded QKV (nullptr after the last layer)
+    float* kc; float* vc; const int32_t* cache_len;
+    const float* proj; float* logits; int ldl, V;            // the head, used when wqf == nullptr
+    int B, d, dff, n_heads, S_max, layer;
+    float eps;
+    unsigned* sync;    // [1] error word, [2] != 0: leave wall-clock stamps at word 64 + 32 wg
+};
+
+#define CHAIN_THREADS 512
+
+// MT = ceil(B / 16); d_model = 512 (one K pass per stage: the LL input form loads its fragments once)
+template <int MT>
+__global__ __launch_bounds__(CHAIN_THREADS) void decode_chain_kernel(ChainArgs c) {
+    constexpr int PW = 4, NJ = 8;
+    unsigned* sync = c.sync;
+    const int wg = blockIdx.x, nwg = gridDim.x;
+    const LnFuse none{};
+    // (decode position, layer, stage): the position advances once per step, before the step's first launch
+    const uint32_t tag0 = ((uint32_t)(c.cache_len[0] + 1) * 64u + (uint32_t)c.layer) * 8u;
+    long long* stamps = sync[2] ? reinterpret_cast<long long*>(sync + 64) + (size_t)wg * 16 : nullptr;
+#define CHAIN_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
+    CHAIN_STAMP(0);
+    // ---- S1: out-projection + bias + residual -> xm (LL, tag 1).  (d/16) column blocks x row groups of 8 (or 16) rows.
+    {
+        GemmArgs a{};
+        a.A = c.attn; a.lda = c.d; a.W = c.wo; a.bias = c.bo; a.res = c.x; a.ldr = c.d;
+        a.out = c.xm_ll; a.out_org = c.xm_ll; a.ll_out = c.xm_ll; a.tag_out = tag0 + 1; a.ldo = c.d;
+        a.M = c.B; a.N = c.d; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
+        const int nx = c.d / 16;
+        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
+        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
+        for (int it = wg; it < nx * nz; it += nwg) {
+            skinny_body<1, 8, EPI_PLAIN, PW, 0, 1, 0, 2>(a, none, VB{it % nx, 0, it / nx, 1, nz});
+            __syncthreads();
+        }
+    }
+    CHAIN_STAMP(1);
+    // ---- S2: folded LN2 + linear_1 + GELU: xm (tag 1) -> hid (LL, tag 2)
+    {
+        GemmArgs a{};
+        a.A = c.xm_ll; a.a_org = c.xm_ll; a.ll_in = c.xm_ll; a.tag_in = tag0 + 1; a.lda = c.d; a.W = c.w1f;
+        a.out = c.hid_ll; a.out_org = c.hid_ll; a.ll_out = c.hid_ll; a.tag_out = tag0 + 2; a.ldo = c.dff;
+        a.M = c.B; a.N = c.dff; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_GELU_ERF; a.err_word = sync + 1;
+        LnFuse ln{nullptr, nullptr, nullptr, nullptr, c.eps, c.w1c1, c.w1c2};
+        const int nx = c.dff / 16;
+        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
+        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
+        for (int it = wg; it < nx * nz; it += nwg) {
+            skinny_body<1, 8, EPI_PLAIN, PW, 2, NJ, 0, 3>(a, ln, VB{it % nx, 0, it / nx, 1, nz});
+            __syncthreads();
+        }
+    }
+    CHAIN_STAMP(2);
+    // ---- S3: linear_2 in K slices of 256: hid (tag 2) -> slabs [slice][B][d] (LL, tag 3)
+    const int slices = c.dff / 256;
+    {
+        GemmArgs a{};
+        a.A = c.hid_ll; a.a_org = c.hid_ll; a.ll_in = c.hid_ll; a.tag_in = tag0 + 2; a.lda = c.dff; a.W = c.w2;
+        a.out = c.slab_ll; a.out_org = c.slab_ll; a.ll_out = c.slab_ll; a.tag_out = tag0 + 3; a.ldo = c.d;
+        a.M = c.B; a.N = c.d; a.K = c.dff; a.k_len = 256; a.act = VH_ACT_NONE; a.err_word = sync + 1;
+        const int nx = c.d / 16;
+        for (int it = wg; it < nx * slices; it += nwg) {
+            skinny_body<MT, 8, EPI_PARTIAL, 2, 0, 1, 0, 3>(a, none, VB{it % nx, it / nx, 0, slices, 1});
+            __syncthreads();
+        }
+    }
+    CHAIN_STAMP(3);
+    // ---- S4: x = sum of the slabs (slice order: reproducible) + b2 + xm -> x (plain, the next launch's residual)
+    //          and x (LL, tag 4) for S5
+    {
+        const int groups = c.d / 4, items = c.B * groups;
+        const int64_t stride = (int64_t)c.B * c.d;
+        for (int idx = wg * CHAIN_THREADS + threadIdx.x; idx < items; idx += nwg * CHAIN_THREADS) {
+            const int m = idx / groups, n = (idx - m * groups) * 4;
+            const int64_t e = (int64_t)m * c.d + n;
+            LLQuad part[16], xmq;
+            int spins = 0;
+            {   // cheap pre-poll: one pair of the last slice's slab
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(c.slab_ll + 2 * (e + (slices - 1) * stride));
+                while ((uint32_t)(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != tag0 + 3 &&
+                       ++spins <= LL_SPIN_LIMIT)
+                    __builtin_amdgcn_s_sleep(8);
+                spins = 0;
+            }
+            for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int s0 = 0; s0 < 16; ++s0)
+                    if (s0 < slices) {
+                        part[s0] = spins ? ll_load4(c.slab_ll + 2 * (e + s0 * stride)) : ll_load4_cached(c.slab_ll + 2 * (e + s0 * stride));
+                        ok = ok && ll_ready(part[s0], tag0 + 3);
+                    }
+                xmq = spins ? ll_load4(c.xm_ll + 2 * e) : ll_load4_cached(c.xm_ll + 2 * e);
+                ok = ok && ll_ready(xmq, tag0 + 1);
+                if (ok) break;
+                if (++spins > LL_SPIN_LIMIT) {
+                    __hip_atomic_store(sync + 1, 0xC0000000u | ((tag0 + 3) & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(16);
+            }
+            f32x4 acc = ll_value(part[0]);
+#pragma unroll
+            for (int s0 = 1; s0 < 16; ++s0)
+                if (s0 < slices) acc += ll_value(part[s0]);
+            acc += ld4(c.b2 + n);
+            acc += ll_value(xmq);
+            st4(c.x + e, acc);
+            ll_store4(c.x_ll + 2 * e, acc, tag0 + 4);
+        }
+    }
+    CHAIN_STAMP(4);
+    // ---- S5: x (tag 4) -> folded LN1 + QKV of the next layer (K/V appended at cache_len), or the head
+    if (c.wqf) {
+        GemmArgs a{};
+        a.A = c.x_ll; a.a_org = c.x_ll; a.ll_in = c.x_ll; a.tag_in = tag0 + 4; a.lda = c.d; a.W = c.wqf; a.out = c.q; a.ldo = c.d;
+        a.M = c.B; a.N = 3 * c.d; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
+        a.kc = c.kc; a.vc = c.vc; a.cache_len = c.cache_len; a.T = 1; a.S_max = c.S_max; a.d_model = c.d; a.n_heads = c.n_heads;
+        LnFuse ln{nullptr, nullptr, nullptr, nullptr, c.eps, c.qc1, c.qc2};
+        const int nx = 3 * c.d / 16;
+        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
+        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
+        for (int it = wg; it < nx * nz; it += nwg) {
+            skinny_body<1, 8, EPI_QKV, PW, 2, NJ, 0, 1>(a, ln, VB{it % nx, 0, it / nx, 1, nz});
+            __syncthreads();
+        }
+    } else {
+        GemmArgs a{};
+        a.A = c.x_ll; a.a_org = c.x_ll; a.ll_in = c.x_ll; a.tag_in = tag0 + 4; a.lda = c.d; a.W = c.proj; a.out = c.logits; a.ldo = c.ldl;
+        a.M = c.B; a.N = c.V; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
+        const int nx = (c.V + 15) / 16;
+        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
+        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
+        for (int it = wg; it < nx * nz; it += nwg) {
+            skinny_body<1, 8, EPI_PLAIN, PW, 0, 1, 0, 1>(a, none, VB{it % nx, 0, it / nx, 1, nz});
+            __syncthreads();
+        }
+    }
+    CHAIN_STAMP(5);
+}
+
+extern "C" size_t vh_decode_chain_ws_bytes(int B, int d_model, int dff) {
+    // (value, tag) buffers: x_mid (B, d), slabs (dff / 256, B, d), x (B, d), hidden (B, dff)
+    return 2 * ((size_t)(2 + dff / 256) * B * d_model + (size_t)B * dff) * sizeof(float);
+}
+
+extern "C" int vh_decode_chain(const float* attn, float* x, float* q, const float* wo, const float* bo,
+                               const float* w1f, const float* w1c1, const float* w1c2, const float* w2,
+                               const float* b2, const float* wqf, const float* qc1, const float* qc2, float* kcache,
+                               float* vcache, const int32_t* cache_len, const float* proj, float* logits, int ldl,
+                               int V, int B, int d_model, int dff, int n_heads, int S_max, int layer, float ln_eps,
+                               void* workspace, size_t workspace_bytes, uint32_t* sync, void* stream) {
+    VH_REQUIRE(attn && x && wo && bo && w1f && w1c1 && w1c2 && w2 && b2 && workspace && sync && cache_len, VH_EINVAL,
+               "vh_decode_chain: null pointer");
+    VH_REQUIRE((wqf != nullptr) != (proj != nullptr), VH_EINVAL,
+               "vh_decode_chain: exactly one of the next layer's QKV and the head");
+    VH_REQUIRE(!wqf || (qc1 && qc2 && q && kcache && vcache), VH_EINVAL, "vh_decode_chain: QKV stage pointers");
+    VH_REQUIRE(!proj || (logits && V > 0 && ldl >= V && ldl % 4 == 0), VH_EINVAL, "vh_decode_chain: head stage");
+    VH_REQUIRE(B > 0 && B <= 64 && d_model == 512 && d_model == n_heads * VH_HEAD_DIM && dff % 256 == 0 &&
+                   dff / 256 <= 16 && dff >= 256 && layer >= 0 && layer < 64,
+               VH_EUNSUPPORTED, "vh_decode_chain: B=%d d_model=%d dff=%d layer=%d (B <= 64, d_model = 512, dff a multiple "
+               "of 256 up to 4096, layer < 64)", B, d_model, dff, layer);
+    VH_REQUIRE(workspace_bytes >= vh_decode_chain_ws_bytes(B, d_model, dff) && vh_aligned16(workspace), VH_EINVAL,
+               "vh_decode_chain: workspace too small or unaligned");
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
+            n_cu = 0;
+            vh_set_error("vh_decode_chain: cannot read the CU count");
+            return VH_ELAUNCH;
+        }
+    }
+    ChainArgs c{};
+    float* ws = (float*)workspace;
+    const size_t bd = (size_t)B * d_model;
+    c.attn = attn; c.x = x; c.q = q;
+    c.xm_ll = ws; c.slab_ll = ws + 2 * bd; c.x_ll = c.slab_ll + 2 * (size_t)(dff / 256) * bd; c.hid_ll = c.x_ll + 2 * bd;
+    c.wo = wo; c.bo = bo; c.w1f = w1f; c.w1c1 = w1c1; c.w1c2 = w1c2; c.w2 = w2; c.b2 = b2;
+    c.wqf = wqf; c.qc1 = qc1; c.qc2 = qc2; c.kc = kcache; c.vc = vcache; c.cache_len = cache_len;
+    c.proj = proj; c.logits = logits; c.ldl = ldl; c.V = V;
+    c.B = B; c.d = d_model; c.dff = dff; c.n_heads = n_heads; c.S_max = S_max; c.layer = layer; c.eps = ln_eps; c.sync = sync;
+    // one workgroup per CU: all of them resident at once (consumers spin on their producers' data)
+    const dim3 grid(n_cu > 256 ? 256 : n_cu);
+    const int mt = (B + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (mt == 1) hipLaunchKernelGGL((decode_chain_kernel<1>), grid, dim3(CHAIN_THREADS), 0, s, c);
+    else if (mt == 2) hipLaunchKernelGGL((decode_chain_kernel<2>), grid, dim3(CHAIN_THREADS), 0, s, c);
+    else hipLaunchKernelGGL((decode_chain_kernel<4>), grid, dim3(CHAIN_THREADS), 0, s, c);
+    VH_CHECK_LAUNCH("vh_decode_chain");
     return VH_OK;
 }

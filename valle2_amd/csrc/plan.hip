@@ -58,7 +58,9 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                VH_EINVAL, "vh_ar_decoder: null buffer in desc");
     VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
     VH_REQUIRE((d->x64 == nullptr) == (d->xmid == nullptr), VH_EINVAL, "vh_ar_decoder: x64 and xmid go together");
-    if (d->x64 || d->xs)
+    VH_REQUIRE(!d->chain_ws || (d->chain_sync && d->chain_ws_bytes >= vh_decode_chain_ws_bytes(d->B, d->d_model, d->dff)),
+               VH_EINVAL, "vh_ar_decoder: chain_ws needs chain_sync and vh_decode_chain_ws_bytes() bytes");
+    if (d->x64 || d->xs || d->chain_ws)
         for (int i = 0; i < d->n_layers; ++i)
             VH_REQUIRE(d->layers[i].wqkv_f && d->layers[i].w1_f, VH_EINVAL,
                        "vh_ar_decoder: the fp64 accumulator / two-slab forms need folded weights (layer %d)", i);
@@ -95,9 +97,50 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                            std::vector<hipEvent_t>* kev = nullptr) {
     const vh_ar_decoder_desc& d = dec->d;
     const int B = d.B, D = d.d_model;
+    // decode attention of one layer, optionally bracketed by events (vh_ar_decoder_profile_attn)
+    auto run_attention = [&](const vh_layer& L) -> int {
+        if (!ev)
+            return vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max, d.n_split,
+                                  d.attn_partial, s);
+        hipEvent_t e0, e1;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            vh_set_error("vh_ar_decoder: hipEventCreate failed");
+            return VH_ELAUNCH;
+        }
+        hipEvent_t k0 = nullptr, k1 = nullptr;
+        if (kev && hipEventCreate(&k0) == hipSuccess && hipEventCreate(&k1) == hipSuccess) {
+            vh_internal_attn_decode_events(k0, k1);
+            kev->push_back(k0);
+            kev->push_back(k1);
+        }
+        (void)hipEventRecord(e0, s);
+        const int arc = vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max,
+                                       d.n_split, d.attn_partial, s);
+        (void)hipEventRecord(e1, s);
+        vh_internal_attn_decode_events(nullptr, nullptr);
+        ev->push_back(e0);
+        ev->push_back(e1);
+        return arc;
+    };
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
+        if (d.chain_ws) {
+            // one QKV launch for layer 0, then per layer: attention + ONE persistent launch for the whole GEMM chain
+            // (out-projection, LN2 + linear_1 + GELU, linear_2 + residual, then the next layer's LN1 + QKV or the head)
+            if (i == 0)
+                TRY(vh_linear_qkv_folded(d.x, 0, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
+                                         d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, 0, s));
+            TRY(run_attention(L));
+            const bool last = i + 1 == d.n_layers;
+            const vh_layer* nx = last ? nullptr : &dec->layers[i + 1];
+            TRY(vh_decode_chain(d.attn, d.x, d.q, L.wo, L.bo, L.w1_f, L.w1_c1, L.w1_c2, L.w2, L.b2,
+                                nx ? nx->wqkv_f : nullptr, nx ? nx->qkv_c1 : nullptr, nx ? nx->qkv_c2 : nullptr,
+                                nx ? nx->kcache : nullptr, nx ? nx->vcache : nullptr, d.cache_len,
+                                last ? d.proj_w : nullptr, d.logits, dec->ldl, d.V, B, D, d.dff, d.n_heads, d.S_max, i,
+                                d.ln_eps, d.chain_ws, d.chain_ws_bytes, d.chain_sync, s));
+            continue;
+        }
         const bool x2 = d.xs && !d.x64;              // residual stream between layers in the two-slab form
         const int64_t ss = (int64_t)B * D;           // slab stride
         if (d.x64)
@@ -112,30 +155,7 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         else
             TRY(vh_linear_qkv(d.x, D, L.wqkv, d.q, D, L.kcache, L.vcache, d.cache_len, B, 1, D, d.n_heads,
                               d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
-        if (ev) {
-            hipEvent_t e0, e1;
-            if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
-                vh_set_error("vh_ar_decoder: hipEventCreate failed");
-                return VH_ELAUNCH;
-            }
-            hipEvent_t k0 = nullptr, k1 = nullptr;
-            if (kev && hipEventCreate(&k0) == hipSuccess && hipEventCreate(&k1) == hipSuccess) {
-                vh_internal_attn_decode_events(k0, k1);
-                kev->push_back(k0);
-                kev->push_back(k1);
-            }
-            (void)hipEventRecord(e0, s);
-            const int arc = vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
-                                           d.S_max, d.n_split, d.attn_partial, s);
-            (void)hipEventRecord(e1, s);
-            vh_internal_attn_decode_events(nullptr, nullptr);
-            ev->push_back(e0);
-            ev->push_back(e1);
-            if (arc != VH_OK) return arc;
-        } else {
-            TRY(vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads,
-                               d.S_max, d.n_split, d.attn_partial, s));
-        }
+        TRY(run_attention(L));
         if (d.x64) {
             // accumulator form: out-proj consumes (reads + clears) the fp64 rows → xmid; LN2 + linear_1
             // on xmid; the K slices of linear_2 add (partials + bias + xmid) back onto the fp64 rows
@@ -173,21 +193,23 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                          d.gemm_ws_bytes, s));
     }
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
-    if (d.x64)
+    if (d.chain_ws) {
+        // the last layer's chain launch produced the logits
+    } else if (d.x64)
         TRY(vh_linear_x64(d.x64, 1, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, s));
     else if (d.xs)
         TRY(vh_linear_x2(d.xs, 1, D, d.proj_w, nullptr, nullptr, 0, 0, (int64_t)B * D, d.logits, dec->ldl, B, d.V, D, s));
     else
         TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
                       nullptr, nullptr, nullptr, nullptr, 0.f, s));
-    float* xf = d.x64 ? nullptr : d.x;
+    float* xf = (d.x64 && !d.chain_ws) ? nullptr : d.x;
     if (d.top_k == 1)
         TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
-                           d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, xf, d.x64, B, D, s));
+                           d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, xf, d.chain_ws ? nullptr : d.x64, B, D, s));
     else
         TRY(vh_sample_step(d.logits, dec->ldl, d.V, d.eos, d.top_k, d.top_p, d.temperature, d.seed,
                            d.codes, d.codes_stride, d.eos_count, d.pos_base, d.sum_logprobs, d.audio_emb,
-                           d.audio_pe, d.audio_pos, d.cache_len, xf, d.x64, B, D, s));
+                           d.audio_pe, d.audio_pos, d.cache_len, xf, d.chain_ws ? nullptr : d.x64, B, D, s));
     return VH_OK;
 }
 

@@ -52,6 +52,12 @@ def _layer_params(layer):
 # Forms of the decode step's GEMM chain (A/B switches; every form is under the same parity tests):
 FOLD_LAYERNORM = os.environ.get('VALLE2_FOLD_LN', '1') != '0'   # LayerNorm folded into the QKV / linear_1
                                                                  # weights (vh_ln_fold)
+PERSISTENT_CHAIN = os.environ.get('VALLE2_CHAIN', '0') == '1'   # the GEMM chain between two attention launches as ONE
+                                                                 # persistent launch, stages handing over through
+                                                                 # (value, tag) pairs (vh_decode_chain).  Off: measured
+                                                                 # 700 vs 617 us per step; bit-identical
+                                                                 # results, kept as an option; needs the folded weights,
+                                                                 # d_model = 512, dff % 256 == 0, dff <= 4096
 TWO_SLAB_RESIDUAL = os.environ.get('VALLE2_X2', '0') == '1'     # residual stream between layers as two fp32 slabs
                                                                  # (linear_2's two K halves, added on load by the
                                                                  # consumers: no split-K reduce launch).  Off:
@@ -206,8 +212,16 @@ class ArDecoder:
         self.acc64 = bool(ACC64_RESIDUAL and self._folded is not None and d % 128 == 0 and dff % 128 == 0)
         self.x64 = torch.zeros(batch, d, device=dev, dtype=torch.float64) if self.acc64 else None
         self.xmid = torch.empty(batch, d, **f32) if self.acc64 else None
-        self.x2 = bool(TWO_SLAB_RESIDUAL and not self.acc64 and self._folded is not None and dff % 2048 == 0
-                       and d <= 1024 and d % 128 == 0)
+        self.chain = bool(PERSISTENT_CHAIN and self._folded is not None and d == 512 and dff % 256 == 0
+                          and 256 <= dff <= 4096 and cfg.num_layers <= 64)
+        chain_bytes = _lib.lib().vh_decode_chain_ws_bytes(batch, d, dff) if self.chain else 0
+        self.chain_ws = torch.zeros(chain_bytes // 4, **f32) if self.chain else None     # tags start at 0 = never valid
+        self.chain_sync = torch.zeros(64 + 32 * 256, device=dev, dtype=torch.int32) if self.chain else None
+        if self.chain:
+            self.acc64 = False
+            self.x64 = self.xmid = None
+        self.x2 = bool(TWO_SLAB_RESIDUAL and not self.acc64 and not self.chain and self._folded is not None
+                       and dff % 2048 == 0 and d <= 1024 and d % 128 == 0)
         self.xs = torch.zeros(2, batch, d, **f32) if self.x2 else None
         self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
@@ -222,7 +236,8 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
-            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid), xs=ptr(self.xs))
+            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid), xs=ptr(self.xs),
+            chain_ws=ptr(self.chain_ws), chain_ws_bytes=chain_bytes, chain_sync=ptr(self.chain_sync))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:
@@ -235,6 +250,13 @@ class ArDecoder:
     def x_in(self):
         """Where a step expects the current token's embedding (fp64 rows in accumulator form)."""
         return self.x64 if self.acc64 else self.x
+
+    def check_chain(self):
+        """After a synchronisation: raise if a grid barrier of the persistent chain timed out (its workgroups were
+        not all resident, or a previous launch was cut short) — the decoded tokens are then not to be trusted."""
+        if self.chain and int(self.chain_sync[1].item()) != 0:
+            raise _lib.VhError('vh_decode_chain: a wait on a stage hand-over timed out (the launch needs one resident workgroup per '
+                               'CU); set VALLE2_CHAIN=0 to decode with one launch per stage')
 
     def close(self):
         if getattr(self, '_h', None):
