@@ -470,6 +470,10 @@ typedef struct {
      * long K): the largest of vh_linear_ws_bytes(B*T, d_model, d_model), (B*T, d_model, dff), (B*T, dff, d_model) */
     void *gemm_ws;
     size_t gemm_ws_bytes;
+    /* optional: the stack's INPUT rows (B*T, d) when they must stay untouched (the module API returns a new
+     * tensor, modules.py:341-349): layer 0 reads its LayerNorm input and its residual from x_in and the stack
+     * writes its output to x — no copy of the input.  NULL: x is input and output. */
+    const float *x_in;
 } vh_forward_desc;
 int vh_transformer_forward(const vh_forward_desc* desc, void* stream);
 

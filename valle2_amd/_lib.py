@@ -56,7 +56,7 @@ class VhForwardDesc(C.Structure):
         ('layers', C.POINTER(VhLayer)), ('ada', C.c_void_p),
         ('x_len_dev', C.c_void_p), ('kv_len', C.c_void_p), ('mask', C.c_void_p), ('pad', C.c_void_p),
         ('x', C.c_void_p), ('xn', C.c_void_p), ('q', C.c_void_p), ('attn', C.c_void_p),
-        ('hidden', C.c_void_p), ('gemm_ws', C.c_void_p), ('gemm_ws_bytes', C.c_size_t),
+        ('hidden', C.c_void_p), ('gemm_ws', C.c_void_p), ('gemm_ws_bytes', C.c_size_t), ('x_in', C.c_void_p),
     ]
 
 

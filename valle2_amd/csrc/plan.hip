@@ -296,13 +296,14 @@ extern "C" int vh_transformer_forward(const vh_forward_desc* f, void* stream) {
     for (int i = 0; i < f->n_layers; ++i) {
         const vh_layer& L = f->layers[i];
         const float* ada = f->ada ? f->ada + (int64_t)i * 4 * D : nullptr;
-        TRY(vh_layernorm(f->x, L.ln1_g, L.ln1_b, ada, ada ? ada + D : nullptr, f->xn, M, D, f->ln_eps,
+        const float* src = (i == 0 && f->x_in) ? f->x_in : f->x;     // layer 0 may read a caller-owned input
+        TRY(vh_layernorm(src, L.ln1_g, L.ln1_b, ada, ada ? ada + D : nullptr, f->xn, M, D, f->ln_eps,
                          stream));
         TRY(vh_linear_qkv(f->xn, D, L.wqkv, f->q, D, L.kcache, L.vcache, nullptr, B, T, D, f->n_heads,
                           f->S_max, nullptr, nullptr, nullptr, nullptr, 0.f, stream));
         TRY(vh_attn_rows(f->q, D, L.kcache, L.vcache, f->attn, D, B, f->n_heads, T, T, f->S_max,
                          f->mode, f->x_len, f->x_len_dev, f->kv_len, f->mask, f->pad, stream));
-        TRY(vh_linear_ws(f->attn, D, L.wo, L.bo, f->x, D, f->x, D, M, D, D, VH_ACT_NONE, f->gemm_ws,
+        TRY(vh_linear_ws(f->attn, D, L.wo, L.bo, src, D, f->x, D, M, D, D, VH_ACT_NONE, f->gemm_ws,
                          f->gemm_ws_bytes, stream));
         TRY(vh_layernorm(f->x, L.ln2_g, L.ln2_b, ada ? ada + 2 * D : nullptr, ada ? ada + 3 * D : nullptr,
                          f->xn, M, D, f->ln_eps, stream));

@@ -149,13 +149,16 @@ class ForwardScratch:
 
 
 def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_dev=None,
-                        kv_len=None, mask=None, pad=None, embedding=None, scratch=None):
+                        kv_len=None, mask=None, pad=None, embedding=None, scratch=None, x_in=None):
     """Run all layers over x (B, T, d) IN PLACE (valle/models/modules.py:341-349), writing each
-    layer's K/V to `cache` rows 0..T-1.  Returns x."""
+    layer's K/V to `cache` rows 0..T-1.  Returns x.  With `x_in` (same shape, contiguous) the input rows are
+    read from there and left untouched, x is output only."""
     cfg = transformer.hparams
     B, T, d = x.shape
     if not x.is_contiguous():
         raise _lib.VhError('x must be contiguous')
+    if x_in is not None and (tuple(x_in.shape) != tuple(x.shape) or x_in.dtype != torch.float32):
+        raise _lib.VhError('x_in must match x')
     if cache.batch != B or cache.s_max < T or cache.n_layers != cfg.num_layers:
         raise _lib.VhError('KV cache does not fit this forward')
     scratch = scratch or ForwardScratch(B * T, d, cfg.dim_feedforward, x.device)
@@ -170,7 +173,7 @@ def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_
         S_max=cache.s_max, mode=mode, x_len=int(x_len), ln_eps=1e-5, layers=table, ada=ptr(ada),
         x_len_dev=ptr(x_len_dev), kv_len=ptr(kv_len), mask=ptr(mask), pad=ptr(pad),
         x=ptr(x), xn=ptr(scratch.xn), q=ptr(scratch.q), attn=ptr(scratch.attn),
-        hidden=ptr(scratch.hidden), gemm_ws=ptr(scratch.ws), gemm_ws_bytes=scratch.ws_bytes)
+        hidden=ptr(scratch.hidden), gemm_ws=ptr(scratch.ws), gemm_ws_bytes=scratch.ws_bytes, x_in=ptr(x_in))
     check(_lib.lib().vh_transformer_forward(C.byref(desc), stream()), 'vh_transformer_forward')
     return x
 

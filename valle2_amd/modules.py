@@ -430,8 +430,9 @@ class Transformer(nn.Module):
         cfg = self.hparams
         cache = KVCache(cfg.num_layers, b, cfg.n_heads, t + (64 if use_cache else 0), x.device)
         spec = _mask_spec(attn_mask, padding_mask, t, t, x.device)
-        y = x.contiguous().clone()
-        transformer_forward(self, y, cache, embedding=embedding, **spec)
+        x = x.contiguous()                # the caller's tensor stays untouched: layer 0 reads it, the stack writes y
+        y = torch.empty_like(x)
+        transformer_forward(self, y, cache, embedding=embedding, x_in=x, **spec)
         new_kv: tuple = ()
         if use_cache:
             for i in range(cfg.num_layers):
