@@ -65,6 +65,8 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16
        VH_TUNE_SPLITK_FIXUP = 5,    /* wide-K decode GEMM split over K: 0 (default) = slabs + reduce kernel; 2 = one launch,
                                        the last K slice to arrive sums the slabs (measured slower: three dependent
                                        memory-side round trips cost more than a kernel boundary) */
+       VH_TUNE_GRAPH_STEPS = 6,     /* decode graph: 0 (default) = replay in graphs of 8 consecutive steps (+ single-step graphs
+                                       for the remainder); 1 = one graph launch per step */
        VH_TUNE_COUNT = 8 };
 int vh_set_tuning(int knob, int value);
 

@@ -400,3 +400,21 @@ def test_generate_batch_ragged_rows_vs_oracle():
         ref = O.ar_generate(sd, cfg, *u, trace=trace)
         tokens_match(rows[r, starts[r]: starts[r] + 20], ref, torch.tensor(trace['margin']))
         assert torch.equal(rows[r, 1:starts[r]].cpu(), u[1][:, 0]) and int(rows[r, 0]) == cfg.bos_token
+
+
+def test_generate_batch_beyond_64_rows_runs_in_groups():
+    """More rows than one decode launch serves (64): consecutive groups, every row equal to itself in a small batch."""
+    from valle2_amd import synth
+    kw = dict(C.AR_TINY, max_audio_len=10)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=5, rich=True), cfg)
+    m = build('ValleAR', kw, sd)
+    g = torch.Generator().manual_seed(1)
+    texts = [torch.randint(0, 256, (8 + i % 5,), generator=g).to(DEV) for i in range(70)]
+    firsts = [torch.randint(0, 1024, (12 + i % 7,), generator=g).to(DEV) for i in range(70)]
+    out = m.generate_batch(texts, firsts)
+    starts = m.last_generate_stats['prompt_lens']
+    assert out.shape[0] == 70 and len(starts) == 70 and m.last_generate_stats['sum_logprobs'].shape == (70,)
+    for r in (0, 63, 64, 69):
+        alone = m.generate_batch([texts[r]], [firsts[r]])
+        assert torch.equal(out[r, starts[r]:starts[r] + 10], alone[0, starts[r]:starts[r] + 10]), r

@@ -41,6 +41,8 @@ struct vh_ar_decoder {
     std::vector<vh_layer> layers;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_n = nullptr;        // VH_GRAPH_STEPS consecutive steps in one graph (fewer graph launches per generate)
+    hipGraphExec_t exec_n = nullptr;
     int ldl = 0;
 };
 
@@ -86,6 +88,8 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
     if (!dec) return;
     if (dec->exec) (void)hipGraphExecDestroy(dec->exec);
     if (dec->graph) (void)hipGraphDestroy(dec->graph);
+    if (dec->exec_n) (void)hipGraphExecDestroy(dec->exec_n);
+    if (dec->graph_n) (void)hipGraphDestroy(dec->graph_n);
     delete dec;
 }
 
@@ -218,27 +222,44 @@ extern "C" int vh_ar_decoder_step(vh_ar_decoder* dec, void* stream) {
     return decoder_enqueue(dec, (hipStream_t)stream, nullptr);
 }
 
+#define VH_GRAPH_STEPS 8
+
+static int capture_steps(vh_ar_decoder* dec, hipStream_t s, int n_steps, hipGraph_t* graph, hipGraphExec_t* exec) {
+    if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
+    if (*graph) { (void)hipGraphDestroy(*graph); *graph = nullptr; }
+    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
+    int rc = VH_OK;
+    for (int i = 0; i < n_steps && rc == VH_OK; ++i) rc = decoder_enqueue(dec, s, nullptr);
+    e = hipStreamEndCapture(s, graph);
+    if (rc != VH_OK) return rc;
+    VH_REQUIRE(e == hipSuccess && *graph, VH_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    e = hipGraphInstantiate(exec, *graph, nullptr, nullptr, 0);
+    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    return VH_OK;
+}
+
 extern "C" int vh_ar_decoder_capture(vh_ar_decoder* dec, void* stream) {
     VH_REQUIRE(dec, VH_EINVAL, "vh_ar_decoder_capture: null decoder");
     VH_REQUIRE(stream, VH_EINVAL, "vh_ar_decoder_capture: capture needs a non-null stream");
     hipStream_t s = (hipStream_t)stream;
-    if (dec->exec) { (void)hipGraphExecDestroy(dec->exec); dec->exec = nullptr; }
-    if (dec->graph) { (void)hipGraphDestroy(dec->graph); dec->graph = nullptr; }
-    hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
-    const int rc = decoder_enqueue(dec, s, nullptr);
-    e = hipStreamEndCapture(s, &dec->graph);
-    if (rc != VH_OK) return rc;
-    VH_REQUIRE(e == hipSuccess && dec->graph, VH_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
-    e = hipGraphInstantiate(&dec->exec, dec->graph, nullptr, nullptr, 0);
-    VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    // the step advances device-side state only, so N captured steps are the same step N times: one graph of a
+    // single step (remainders) and one of VH_GRAPH_STEPS steps (the bulk: an eighth of the graph launches)
+    TRY(capture_steps(dec, s, 1, &dec->graph, &dec->exec));
+    if (vh_tuning(VH_TUNE_GRAPH_STEPS) != 1) TRY(capture_steps(dec, s, VH_GRAPH_STEPS, &dec->graph_n, &dec->exec_n));
     return VH_OK;
 }
 
 extern "C" int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream) {
     VH_REQUIRE(dec && dec->exec, VH_ESTATE, "vh_ar_decoder_replay: capture first");
     VH_REQUIRE(n_steps >= 0, VH_EINVAL, "vh_ar_decoder_replay: n_steps=%d", n_steps);
-    for (int i = 0; i < n_steps; ++i) {
+    int i = 0;
+    if (dec->exec_n)
+        for (; i + VH_GRAPH_STEPS <= n_steps; i += VH_GRAPH_STEPS) {
+            hipError_t e = hipGraphLaunch(dec->exec_n, (hipStream_t)stream);
+            VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+        }
+    for (; i < n_steps; ++i) {
         hipError_t e = hipGraphLaunch(dec->exec, (hipStream_t)stream);
         VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
     }

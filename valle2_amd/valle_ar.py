@@ -27,6 +27,7 @@ except Exception:  # pragma: no cover - lightning is absent in this image
             return None
 
 EOS_POLL = 32
+MAX_DECODE_ROWS = 64      # rows per decode launch (vh_ar_decoder: 1..64)
 
 
 class ValleAR(_Base):
@@ -178,6 +179,26 @@ class ValleAR(_Base):
         if B == 0 or len(first_codes) != B:
             raise ValueError('generate_batch: texts and first_codes must be non-empty lists of equal length')
         max_new = cfg.max_audio_len if max_new is None else max_new
+        if B > MAX_DECODE_ROWS:
+            # the decode kernels serve up to 64 rows per launch (4 MFMA row tiles): larger batches run as consecutive
+            # groups of 64 rows; rows are independent, so the result is what one pass would give
+            parts, stats = [], []
+            for s0 in range(0, B, MAX_DECODE_ROWS):
+                parts.append(self.generate_batch(texts[s0:s0 + MAX_DECODE_ROWS], first_codes[s0:s0 + MAX_DECODE_ROWS],
+                                                 max_new=max_new, use_graph=use_graph))
+                stats.append(self.last_generate_stats)
+            width = max(p.shape[1] for p in parts)
+            out = torch.full((B, width), self.eos_token, device=dev, dtype=torch.int64)
+            r = 0
+            for p in parts:
+                out[r:r + p.shape[0], :p.shape[1]] = p
+                r += p.shape[0]
+            merged = dict(stats[-1])
+            merged['prompt_lens'] = [x for st in stats for x in st['prompt_lens']]
+            merged['sum_logprobs'] = torch.cat([st['sum_logprobs'] for st in stats])
+            merged['tokens_appended'] = max(st['tokens_appended'] for st in stats)
+            self.last_generate_stats = merged
+            return out
         txs = [int(t.shape[0]) for t in texts]
         pls = [int(c.shape[0]) + 1 for c in first_codes]                  # BOS + prompt
         ragged = len(set(txs)) > 1 or len(set(pls)) > 1
