@@ -359,7 +359,7 @@ def main():
         result['roofline'] = {
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_unit': 'bytes/launch',
-            'kernel': 'attn_decode_kernel', 'launches': (new - 1) * cfg.num_layers,
+            'kernel': 'attn_decode_ring_kernel<8, 2> (vh_attn_decode)', 'launches': (new - 1) * cfg.num_layers,
             'avg_launch_us': dur_s * 1e6,
             'timing': 'kernel start/stop events' if kern_s > 0 else 'marker-event bracket',
             'marker_bracket_us': raw_s * 1e6, 'marker_floor_us': floor_s * 1e6,

@@ -54,7 +54,10 @@ const char* vh_last_error(void);
 
 /* Kernel-selection knobs for benchmarking A/B runs in one process (0 = built-in default).
  * Results are identical up to fp32 summation order whatever the setting. */
-enum { VH_TUNE_DECODE_VARIANT = 0,  /* 1 (default) = 32-key burst kernel, 2 = 16-key pipelined */
+enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,head) per CU and n_split == 1, else burst 1);
+                                       1 = 32-key burst kernel, 2 = 16-key pipelined, 3 = burst with temporal loads,
+                                       4..9 = ring kernels (waves x register sets x keys: 8x3x32, 16x1x32, 12x2x32, 8x2x32,
+                                       16x2x16, 8x4x16), 10.. = diagnostics without arithmetic */
        VH_TUNE_DECODE_WAVES = 1,    /* waves per decode-attention workgroup: 4, 8 or 16 */
        VH_TUNE_ROW_GROUPS = 2,      /* decode GEMMs (16 < M <= 64): 1 (default) = one workgroup per 16 rows x 16 columns,
                                        (8 rows while the grid stays within the CUs), 2 = one workgroup per

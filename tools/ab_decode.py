@@ -25,20 +25,25 @@ def main(rounds=8):
     firsts = [u[1][:, 0].cuda() for u in utts]
     forms = {'default': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
              'two-slab': dict(TWO_SLAB_RESIDUAL=True, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
-             'chain': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=True)}
+             'ring attention (8 waves x 2 sets)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=7),
+             'ring attention (16 waves x 2 sets of 16 keys)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=8),
+             'ring attention (8 waves x 4 sets of 16 keys)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=9)}
     res = {k: [] for k in forms}
     outs = {}
     for r in range(rounds + 1):
         for name, flags in forms.items():
+            from valle2_amd import _lib
+            _lib.lib().vh_set_tuning(0, flags.get('_variant', 0))
             for k, v in flags.items():
-                setattr(engine, k, v)
+                if not k.startswith('_'):
+                    setattr(engine, k, v)
             out = m.generate_batch(texts, firsts)
             torch.cuda.synchronize()
             if r:
                 res[name].append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
             outs[name] = out
     for name, v in res.items():
-        print(f'{name:10s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')
+        print(f'{name:46s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')
     print('same tokens:', all(bool(torch.equal(outs['default'], o)) for o in outs.values()))
 
 

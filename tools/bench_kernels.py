@@ -56,6 +56,17 @@ def bench_attn():
                             i[0] += 1
                             K.attn_decode(q, kc, vc, out, cl, 1, ns, ws)
                         res.setdefault((variant, waves, ns), []).append(timeit(fn, iters=48))
+        for rnd in range(3):                      # ring kernels (round 2): the variant fixes waves x register sets
+            for variant in (4, 5, 6, 7, 8, 9):
+                lib.vh_set_tuning(0, variant)
+                lib.vh_set_tuning(1, 0)
+                i = [0]
+
+                def fn():
+                    kc, vc = caches[i[0] % 12]
+                    i[0] += 1
+                    K.attn_decode(q, kc, vc, out, cl, 1, 1, None)
+                res.setdefault((variant, 0, 1), []).append(timeit(fn, iters=48))
         for k, v in sorted(res.items(), key=lambda kv: statistics.median(kv[1])):
             us = statistics.median(v)
             print(f'attn S={S} variant={k[0]} waves={k[1]} n_split={k[2]}: {us:7.2f} us  '

@@ -222,6 +222,140 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
     }
 }
 
+// Ring variant (round 2).  What the burst kernel leaves on the table: tools/probe_read_bw.hip shows that plain
+// streaming READS reach 8.0-8.1 TB/s on this part when every CU keeps >= 256 KB of non-temporal loads in flight all
+// the time (16 x 16 B per thread x 1024 threads), against 6.5 TB/s with half of that — the 6.29 TB/s "copy rate"
+// round 1 took for the ceiling is a read+write figure.  The burst kernel has 256 KB in flight only at the moment
+// its 16 waves have all just issued; each wave then waits for its whole burst, reduces it, and only then asks
+// again, and its very first request waits for a dependent load of cache_len[b].  Here a wave owns a ring of D
+// register sets of 32 keys each: D-1 bursts are always outstanding while one is reduced, and the first D-1 bursts
+// are issued BEFORE the context length is known (addresses clamped inside the cache allocation; what lies beyond
+// the row's length is masked once the length has arrived), so the stream starts with the kernel.
+// NW waves x D sets x 16 KB in flight per CU: 8 x 3 = 384 KB (232 VGPRs, 2 waves per SIMD).
+template <int NW, int D, int CK = 32, bool NOCOMP = false>
+__global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ kc,
+    const float* __restrict__ vc, float* __restrict__ out, int ldo,
+    const int32_t* __restrict__ cache_len, int len_bias, int n_heads, int S_max, int n_split,
+    float* __restrict__ partial) {
+    __shared__ float s_m[NW], s_l[NW];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
+    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const float* kb = kc + (int64_t)bh * S_max * HD + 4 * c16;
+    const float* vb = vc + (int64_t)bh * S_max * HD + 4 * c16;
+
+    constexpr int LPS = CK / 4;                                    // loads per set and operand: 4 keys per wave instruction
+    f32x4 kf[D][LPS], vf[D][LPS];
+    int key_limit = S_max - 1;                                     // before the length is known: stay inside the allocation
+    auto load = [&](int c, f32x4 (&kq)[LPS], f32x4 (&vq)[LPS]) {  // unconditional loads, clamped row index
+        const int key0 = c * CK + g;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int key = min(key0 + 4 * i, key_limit);
+            kq[i] = ld4_stream(kb + (int64_t)key * HD);
+            vq[i] = ld4_stream(vb + (int64_t)key * HD);
+        }
+    };
+    // speculative start (n_split == 1: the wave's chunks are w, w + NW, ... whatever the length is)
+    const bool spec = n_split == 1;
+    if (spec) {
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j) load(w + j * NW, kf[j], vf[j]);
+    }
+    const int len = cache_len[b] + len_bias;
+    const int nchunks = (len + CK - 1) / CK;
+    const int cps = (nchunks + n_split - 1) / n_split;
+    const int c_begin = split * cps;
+    const int c_end = min(nchunks, c_begin + cps);
+    key_limit = len - 1;                 // from here on the tail re-reads the row's last key instead of rows beyond it
+    const float qscale = 0.125f * LOG2E;
+    const f32x4 q4 = ld4(q + (int64_t)b * ldq + head * HD + 4 * c16) * qscale;
+    if (!spec) {
+#pragma unroll
+        for (int j = 0; j < D - 1; ++j)
+            if (c_begin + w + j * NW < c_end) load(c_begin + w + j * NW, kf[j], vf[j]);
+    }
+
+    float m = NEG_INF, l = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    auto reduce = [&](int c, const f32x4 (&kq)[LPS], const f32x4 (&vq)[LPS]) {
+        if (NOCOMP) {                                             // diagnostic: the loads alone (wrong results)
+#pragma unroll
+            for (int i = 0; i < LPS; ++i) o += kq[i] + vq[i];
+            m = 0.f; l = 1.f;
+            return;
+        }
+        const int key0 = c * CK + g;
+        const bool whole = c * CK + CK <= len;                    // wave-uniform: no masking for interior chunks
+        float sc[LPS];
+        float cmax = NEG_INF;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const f32x4 t = kq[i] * q4;
+            const float d = row16_sum((t.x + t.y) + (t.z + t.w));
+            sc[i] = (whole || key0 + 4 * i < len) ? d : NEG_INF;
+            cmax = fmaxf(cmax, sc[i]);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m, cmax);  // finite: chunk c < nchunks holds >= 1 valid key
+        const float alpha = vh_exp2(m - m_new);
+        o *= alpha;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const float p = vh_exp2(sc[i] - m_new);
+            l += p;
+            // rows beyond the length hold whatever the allocation held (possibly NaN): select, do not multiply by 0
+            const f32x4 vv = (whole || key0 + 4 * i < len) ? vq[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            o += vv * p;
+        }
+        m = m_new;
+    };
+    for (int c0 = c_begin + w; c0 < c_end; c0 += D * NW) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int c = c0 + j * NW;
+            if (c < c_end) {
+                const int cn = c + (D - 1) * NW;                 // the burst that keeps D - 1 outstanding
+                if (cn < c_end) load(cn, kf[(j + D - 1) % D], vf[(j + D - 1) % D]);
+                reduce(c, kf[j], vf[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        o.x += __shfl_xor(o.x, sh, 64); o.y += __shfl_xor(o.y, sh, 64);
+        o.z += __shfl_xor(o.z, sh, 64); o.w += __shfl_xor(o.w, sh, 64);
+        l += __shfl_xor(l, sh, 64);
+    }
+    if (lane < 16) st4(&s_o[w][4 * c16], o);
+    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
+    __syncthreads();
+    if (tid < HD) {
+        float M = s_m[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
+            L += s_l[k] * wgt;
+            O += s_o[k][tid] * wgt;
+        }
+        if (n_split == 1) {
+            out[(int64_t)b * ldo + head * HD + tid] = O / L;
+        } else {
+            float* pr = partial + ((int64_t)bh * n_split + split) * PART_LD;
+            pr[tid] = O;
+            if (tid == 0) { pr[HD] = M; pr[HD + 1] = L; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(
     const float* __restrict__ partial, float* __restrict__ out, int ldo, int n_heads, int n_split) {
     const int bh = blockIdx.x, b = bh / n_heads, head = bh - b * n_heads;
@@ -268,10 +402,22 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
 #define AD(KERN, ...)                                                                              \
     hipExtLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, q, ldq, \
                           kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
-    const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
+    int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
     const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
+    // default: one (b, head) per CU and no key split -> the ring kernel (8 waves x 2 register sets of 32 keys, speculative
+    // start: 605.9 vs 615.2 us per decode step, profiles/r2_ab_decode_ring.log); otherwise the burst kernel
+    if (variant == 0 && big && n_split == 1 && nw == 0) variant = 7;
     const int waves = nw ? nw : (big ? 16 : 4);
-    if (variant == 3) {          // burst kernel with plain (temporal) loads, for A/B runs
+    if (variant >= 4) {          // ring kernels: 4 = 8 waves x 3 sets, 5 = 16 waves x 1 set + speculative start, 6 = 12 x 2, 7 = 8 x 2
+        if (variant == 4) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 3); }
+        else if (variant == 5) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 1); }
+        else if (variant == 6) { const int waves = 12; AD(attn_decode_ring_kernel, 12, 2); }
+        else if (variant == 7) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 2); }
+        else if (variant == 8) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 2, 16); }
+        else if (variant == 9) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 4, 16); }
+        else if (variant == 10) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 1, 32, true); }   // diagnostic: no compute
+        else { const int waves = 8; AD(attn_decode_ring_kernel, 8, 2, 32, true); }                         // diagnostic
+    } else if (variant == 3) {          // burst kernel with plain (temporal) loads, for A/B runs
         if (waves == 16) AD(attn_decode_kernel, 16, false); else if (waves == 8) AD(attn_decode_kernel, 8, false);
         else AD(attn_decode_kernel, 4, false);
     } else if (variant != 2) {   // default: burst kernel, non-temporal K/V loads
