@@ -529,6 +529,39 @@ def test_attn_decode(K, B, h, S, n_split):
     close(out, ref, atol=3e-5)
 
 
+@pytest.mark.parametrize('variant', [7, 4, 8, 9, 1])
+@pytest.mark.parametrize('S_max', [40, 300, 1100])
+def test_attn_decode_ring_kernels_short_and_ragged_rows(K, variant, S_max):
+    """The ring kernels issue their first burst before the row's length is known and never predicate a load:
+    rows shorter than a burst, lengths at chunk edges, and NaN / Inf garbage beyond every row's length (what a
+    torch.empty cache may hold) must not leak into the result.  One (b, head) per CU (B x h = 256, n_split = 1),
+    as in the decode step."""
+    from valle2_amd import _lib
+    B, h = 32, 8
+    d = 64 * h
+    gen = g(70 + S_max)
+    q = torch.randn(B, d, generator=gen)
+    k = torch.randn(B, h, S_max, 64, generator=gen)
+    v = torch.randn(B, h, S_max, 64, generator=gen)
+    edges = [1, 2, 5, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1087]
+    lens = torch.tensor([min(S_max, edges[i % len(edges)] + (i // len(edges))) for i in range(B)], dtype=torch.int32)
+    ref = torch.empty(B, d)
+    for b in range(B):
+        L = int(lens[b])
+        ref[b] = _sdpa_ref(q[b].view(1, h, 1, 64), k[b:b + 1, :, :L], v[b:b + 1, :, :L], None).reshape(d)
+        k[b, :, L:] = float('nan')                      # poison everything beyond the row's length
+        v[b, :, L:] = float('inf')
+    out = torch.full((B, d), float('nan'), device=DEV)
+    lib = _lib.lib()
+    lib.vh_set_tuning(0, variant)
+    try:
+        K.attn_decode(q.to(DEV), k.to(DEV), v.to(DEV), out, (lens - 1).to(DEV), 1, 1, None)
+    finally:
+        lib.vh_set_tuning(0, 0)
+    assert bool(torch.isfinite(out).all()), 'garbage beyond a row\'s length leaked into the attention output'
+    close(out, ref, atol=3e-5)
+
+
 def test_linear_qkv_scatter(K):
     B, T, h = 3, 5, 2
     d = 64 * h
