@@ -1,4 +1,4 @@
-"""Static checks on the compiled gfx950 code of the LDS-DMA tile GEMM (no GPU needed; hipcc cross-compiles).
+"""Static checks on the compiled gfx950 code of the LDS-DMA tile GEMMs (forward NT kernel and the TN weight-gradient kernel) (no GPU needed; hipcc cross-compiles).
 
 The kernel issues its DMA from inline assembly that writes M0, a reserved register the compiler does not track
 through a clobber list, and relies on its main loop holding no vector ALU instruction besides the MFMAs.  Both are
@@ -32,7 +32,13 @@ def check(asm):
     kernels = re.findall(r'^(_Z20gemm_tile_dma_kernelILi\dE\w*):[^\n]*\n(.*?)s_endpgm', asm, re.S | re.M)
     if len(kernels) < 3:
         problems.append(f'expected >= 3 instantiations of gemm_tile_dma_kernel, found {len(kernels)}')
-    for name, body in kernels:
+    # the weight-gradient kernel (round 2): same rules, 64 ds_read2_b32 per two K steps instead of 32 ds_read_b128
+    tn = re.findall(r'^(_Z19gemm_tile_tn_kernel\w*):[^\n]*\n(.*?)s_endpgm', asm, re.S | re.M)
+    if len(tn) != 1:
+        problems.append(f'expected gemm_tile_tn_kernel once, found {len(tn)}')
+    expected = {name: (128, 16, 32) for name, _ in kernels}
+    expected.update({name: (128, 16, 64) for name, _ in tn})
+    for name, body in kernels + tn:
         lines = [l.strip() for l in body.splitlines()]
         code = [l for l in lines if l and not l.startswith(';')]
         for l in code:
@@ -57,9 +63,9 @@ def check(asm):
         n_mfma = sum(o.startswith('v_mfma') for o in ops)
         n_dma = sum(o.startswith('global_load_lds') for o in ops)
         n_lds = sum(o.startswith('ds_read') for o in ops)
-        if (n_mfma, n_dma, n_lds) != (128, 16, 32):
+        if (n_mfma, n_dma, n_lds) != expected[name]:
             problems.append(f'{name}: K loop (two steps) has {n_mfma} MFMA / {n_dma} DMA / {n_lds} ds_read, '
-                            f'expected 128 / 16 / 32')
+                            f'expected {expected[name]}')
     return problems
 
 
