@@ -70,6 +70,8 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
                                        memory-side round trips cost more than a kernel boundary) */
        VH_TUNE_GRAPH_STEPS = 6,     /* decode graph: 0 (default) = replay in graphs of 8 consecutive steps (+ single-step graphs
                                        for the remainder); 1 = one graph launch per step */
+       VH_TUNE_PIPE_MODE = 7,       /* pipelined decode attention (desc.qkv_ll): 0 (default) = attention on the decoder's second
+                                     * stream; 1 = same kernels in stream order on the caller's stream (A/B of the kernels alone) */
        VH_TUNE_COUNT = 8 };
 int vh_set_tuning(int knob, int value);
 
@@ -155,6 +157,14 @@ int vh_linear_qkv_folded(const void* A, int a_form, int lda, const float* Wf, co
                          const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
                          const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
                          float ln_eps, int64_t a_slab_stride, void* stream);
+/* Pipelined decode form of vh_linear_qkv_folded (one new row per sequence, T = 1): q, and the K / V rows in
+ * addition to their cache write, are published as (value, tag) pairs — qkv_ll[which][b][c] = 2 floats, which = 0 q,
+ * 1 k, 2 v; tag = ((cache_len[0] + 1) * 64 + layer) * 8 + 5 — for a vh_attn_decode_pipe launch that is ALREADY
+ * RUNNING on another stream and spins on them.  No plain q output.  layer < 64; cache_len[0] must advance between
+ * steps; the caller zeroes qkv_ll before a sequence of steps whose first cache_len[0] may repeat an old one. */
+int vh_linear_qkv_folded_pipe(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                              float* kcache, float* vcache, const int32_t* cache_len, int B, int d_model, int n_heads,
+                              int S_max, float ln_eps, float* qkv_ll, int layer, void* stream);
 /* a_form: 0 = A is fp32 rows; 1 = fp64 accumulator rows (below); 2 = the TWO-SLAB form of the residual
  * stream: row r = A[r] + A[a_slab_stride + r] (two fp32 slabs, added in the operand load).
  *
@@ -260,6 +270,21 @@ size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
 int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
                    int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,
                    int n_split, void* partial, void* stream);
+/* Decode attention that may be launched BEFORE its query exists (modules.py:134-139 with T = 1), on another stream
+ * than the launches that feed and consume it: every workgroup (one per (b, head), one per CU, <= 128 VGPRs so that
+ * the GEMM launches it waits for fit beside it) requests the first 256 cached keys / values, then waits — bounded; on
+ * a timeout err[0] becomes 0xA0000000 | layer, the output is garbage and later launches stop waiting (err: the block
+ * of vh_ar_decoder_desc.pipe_err) — for the pairs vh_linear_qkv_folded_pipe publishes with the (cache_len[0], layer)
+ * tag; cache_len is re-read at agent scope while waiting (its update by the previous step's sample launch may still
+ * be pending when this launch starts).  Attends keys 0 .. cache_len[b] with the newest K / V row taken from the
+ * pairs, and publishes the output as pairs, out_ll[b][c] (tag + 1), for vh_linear_ll_in. */
+int vh_attn_decode_pipe(const float* qkv_ll, const float* kcache, const float* vcache, float* out_ll,
+                        const int32_t* cache_len, int B, int n_heads, int S_max, int layer, uint32_t* err, void* stream);
+/* out = A W^T + bias + residual (modules.py:171,277) where A (M, K) arrives as the pairs a vh_attn_decode_pipe launch
+ * of the same (cache_len[0], layer) publishes, possibly AFTER this launch started: the weights are requested first, the
+ * wait for the pairs is bounded (err[0] = 0x80000000 | ... on a timeout).  M <= 64, N % 16 == 0, K == 512. */
+int vh_linear_ll_in(const float* a_ll, const float* W, const float* bias, const float* residual, int ldr, float* out,
+                    int ldo, int M, int N, int K, const int32_t* cache_len, int layer, uint32_t* err, void* stream);
 
 /* ---- K12/K13: greedy sampling + decode-state update + next-token embedding ------------------
  * replaces topk_sampling(top_k=1) (valle/models/utils.py:46-68: argmax, lowest index on ties),
@@ -338,6 +363,17 @@ typedef struct {
     float *chain_ws;
     size_t chain_ws_bytes;
     uint32_t *chain_sync;
+    /* optional: pipelined decode attention (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe + vh_linear_ll_in): qkv_ll
+     * = 3 x (B, d_model) (value, tag) pairs = 6*B*d_model floats, zeroed by the caller before every generate; pipe_err =
+     * 16 + 512 uint32, zero ([0] error word; [1] nonzero: workgroup 0 of every attention launch leaves three
+     * wall-clock stamps — start, inputs arrived, end — as uint64 at word 16 + 8 * layer).  The decoder then owns a second
+     * stream and a second set of graphs: the attention launches of a run of steps go there, back to back, so layer
+     * l+1's attention starts (and requests its first keys) as soon as layer l's has finished; the two streams meet
+     * only at the ends of vh_ar_decoder_step / _replay, in between they hand data over through the pairs.  Needs folded
+     * weights, d_model == 512, 2 <= n_layers <= 64; ignored with x64 / xs / chain_ws. */
+    float *qkv_ll;
+    float *attn_ll;                   /* (B, d_model) pairs = 2*B*d_model floats, zeroed likewise: the attention output */
+    uint32_t *pipe_err;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

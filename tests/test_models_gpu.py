@@ -286,6 +286,37 @@ def test_persistent_chain_is_bit_identical_to_one_launch_per_stage():
 
 
 
+@pytest.mark.parametrize('rows', [5, 40])
+def test_pipelined_attention_is_bit_identical(rows):
+    """VALLE2_PIPE: the attention launches run on the decoder's second stream, a layer early, and take q / k / v from
+    (value, tag) pairs (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe).  Same arithmetic in the same order as the
+    8-wave ring kernel's 32-key chunks: tokens must equal the stream-ordered decoder's bit for bit, graph and eager,
+    ragged rows, and with more (row, head) workgroups than CUs (40 rows x 8 heads = 320)."""
+    from valle2_amd import engine, synth
+    kw = dict(C.MID, norm='LayerNorm', num_beams=rows, top_k=1, max_audio_len=40)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True), cfg)
+    m = build('ValleAR', kw, sd)
+    g = torch.Generator().manual_seed(8)
+    tl = [(30, 17, 44, 30, 9)[i % 5] + i // 5 for i in range(rows)]
+    pl = [(50, 61, 20, 50, 33)[i % 5] + i // 5 for i in range(rows)]
+    texts = [torch.randint(0, 256, (n,), generator=g).to(DEV) for n in tl]
+    firsts = [torch.randint(0, 1024, (n,), generator=g).to(DEV) for n in pl]
+    old = engine.PIPELINED_ATTENTION
+    outs = {}
+    try:
+        for pipe in (False, True):
+            engine.PIPELINED_ATTENTION = pipe
+            for graph in (True, False):
+                outs[(pipe, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
+                assert m.last_generate_stats['pipe'] == pipe
+    finally:
+        engine.PIPELINED_ATTENTION = old
+    ref = outs[(False, True)]
+    for k, v in outs.items():
+        assert torch.equal(v, ref), f'pipe={k[0]} graph={k[1]} differs from the stream-ordered graph decoder'
+
+
 def test_generate_batch_distinct_rows_vs_oracle():
     """Rows are independent utterances: each row of generate_batch must equal the oracle run on
     that utterance alone (a kernel that mixed rows or read row 0 for everyone would pass the

@@ -23,17 +23,20 @@ def main(rounds=8):
     utts = [synth.synth_utterance(cfg, 128, 128, 767, seed=1234 + u) for u in range(32)]
     texts = [torch.cat([u[0], u[2]]).cuda() for u in utts]
     firsts = [u[1][:, 0].cuda() for u in utts]
-    forms = {'default': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
-             'two-slab': dict(TWO_SLAB_RESIDUAL=True, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False),
-             'ring attention (8 waves x 2 sets)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=7),
-             'ring attention (16 waves x 2 sets of 16 keys)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=8),
-             'ring attention (8 waves x 4 sets of 16 keys)': dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, _variant=9)}
+    base = dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, PIPELINED_ATTENTION=False)
+    forms = {'default': dict(base),
+             'two-slab': dict(base, TWO_SLAB_RESIDUAL=True),
+             'pipelined attention': dict(base, PIPELINED_ATTENTION=True),
+             'pipelined kernels in stream order': dict(base, PIPELINED_ATTENTION=True, _pipe_mode=1)}
+    if len(sys.argv) > 1:
+        forms = {k: v for k, v in forms.items() if k == 'default' or any(a in k for a in sys.argv[1:])}
     res = {k: [] for k in forms}
     outs = {}
     for r in range(rounds + 1):
         for name, flags in forms.items():
             from valle2_amd import _lib
             _lib.lib().vh_set_tuning(0, flags.get('_variant', 0))
+            _lib.lib().vh_set_tuning(7, flags.get('_pipe_mode', 0))
             for k, v in flags.items():
                 if not k.startswith('_'):
                     setattr(engine, k, v)

@@ -45,6 +45,7 @@ class VhArDecoderDesc(C.Structure):
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p), ('xs', C.c_void_p),
         ('chain_ws', C.c_void_p), ('chain_ws_bytes', C.c_size_t), ('chain_sync', C.c_void_p),
+        ('qkv_ll', C.c_void_p), ('attn_ll', C.c_void_p), ('pipe_err', C.c_void_p),
     ]
 
 
@@ -109,6 +110,12 @@ SIGNATURES = {
                                    c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
     'vh_attn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_linear_qkv_folded_pipe': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int,
+                                           C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, C.c_int, C.c_void_p]),
+    'vh_attn_decode_pipe': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_void_p, C.c_void_p]),
+    'vh_linear_ll_in': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 c_i32p, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,

@@ -46,6 +46,9 @@ struct GemmArgs {
     const float* ll_in; const float* a_org; uint32_t tag_in;
     float* ll_out; const float* out_org; uint32_t tag_out;
     uint32_t* err_word;
+    // pipelined decode (EPI_QKV with ll_out set): q and the newest K / V row also go out as (value, tag) pairs,
+    // [q | k | v] x (ll_rows, d_model); tag = ((cl0[0] + 1) * 64 + tag_out) * 8 + 5 (tag_out carries the layer)
+    const int32_t* cl0; int ll_rows;
     int64_t s2;   // two-slab form of the residual stream (X64 bits 2/3, EPI_SLAB2): element offset of slab 1
     float* slab;  // EPI_FIXUP: partial sums [slice][M][lds] and one arrival counter per column block
     int lds;
@@ -870,8 +873,10 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
     // Row groups (vb.nz > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
+    int row0 = 0;                                          // first row of this workgroup's group in the whole problem
     if (vb.nz > 1) {
         const int r0 = vb.z * a.rg_rows;
+        row0 = r0;
         a.A = reinterpret_cast<const float*>(reinterpret_cast<const AT*>(a.A) + (int64_t)r0 * a.lda);
         if (a.res) {
             if (X64 & 2) a.res = reinterpret_cast<const float*>(reinterpret_cast<const double*>(a.res) + (int64_t)r0 * a.ldr);
@@ -976,7 +981,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
                 const float* sp = reinterpret_cast<const float*>(a.A) + (int64_t)(rsel ? a.M - 1 : 0) * a.lda +
                                   (LN ? 0 : k_lo) + 16 * min(blk, nblk - 1);
                 const uint64_t* q = reinterpret_cast<const uint64_t*>(LL_IN(sp));
-                int spins = 0;
+                // an earlier timeout is final: later waits give up at once (the results are void anyway)
+                int spins = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
                 for (;;) {
                     const uint64_t pr = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__all((uint32_t)(pr >> 32) == a.tag_in)) break;
@@ -986,7 +992,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
             }
             __syncthreads();
         }
-        int spins = 0;
+        int spins = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
         for (;;) {
             if (LN) ln_load(0);
             issue_x_ll(0);
@@ -1002,7 +1008,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
             if (__all(ok)) break;
             ll_first = false;
             if (++spins > LL_SPIN_LIMIT) {              // bounded: flag the error and go on (garbage out, no hang)
-                if (lane == 0) __hip_atomic_store(a.err_word, 0x80000000u | (a.tag_in & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) atomicCAS(a.err_word, 0u, 0x80000000u | (a.tag_in & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff));   // the first timeout stays
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
@@ -1156,8 +1162,12 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
             }
         } else {  // EPI_QKV with the cache position already in a register
             const int which = en / a.d_model, c = en - which * a.d_model;
+            if (EPI == EPI_QKV && a.ll_out && a.cl0) {         // pipelined decode: publish through the (value, tag) block
+                const uint32_t ptag = ((uint32_t)(a.cl0[0] + 1) * 64u + a.tag_out) * 8u + 5u;
+                ll_store4(a.ll_out + 2 * (((int64_t)which * a.ll_rows + row0 + em) * a.d_model + c), sacc, ptag);
+            }
             if (which == 0) {
-                STX(a.out + (int64_t)em * a.ldo + c, sacc);
+                if (!(EPI == EPI_QKV && a.ll_out && a.cl0)) STX(a.out + (int64_t)em * a.ldo + c, sacc);
             } else {
                 const int head = c / VH_HEAD_DIM, e = c - head * VH_HEAD_DIM;
                 const int b = em / a.T, t = em - b * a.T;
@@ -1208,6 +1218,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
     a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
     skinny_body<MT, NW, EPI, PW, LN, NJ, X64, 0>(a, ln, VB{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
                                                                 (int)gridDim.y, (int)gridDim.z});
+}
+
+// Pipelined decode: the out-projection whose A rows — the attention output — arrive as (value, tag) pairs from a
+// vh_attn_decode_pipe launch that runs on ANOTHER stream: this launch requests its weights, then waits (bounded) for
+// the pairs.  a.tag_in carries the layer on entry; the step comes from cache_len[0] (stable on this stream).
+template <int NW, int PW>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_ll_in(const float* hW, int hK, int hM, int hN, const int32_t* cl0,
+                                                             GemmArgs a, LnFuse ln) {
+    a.W = hW; a.K = hK; a.k_len = hK; a.M = hM; a.N = hN;
+    a.tag_in = ((uint32_t)(cl0[0] + 1) * 64u + a.tag_in) * 8u + 6u;
+    skinny_body<1, NW, EPI_PLAIN, PW, 0, 1, 0, 1>(a, ln, VB{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
+                                                            (int)gridDim.y, (int)gridDim.z});
 }
 
 // =============================================================================================
@@ -1597,6 +1619,47 @@ extern "C" int vh_linear_qkv_folded(const void* A, int a_form, int lda, const fl
     if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
     a.s2 = a_slab_stride;
     return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream, a_form == 1 ? 1 : (a_form == 2 ? 4 : 0));
+}
+
+// pipelined decode: the folded QKV launch that also publishes q and the newest K / V row as (value, tag) pairs
+extern "C" int vh_linear_qkv_folded_pipe(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                                         float* kcache, float* vcache, const int32_t* cache_len, int B, int d_model,
+                                         int n_heads, int S_max, float ln_eps, float* qkv_ll, int layer, void* stream) {
+    VH_REQUIRE(kcache && vcache && cache_len && qkv_ll, VH_EINVAL, "vh_linear_qkv_folded_pipe: null pointer");
+    VH_REQUIRE(B > 0 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM && layer >= 0 && layer < 64, VH_EUNSUPPORTED,
+               "vh_linear_qkv_folded_pipe: d_model=%d n_heads=%d layer=%d", d_model, n_heads, layer);
+    VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(qkv_ll), VH_EALIGN,
+               "vh_linear_qkv_folded_pipe: alignment");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = Wf; a.out = qkv_ll; a.ldo = d_model;       // a.out unused for q in this form
+    a.M = B; a.N = 3 * d_model; a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE;
+    a.kc = kcache; a.vc = vcache; a.cache_len = cache_len; a.T = 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
+    a.ll_out = qkv_ll; a.cl0 = cache_len; a.ll_rows = B; a.tag_out = (uint32_t)layer;
+    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
+    if (int rc = check_gemm("vh_linear_qkv_folded_pipe", a, ln)) return rc;
+    if (int rc = check_folded("vh_linear_qkv_folded_pipe", a, ln)) return rc;
+    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded_pipe", a, ln, (hipStream_t)stream, 0);
+}
+
+extern "C" int vh_linear_ll_in(const float* a_ll, const float* W, const float* bias, const float* residual, int ldr,
+                               float* out, int ldo, int M, int N, int K, const int32_t* cache_len, int layer,
+                               uint32_t* err, void* stream) {
+    VH_REQUIRE(a_ll && W && out && cache_len && err, VH_EINVAL, "vh_linear_ll_in: null pointer");
+    VH_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0 && K == 512 && layer >= 0 && layer < 64, VH_EUNSUPPORTED,
+               "vh_linear_ll_in: decode path only: M <= 64, N %% 16 == 0, K == 512 (M=%d N=%d K=%d)", M, N, K);
+    GemmArgs a{};
+    a.A = a_ll; a.a_org = a_ll; a.ll_in = a_ll; a.lda = K;     // a.A is only an origin: element p lives at ll_in + 2 p
+    a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = N; a.K = K; a.k_len = K; a.act = VH_ACT_NONE;
+    a.tag_in = (uint32_t)layer; a.err_word = err;
+    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
+    if (int rc = check_gemm("vh_linear_ll_in", a, none)) return rc;
+    dim3 grid(N / 16);
+    a.rg_rows = ((int)grid.x * ((M + 7) / 8) <= 256) ? 8 : 16;
+    grid.z = (M + a.rg_rows - 1) / a.rg_rows;
+    hipLaunchKernelGGL((gemm_skinny_ll_in<8, 4>), grid, dim3(512), 0, (hipStream_t)stream, W, K, M, N, cache_len, a, none);
+    VH_CHECK_LAUNCH("vh_linear_ll_in");
+    return VH_OK;
 }
 
 // ---- fp64 accumulator form -----------------------------------------------------------------------

@@ -27,6 +27,12 @@ extern "C" int vh_set_tuning(int knob, int value) {
 extern "C" const char* vh_last_error(void) { return g_err; }
 extern "C" int vh_version(void) { return VH_VERSION; }
 
+#define HIP_TRY(call)                                                             \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        VH_REQUIRE(e_ == hipSuccess, VH_ELAUNCH, #call ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
 #define TRY(call)                \
     do {                         \
         int rc_ = (call);        \
@@ -44,7 +50,16 @@ struct vh_ar_decoder {
     hipGraph_t graph_n = nullptr;        // VH_GRAPH_STEPS consecutive steps in one graph (fewer graph launches per generate)
     hipGraphExec_t exec_n = nullptr;
     int ldl = 0;
+    // pipelined attention (d.qkv_ll): the attention launches live on their own stream, in their own graphs; the two
+    // streams hand data to each other through (value, tag) pairs only — no event between them inside a run of steps
+    hipStream_t side = nullptr;          // created on first use, at a priority OTHER than the caller's stream's
+    int side_prio = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipGraph_t side_graph = nullptr, side_graph_n = nullptr;
+    hipGraphExec_t side_exec = nullptr, side_exec_n = nullptr;
 };
+
+enum { PART_ALL = 0, PART_MAIN = 1, PART_SIDE = 2 };   // which launches of a pipelined step decoder_enqueue issues
 
 static int decoder_check(const vh_ar_decoder_desc* d) {
     VH_REQUIRE(d, VH_EINVAL, "vh_ar_decoder: null desc");
@@ -71,8 +86,16 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                d->dff, d->d_model);
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
+    if (d->qkv_ll) {
+        VH_REQUIRE(d->pipe_err && d->attn_ll && d->n_layers >= 2 && d->n_layers <= 64 && d->d_model == 512, VH_EINVAL,
+                   "vh_ar_decoder: qkv_ll needs attn_ll, pipe_err, 2 <= n_layers <= 64 and d_model == 512");
+        for (int i = 0; i < d->n_layers; ++i)
+            VH_REQUIRE(d->layers[i].wqkv_f, VH_EINVAL, "vh_ar_decoder: pipelined attention needs folded weights (layer %d)", i);
+    }
     return VH_OK;
 }
+
+extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec);
 
 extern "C" vh_ar_decoder* vh_ar_decoder_create(const vh_ar_decoder_desc* desc) {
     if (decoder_check(desc) != VH_OK) return nullptr;
@@ -81,6 +104,15 @@ extern "C" vh_ar_decoder* vh_ar_decoder_create(const vh_ar_decoder_desc* desc) {
     dec->layers.assign(desc->layers, desc->layers + desc->n_layers);
     dec->d.layers = dec->layers.data();
     dec->ldl = (desc->V + 3) & ~3;
+    if (dec->d.x64 || dec->d.xs || dec->d.chain_ws) dec->d.qkv_ll = nullptr;
+    if (dec->d.qkv_ll) {
+        if (hipEventCreateWithFlags(&dec->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&dec->ev_join, hipEventDisableTiming) != hipSuccess) {
+            vh_set_error("vh_ar_decoder: could not create the attention stream");
+            vh_ar_decoder_destroy(dec);
+            return nullptr;
+        }
+    }
     return dec;
 }
 
@@ -90,6 +122,13 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
     if (dec->graph) (void)hipGraphDestroy(dec->graph);
     if (dec->exec_n) (void)hipGraphExecDestroy(dec->exec_n);
     if (dec->graph_n) (void)hipGraphDestroy(dec->graph_n);
+    if (dec->side_exec) (void)hipGraphExecDestroy(dec->side_exec);
+    if (dec->side_graph) (void)hipGraphDestroy(dec->side_graph);
+    if (dec->side_exec_n) (void)hipGraphExecDestroy(dec->side_exec_n);
+    if (dec->side_graph_n) (void)hipGraphDestroy(dec->side_graph_n);
+    if (dec->ev_fork) (void)hipEventDestroy(dec->ev_fork);
+    if (dec->ev_join) (void)hipEventDestroy(dec->ev_join);
+    if (dec->side) (void)hipStreamDestroy(dec->side);
     delete dec;
 }
 
@@ -98,9 +137,10 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
 void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop);   // attention.hip
 
 static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEvent_t>* ev,
-                           std::vector<hipEvent_t>* kev = nullptr) {
+                           std::vector<hipEvent_t>* kev = nullptr, int part = PART_ALL) {
     const vh_ar_decoder_desc& d = dec->d;
     const int B = d.B, D = d.d_model;
+    const bool pipe = d.qkv_ll && !ev;           // the attention profile times the stand-alone kernel
     // decode attention of one layer, optionally bracketed by events (vh_ar_decoder_profile_attn)
     auto run_attention = [&](const vh_layer& L) -> int {
         if (!ev)
@@ -147,7 +187,25 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         }
         const bool x2 = d.xs && !d.x64;              // residual stream between layers in the two-slab form
         const int64_t ss = (int64_t)B * D;           // slab stride
-        if (d.x64)
+        if (pipe) {
+            // QKV publishes q and the newest K / V row as (value, tag) pairs; the attention launch — normally on the
+            // decoder's second stream (PART_SIDE), where it started as soon as the previous layer's attention ended
+            // and has requested its first keys since — takes them from there and publishes its output the same way
+            // for the out-projection, which is launched right behind the QKV and waits for it with its weights loaded.
+            if (part != PART_SIDE)
+                TRY(vh_linear_qkv_folded_pipe(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, L.kcache, L.vcache, d.cache_len, B, D,
+                                              d.n_heads, d.S_max, d.ln_eps, d.qkv_ll, i, s));
+            if (part != PART_MAIN)
+                TRY(vh_attn_decode_pipe(d.qkv_ll, L.kcache, L.vcache, d.attn_ll, d.cache_len, B, d.n_heads, d.S_max, i,
+                                        d.pipe_err, s));
+            if (part == PART_SIDE) continue;
+            TRY(vh_linear_ll_in(d.attn_ll, L.wo, L.bo, d.x, D, d.x, D, B, D, D, d.cache_len, i, d.pipe_err, s));
+            TRY(vh_linear_folded(d.x, D, L.w1_f, L.w1_c1, L.w1_c2, nullptr, 0, d.hidden, d.dff, B, d.dff, D,
+                                 VH_ACT_GELU_ERF, d.ln_eps, s));
+            TRY(vh_linear_ws(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, d.gemm_ws,
+                             d.gemm_ws_bytes, s));
+            continue;
+        } else if (d.x64)
             TRY(vh_linear_qkv_folded(d.x64, 1, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
                                      d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, 0, s));
         else if (x2 && i > 0)                        // layer 0 reads the token embedding (one tensor)
@@ -196,6 +254,7 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         TRY(vh_linear_ws(d.hidden, d.dff, L.w2, L.b2, d.x, D, d.x, D, B, D, d.dff, VH_ACT_NONE, d.gemm_ws,
                          d.gemm_ws_bytes, s));
     }
+    if (part == PART_SIDE) return VH_OK;
     // head (no bias, no final norm: valle_ar.py:29,158) then greedy sampling + state update
     if (d.chain_ws) {
         // the last layer's chain launch produced the logits
@@ -217,20 +276,62 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     return VH_OK;
 }
 
+static bool two_streams(const vh_ar_decoder* dec) { return dec->d.qkv_ll && vh_tuning(VH_TUNE_PIPE_MODE) != 1; }
+
+// The attention stream joins / leaves the caller's stream around a run of steps (never inside one).
+// The two streams wait for each other's DATA, so they must sit on different hardware queues: the runtime multiplexes
+// streams of one priority onto a few queues (in order within a queue: a launch waiting for data from a launch behind
+// it would never end), but keeps separate queues per priority level — so the attention stream gets a priority the
+// caller's stream does not have.
+static int pipe_side_stream(vh_ar_decoder* dec, hipStream_t s) {
+    int prio = 0, least = 0, greatest = 0;
+    HIP_TRY(hipStreamGetPriority(s, &prio));
+    if (dec->side) {
+        VH_REQUIRE(prio != dec->side_prio, VH_ESTATE,
+                   "vh_ar_decoder: the caller's stream changed to priority %d, the attention stream's own", prio);
+        return VH_OK;
+    }
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    VH_REQUIRE(least != greatest, VH_EUNSUPPORTED, "vh_ar_decoder: pipelined attention needs stream priorities");
+    // the LOWER priority where there is a choice ("least"): the attention workgroups that wait for a CU must never
+    // hold up the dispatch of the QKV launch the resident ones are waiting for
+    dec->side_prio = prio == least ? greatest : least;
+    HIP_TRY(hipStreamCreateWithPriority(&dec->side, hipStreamNonBlocking, dec->side_prio));
+    return VH_OK;
+}
+
+static int pipe_fork(vh_ar_decoder* dec, hipStream_t s) {
+    TRY(pipe_side_stream(dec, s));
+    HIP_TRY(hipEventRecord(dec->ev_fork, s));
+    HIP_TRY(hipStreamWaitEvent(dec->side, dec->ev_fork, 0));
+    return VH_OK;
+}
+static int pipe_join(vh_ar_decoder* dec, hipStream_t s) {
+    HIP_TRY(hipEventRecord(dec->ev_join, dec->side));
+    HIP_TRY(hipStreamWaitEvent(s, dec->ev_join, 0));
+    return VH_OK;
+}
+
 extern "C" int vh_ar_decoder_step(vh_ar_decoder* dec, void* stream) {
     VH_REQUIRE(dec, VH_EINVAL, "vh_ar_decoder_step: null decoder");
-    return decoder_enqueue(dec, (hipStream_t)stream, nullptr);
+    hipStream_t s = (hipStream_t)stream;
+    if (!two_streams(dec)) return decoder_enqueue(dec, s, nullptr);
+    TRY(pipe_fork(dec, s));
+    TRY(decoder_enqueue(dec, dec->side, nullptr, nullptr, PART_SIDE));
+    TRY(decoder_enqueue(dec, s, nullptr, nullptr, PART_MAIN));
+    return pipe_join(dec, s);
 }
 
 #define VH_GRAPH_STEPS 8
 
-static int capture_steps(vh_ar_decoder* dec, hipStream_t s, int n_steps, hipGraph_t* graph, hipGraphExec_t* exec) {
+static int capture_steps(vh_ar_decoder* dec, hipStream_t s, int n_steps, hipGraph_t* graph, hipGraphExec_t* exec,
+                         int part = PART_ALL) {
     if (*exec) { (void)hipGraphExecDestroy(*exec); *exec = nullptr; }
     if (*graph) { (void)hipGraphDestroy(*graph); *graph = nullptr; }
     hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
     VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipStreamBeginCapture: %s", hipGetErrorString(e));
     int rc = VH_OK;
-    for (int i = 0; i < n_steps && rc == VH_OK; ++i) rc = decoder_enqueue(dec, s, nullptr);
+    for (int i = 0; i < n_steps && rc == VH_OK; ++i) rc = decoder_enqueue(dec, s, nullptr, nullptr, part);
     e = hipStreamEndCapture(s, graph);
     if (rc != VH_OK) return rc;
     VH_REQUIRE(e == hipSuccess && *graph, VH_ELAUNCH, "hipStreamEndCapture: %s", hipGetErrorString(e));
@@ -245,24 +346,39 @@ extern "C" int vh_ar_decoder_capture(vh_ar_decoder* dec, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // the step advances device-side state only, so N captured steps are the same step N times: one graph of a
     // single step (remainders) and one of VH_GRAPH_STEPS steps (the bulk: an eighth of the graph launches)
-    TRY(capture_steps(dec, s, 1, &dec->graph, &dec->exec));
-    if (vh_tuning(VH_TUNE_GRAPH_STEPS) != 1) TRY(capture_steps(dec, s, VH_GRAPH_STEPS, &dec->graph_n, &dec->exec_n));
+    const bool two = two_streams(dec);
+    const bool many = vh_tuning(VH_TUNE_GRAPH_STEPS) != 1;
+    TRY(capture_steps(dec, s, 1, &dec->graph, &dec->exec, two ? PART_MAIN : PART_ALL));
+    if (many) TRY(capture_steps(dec, s, VH_GRAPH_STEPS, &dec->graph_n, &dec->exec_n, two ? PART_MAIN : PART_ALL));
+    if (!two) {
+        if (dec->side_exec) { (void)hipGraphExecDestroy(dec->side_exec); dec->side_exec = nullptr; }
+        if (dec->side_exec_n) { (void)hipGraphExecDestroy(dec->side_exec_n); dec->side_exec_n = nullptr; }
+    }
+    if (two) TRY(pipe_side_stream(dec, s));
+    if (two) {                       // the attention launches of a step: a second graph, replayed on the second stream
+        TRY(capture_steps(dec, dec->side, 1, &dec->side_graph, &dec->side_exec, PART_SIDE));
+        if (many) TRY(capture_steps(dec, dec->side, VH_GRAPH_STEPS, &dec->side_graph_n, &dec->side_exec_n, PART_SIDE));
+    }
     return VH_OK;
 }
 
 extern "C" int vh_ar_decoder_replay(vh_ar_decoder* dec, int n_steps, void* stream) {
     VH_REQUIRE(dec && dec->exec, VH_ESTATE, "vh_ar_decoder_replay: capture first");
     VH_REQUIRE(n_steps >= 0, VH_EINVAL, "vh_ar_decoder_replay: n_steps=%d", n_steps);
+    hipStream_t s = (hipStream_t)stream;
+    const bool two = dec->side_exec != nullptr;
+    if (two && n_steps > 0) TRY(pipe_fork(dec, s));
     int i = 0;
     if (dec->exec_n)
         for (; i + VH_GRAPH_STEPS <= n_steps; i += VH_GRAPH_STEPS) {
-            hipError_t e = hipGraphLaunch(dec->exec_n, (hipStream_t)stream);
-            VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+            if (two) HIP_TRY(hipGraphLaunch(dec->side_exec_n, dec->side));
+            HIP_TRY(hipGraphLaunch(dec->exec_n, s));
         }
     for (; i < n_steps; ++i) {
-        hipError_t e = hipGraphLaunch(dec->exec, (hipStream_t)stream);
-        VH_REQUIRE(e == hipSuccess, VH_ELAUNCH, "hipGraphLaunch: %s", hipGetErrorString(e));
+        if (two) HIP_TRY(hipGraphLaunch(dec->side_exec, dec->side));
+        HIP_TRY(hipGraphLaunch(dec->exec, s));
     }
+    if (two && n_steps > 0) TRY(pipe_join(dec, s));
     return VH_OK;
 }
 

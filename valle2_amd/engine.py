@@ -58,6 +58,11 @@ PERSISTENT_CHAIN = os.environ.get('VALLE2_CHAIN', '0') == '1'   # the GEMM chain
                                                                  # 700 vs 617 us per step; bit-identical
                                                                  # results, kept as an option; needs the folded weights,
                                                                  # d_model = 512, dff % 256 == 0, dff <= 4096
+PIPELINED_ATTENTION = os.environ.get('VALLE2_PIPE', '0') == '1'  # decode attention on its own stream, launched a layer
+                                                                 # early: it requests its first keys while the previous
+                                                                 # layer's GEMM chain runs and takes q / k / v from
+                                                                 # (value, tag) pairs (vh_attn_decode_pipe); needs the
+                                                                 # folded weights; bit-identical results
 TWO_SLAB_RESIDUAL = os.environ.get('VALLE2_X2', '0') == '1'     # residual stream between layers as two fp32 slabs
                                                                  # (linear_2's two K halves, added on load by the
                                                                  # consumers: no split-K reduce launch).  Off:
@@ -226,6 +231,11 @@ class ArDecoder:
         self.x2 = bool(TWO_SLAB_RESIDUAL and not self.acc64 and not self.chain and self._folded is not None
                        and dff % 2048 == 0 and d <= 1024 and d % 128 == 0)
         self.xs = torch.zeros(2, batch, d, **f32) if self.x2 else None
+        self.pipe = bool(PIPELINED_ATTENTION and self._folded is not None and not (self.acc64 or self.chain or self.x2)
+                         and 2 <= cfg.num_layers <= 64 and d == 512)
+        self.qkv_ll = torch.zeros(3, batch, d, 2, **f32) if self.pipe else None          # tag 0 = never valid
+        self.attn_ll = torch.zeros(batch, d, 2, **f32) if self.pipe else None
+        self.pipe_err = torch.zeros(16 + 512, device=dev, dtype=torch.int32) if self.pipe else None
         self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
@@ -240,7 +250,8 @@ class ArDecoder:
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
             sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid), xs=ptr(self.xs),
-            chain_ws=ptr(self.chain_ws), chain_ws_bytes=chain_bytes, chain_sync=ptr(self.chain_sync))
+            chain_ws=ptr(self.chain_ws), chain_ws_bytes=chain_bytes, chain_sync=ptr(self.chain_sync),
+            qkv_ll=ptr(self.qkv_ll), attn_ll=ptr(self.attn_ll), pipe_err=ptr(self.pipe_err))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:
@@ -260,6 +271,9 @@ class ArDecoder:
         if self.chain and int(self.chain_sync[1].item()) != 0:
             raise _lib.VhError('vh_decode_chain: a wait on a stage hand-over timed out (the launch needs one resident workgroup per '
                                'CU); set VALLE2_CHAIN=0 to decode with one launch per stage')
+        if self.pipe and int(self.pipe_err[0].item()) != 0:
+            raise _lib.VhError(f'vh_attn_decode_pipe: the wait for a query timed out (word {int(self.pipe_err[0].item()) & 0xffffffff:#x}); '
+                               'set VALLE2_PIPE=0 to decode with attention in stream order')
 
     def close(self):
         if getattr(self, '_h', None):

@@ -271,7 +271,7 @@ class ValleAR(_Base):
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             dec.check_chain()
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'two_slab': dec.x2, 'chain': dec.chain,
+                                        'two_slab': dec.x2, 'chain': dec.chain, 'pipe': dec.pipe,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
