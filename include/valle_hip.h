@@ -370,7 +370,7 @@ typedef struct {
      * stream and a second set of graphs: the attention launches of a run of steps go there, back to back, so layer
      * l+1's attention starts (and requests its first keys) as soon as layer l's has finished; the two streams meet
      * only at the ends of vh_ar_decoder_step / _replay, in between they hand data over through the pairs.  Needs folded
-     * weights, d_model == 512, 2 <= n_layers <= 64; ignored with x64 / xs / chain_ws. */
+     * weights, d_model == 512, 2 <= n_layers <= 64, S_max % 32 == 0; ignored with x64 / xs / chain_ws. */
     float *qkv_ll;
     float *attn_ll;                   /* (B, d_model) pairs = 2*B*d_model floats, zeroed likewise: the attention output */
     uint32_t *pipe_err;

@@ -562,6 +562,75 @@ def test_attn_decode_ring_kernels_short_and_ragged_rows(K, variant, S_max):
     close(out, ref, atol=3e-5)
 
 
+@pytest.mark.parametrize('S_max', [64, 320, 1120])
+def test_pipelined_decode_kernels_in_stream_order(K, S_max):
+    """vh_linear_qkv_folded_pipe -> vh_attn_decode_pipe -> vh_linear_ll_in on ONE stream (every wait finds its pairs
+    already there) against vh_linear_qkv_folded -> vh_attn_decode (8-wave ring) -> vh_linear: q and the K / V rows bit for
+    bit, the attention output and the out-projection to rounding (the same chunk order per wave, but the compiler
+    contracts the two kernels' multiply-adds differently: atol 2e-6 / 1e-5); ragged lengths at
+    chunk edges with NaN / Inf beyond every row's length; a stale tag (wrong layer) times out into the error word."""
+    from valle2_amd import _lib
+    lib = _lib.lib()
+    B, h, d = 32, 8, 512
+    gen = g(90 + S_max)
+    x = torch.randn(B, d, generator=gen).to(DEV)
+    wqkv = (0.05 * torch.randn(3 * d, d, generator=gen)).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV)
+    wo, bo = (0.05 * torch.randn(d, d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV)
+    folded = K.ln_fold(wqkv, gamma, beta)
+    edges = [1, 2, 5, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1087]
+    lens = torch.tensor([min(S_max, edges[i % len(edges)] + (i // len(edges))) for i in range(B)], dtype=torch.int32)
+    lens[0] = min(S_max, 300)                                  # cache_len[0] carries the step of the tags
+    kc = torch.randn(B, h, S_max, 64, generator=gen)
+    vc = torch.randn(B, h, S_max, 64, generator=gen)
+    for b in range(B):
+        kc[b, :, int(lens[b]) - 1:] = float('nan')             # the newest row (len - 1) comes from the QKV launch
+        vc[b, :, int(lens[b]) - 1:] = float('inf')
+    cl = (lens - 1).to(DEV)
+    s = K.stream()
+    # reference chain: plain kernels
+    kc0, vc0 = kc.to(DEV), vc.to(DEV)
+    q0 = torch.empty(B, d, device=DEV)
+    K.linear_qkv_folded(x, folded, q0, kc0, vc0, B, 1, h, cache_len=cl)
+    a0 = torch.empty(B, d, device=DEV)
+    lib.vh_set_tuning(0, 7)
+    try:
+        K.attn_decode(q0, kc0, vc0, a0, cl, 1, 1, None)
+    finally:
+        lib.vh_set_tuning(0, 0)
+    y0 = K.linear(a0, wo, bias=bo, residual=x)
+    # pipelined kernels, in stream order
+    kc1, vc1 = kc.to(DEV), vc.to(DEV)
+    qkv_ll = torch.zeros(3, B, d, 2, device=DEV)
+    attn_ll = torch.zeros(B, d, 2, device=DEV)
+    err = torch.zeros(16 + 512, device=DEV, dtype=torch.int32)
+    y1 = torch.full((B, d), float('nan'), device=DEV)
+    layer = 3
+    K.check(lib.vh_linear_qkv_folded_pipe(x.data_ptr(), d, folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(),
+                                          kc1.data_ptr(), vc1.data_ptr(), cl.data_ptr(), B, d, h, S_max, 1e-5,
+                                          qkv_ll.data_ptr(), layer, s), 'vh_linear_qkv_folded_pipe')
+    K.check(lib.vh_attn_decode_pipe(qkv_ll.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), attn_ll.data_ptr(), cl.data_ptr(),
+                                    B, h, S_max, layer, err.data_ptr(), s), 'vh_attn_decode_pipe')
+    K.check(lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
+                                B, d, d, cl.data_ptr(), layer, err.data_ptr(), s), 'vh_linear_ll_in')
+    torch.cuda.synchronize()
+    assert int(err[0]) == 0
+    bits = lambda t: t.view(torch.int32)                       # NaN-proof equality
+    assert torch.equal(bits(kc1), bits(kc0)) and torch.equal(bits(vc1), bits(vc0)), 'K / V rows of the new position'
+    assert torch.equal(qkv_ll[0, :, :, 0], q0), 'published q'
+    tag = ((int(cl[0]) + 1) * 64 + layer) * 8 + 5
+    assert bool((qkv_ll[..., 1].view(torch.int32) == tag).all())
+    assert bool(torch.isfinite(attn_ll[..., 0]).all()), 'garbage beyond a row\'s length leaked into the attention output'
+    close(attn_ll[..., 0], a0.cpu(), atol=2e-6, rtol=0)
+    assert bool((attn_ll[..., 1].view(torch.int32) == tag + 1).all())
+    close(y1, y0.cpu(), atol=1e-5, rtol=0)
+    # a consumer whose pairs never come (tags of another layer) gives up: error word set, no hang
+    K.check(lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
+                                B, d, d, cl.data_ptr(), layer + 1, err.data_ptr(), s), 'vh_linear_ll_in')
+    torch.cuda.synchronize()
+    assert (int(err[0]) & 0xffffffff) >> 28 == 0x8
+
+
 def test_linear_qkv_scatter(K):
     B, T, h = 3, 5, 2
     d = 64 * h

@@ -287,10 +287,10 @@ def test_persistent_chain_is_bit_identical_to_one_launch_per_stage():
 
 
 @pytest.mark.parametrize('rows', [5, 40])
-def test_pipelined_attention_is_bit_identical(rows):
+def test_pipelined_attention_same_tokens(rows):
     """VALLE2_PIPE: the attention launches run on the decoder's second stream, a layer early, and take q / k / v from
-    (value, tag) pairs (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe).  Same arithmetic in the same order as the
-    8-wave ring kernel's 32-key chunks: tokens must equal the stream-ordered decoder's bit for bit, graph and eager,
+    (value, tag) pairs (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe + vh_linear_ll_in).  Same chunk order per wave as
+    the 8-wave ring kernel: the generated tokens must equal the stream-ordered decoder's, graph and eager,
     ragged rows, and with more (row, head) workgroups than CUs (40 rows x 8 heads = 320)."""
     from valle2_amd import engine, synth
     kw = dict(C.MID, norm='LayerNorm', num_beams=rows, top_k=1, max_audio_len=40)
@@ -302,19 +302,22 @@ def test_pipelined_attention_is_bit_identical(rows):
     pl = [(50, 61, 20, 50, 33)[i % 5] + i // 5 for i in range(rows)]
     texts = [torch.randint(0, 256, (n,), generator=g).to(DEV) for n in tl]
     firsts = [torch.randint(0, 1024, (n,), generator=g).to(DEV) for n in pl]
+    from valle2_amd import _lib
     old = engine.PIPELINED_ATTENTION
     outs = {}
     try:
-        for pipe in (False, True):
+        for pipe, mode in ((False, 0), (True, 0), (True, 1)):       # mode 1: the same kernels on ONE stream
             engine.PIPELINED_ATTENTION = pipe
+            _lib.lib().vh_set_tuning(7, mode)
             for graph in (True, False):
-                outs[(pipe, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
+                outs[(pipe, mode, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
                 assert m.last_generate_stats['pipe'] == pipe
     finally:
         engine.PIPELINED_ATTENTION = old
-    ref = outs[(False, True)]
+        _lib.lib().vh_set_tuning(7, 0)
+    ref = outs[(False, 0, True)]
     for k, v in outs.items():
-        assert torch.equal(v, ref), f'pipe={k[0]} graph={k[1]} differs from the stream-ordered graph decoder'
+        assert torch.equal(v, ref), f'pipe={k[0]} mode={k[1]} graph={k[2]} differs from the stream-ordered graph decoder'
 
 
 def test_generate_batch_distinct_rows_vs_oracle():

@@ -15,6 +15,7 @@
 //                       workspace.   HBM-bound (algorithmic bytes = 2·len·64·4 per (b,head)).
 #include <hip/hip_ext.h>
 #include "vh_common.h"
+#include <type_traits>
 
 #define HD VH_HEAD_DIM
 #define LOG2E 1.44269504088896340736f
@@ -367,7 +368,7 @@ void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop) { g_attn_
 // not read: it may not be visible yet).  No kernel boundary between the QKV launch and this kernel, and 40 % of a
 // 1280-key stream is already in registers when q arrives.  Every wait is bounded (err word, garbage out, no hang).
 #define PIPE_SPIN_LIMIT 200000
-#define PIPE_LDS_RESERVE (84 * 1024)
+#define PIPE_LDS_BYTES (8 * 16 * 1024)     // the LDS key / value set: 16 KB per wave
 struct LLQ { uint64_t p[4]; };
 __device__ __forceinline__ LLQ pipe_ld(const float* ll) {
     const uint64_t* q = reinterpret_cast<const uint64_t*>(ll);
@@ -385,41 +386,62 @@ __device__ __forceinline__ f32x4 pipe_val(const LLQ& r) {
                  __uint_as_float((uint32_t)r.p[3])};
 }
 
-template <int NW, int D>
+template <int NW, int D>      // D = 1 (one register set + the LDS set)
 __global__ __launch_bounds__(NW * 64, 4) void attn_decode_pipe_ring_kernel(
     const float* __restrict__ qkv_ll, int B, const float* __restrict__ kc, const float* __restrict__ vc,
     float* __restrict__ out_ll, const int32_t* cache_len, int n_heads, int S_max, int layer, uint32_t* __restrict__ err) {
     constexpr int LPS = 8;
     __shared__ float s_m[NW], s_l[NW];
     __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
-    // One workgroup per CU — by a dynamic LDS request at launch (PIPE_LDS_RESERVE) — and at most 128 VGPRs: the
-    // waiting workgroups must leave registers and wave slots for the GEMM chain they wait for.
+    // One workgroup per CU (the 128 KB LDS set, PIPE_LDS_BYTES, sees to that) and at most 128 VGPRs: the waiting
+    // workgroups must leave registers, wave slots and 29 KB of LDS for the GEMM chain they wait for.
     __shared__ __attribute__((aligned(16))) float s_in[3][HD];       // q, newest k, newest v of this (b, head)
     __shared__ int s_len;
     __shared__ uint32_t s_tag;
     const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, in an SGPR
     const int c16 = lane & 15, g = lane >> 4;
     const int d_model = n_heads * HD;
     const float* kb = kc + (int64_t)bh * S_max * HD + 4 * c16;
     const float* vb = vc + (int64_t)bh * S_max * HD + 4 * c16;
     f32x4 kf[D][LPS], vf[D][LPS];
-    int key_limit = S_max - 1;
+    // S_max % 32 == 0 (host check): a chunk of 32 keys never crosses the end of a (b, head) cache block, so the 16
+    // rows a lane reads are its chunk base + constant offsets; chunks requested before the length is known are
+    // clamped to the last one of the block (wave-uniform) and never reduced.
+    const int c_last = S_max / 32 - 1;
     auto load = [&](int c, f32x4 (&kq)[LPS], f32x4 (&vq)[LPS]) {
-        const int key0 = c * 32 + g;
+        const int64_t r0 = (int64_t)(min(c, c_last) * 32 + g) * HD;
 #pragma unroll
         for (int i = 0; i < LPS; ++i) {
-            const int key = min(key0 + 4 * i, key_limit);
-            kq[i] = ld4_stream(kb + (int64_t)key * HD);
-            vq[i] = ld4_stream(vb + (int64_t)key * HD);
+            kq[i] = ld4_stream(kb + r0 + 4 * i * HD);
+            vq[i] = ld4_stream(vb + r0 + 4 * i * HD);
+        }
+    };
+    // A second set of 32 keys per wave lives in LDS (16 KB per wave, written by LDS-DMA: no registers): slot
+    // [i][lane] holds what register kq[i] / vq[i] of that lane would hold, so the reduction reads its own 16 bytes.
+    extern __shared__ __attribute__((aligned(16))) float pipe_dyn[];
+    float* const my_k = pipe_dyn + w * 4096;
+    float* const my_v = my_k + 2048;
+    typedef __attribute__((address_space(3))) void* lds_vp;
+    typedef const __attribute__((address_space(1))) void* glb_vp;
+    auto dma = [&](int c) {
+        const int64_t r0 = (int64_t)(min(c, c_last) * 32 + g) * HD;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)(kb + r0 + 4 * i * HD), (lds_vp)(my_k + i * 256), 16, 0, 2);   // aux 2 = nt
+            __builtin_amdgcn_global_load_lds((glb_vp)(vb + r0 + 4 * i * HD), (lds_vp)(my_v + i * 256), 16, 0, 2);
         }
     };
     // diagnostics (err[1] != 0): workgroup 0 leaves wall-clock stamps (start, inputs arrived, end) per layer
     const bool stamps = err[1] != 0 && bh == 0 && tid == 0;
     unsigned long long* st = reinterpret_cast<unsigned long long*>(err) + 8 + layer * 4;
     if (stamps) st[0] = wall_clock64();
+    // Before anything of this step is known: 64 keys per wave, 256 KB per workgroup.  (Pacing these requests — they
+    // are a 64 MB burst chip-wide, beside the latency-bound GEMM launches — changed nothing: 577-583 us per step
+    // for gaps of 0 to 1280 cycles between row pairs, profiles/r2_ab_decode_pipe.log.)
 #pragma unroll
-    for (int j = 0; j < D; ++j) load(w + j * NW, kf[j], vf[j]);      // before anything of this step is known
+    for (int j = 0; j < D; ++j) load(w + j * NW, kf[j], vf[j]);
+    dma(w + D * NW);
     // This step's inputs.  Lane 0 of wave 0 watches ONE pair (512 workgroups polling whole rows would flood the
     // memory system the GEMM chain is using); once it carries the tag, lanes 0-47 of that wave fetch q / k / v
     // (16 lanes x 4 floats each) until every pair does, and hand them to the other waves through LDS.  The other
@@ -459,29 +481,29 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_decode_pipe_ring_kernel(
     __syncthreads();
     if (stamps) st[1] = wall_clock64();
     const int len = s_len;                       // keys 0 .. len-1, the newest one from the pairs
-    key_limit = len - 1;
     const int c_end = (len + 31) >> 5;
     const float qscale = 0.125f * LOG2E;
     const f32x4 q4 = ld4(&s_in[0][4 * c16]) * qscale;
-    const f32x4 knew = ld4(&s_in[1][4 * c16]), vnew = ld4(&s_in[2][4 * c16]);
 
     float m = NEG_INF, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    auto reduce = [&](int c, f32x4 (&kq)[LPS], f32x4 (&vq)[LPS]) {
+    // one 32-key chunk into the running softmax; getk(i) / getv(i): this lane's 16 bytes of key row key0 + 4 i.
+    // Interior chunks (wave-uniform test) take the path without masks; the last one masks keys >= len and takes the
+    // row this step appended from the pairs (kept in LDS until then: 8 registers the interior path does not pay for).
+    auto reduce_t = [&](int c, auto getk, auto getv, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value;
         const int key0 = c * 32 + g;
-        const bool whole = c * 32 + 32 <= len - 1;                // interior chunk: no masking, no newest row
-        if (!whole) {
-#pragma unroll
-            for (int i = 0; i < LPS; ++i)
-                if (key0 + 4 * i == len - 1) { kq[i] = knew; vq[i] = vnew; }    // the row this step appended
-        }
+        f32x4 knew = {0.f, 0.f, 0.f, 0.f}, vnew = {0.f, 0.f, 0.f, 0.f};
+        if (!WHOLE) { knew = ld4(&s_in[1][4 * c16]); vnew = ld4(&s_in[2][4 * c16]); }
         float sc[LPS];
         float cmax = NEG_INF;
 #pragma unroll
         for (int i = 0; i < LPS; ++i) {
-            const f32x4 t = kq[i] * q4;
+            f32x4 kk = getk(i);
+            if (!WHOLE && key0 + 4 * i == len - 1) kk = knew;
+            const f32x4 t = kk * q4;
             const float dd = row16_sum((t.x + t.y) + (t.z + t.w));
-            sc[i] = (whole || key0 + 4 * i < len) ? dd : NEG_INF;
+            sc[i] = (WHOLE || key0 + 4 * i < len) ? dd : NEG_INF;
             cmax = fmaxf(cmax, sc[i]);
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
@@ -494,19 +516,34 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_decode_pipe_ring_kernel(
         for (int i = 0; i < LPS; ++i) {
             const float p = vh_exp2(sc[i] - m_new);
             l += p;
-            const f32x4 vv = (whole || key0 + 4 * i < len) ? vq[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 vv = getv(i);
+            if (!WHOLE) {
+                if (key0 + 4 * i == len - 1) vv = vnew;
+                if (key0 + 4 * i >= len) vv = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
             o += vv * p;
         }
         m = m_new;
     };
-    for (int c0 = w; c0 < c_end; c0 += D * NW) {
+    auto reduce = [&](int c, auto getk, auto getv) {
+        if (c * 32 + 32 <= len - 1) reduce_t(c, getk, getv, std::true_type{});
+        else reduce_t(c, getk, getv, std::false_type{});
+    };
+    // Ring of D register sets + the LDS set, NW chunks apart: while one is reduced the others are in flight.
+    constexpr int RING = (D + 1) * NW;
+    for (int c0 = w; c0 < c_end; c0 += RING) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
             const int c = c0 + j * NW;
             if (c < c_end) {
-                reduce(c, kf[j], vf[j]);
-                if (c + D * NW < c_end) load(c + D * NW, kf[j], vf[j]);      // refill the set just consumed
+                reduce(c, [&](int i) { return kf[j][i]; }, [&](int i) { return vf[j][i]; });
+                if (c + RING < c_end) load(c + RING, kf[j], vf[j]);          // refill the set just consumed
             }
+        }
+        const int c = c0 + D * NW;
+        if (c < c_end) {
+            reduce(c, [&](int i) { return ld4(my_k + i * 256 + lane * 4); }, [&](int i) { return ld4(my_v + i * 256 + lane * 4); });
+            if (c + RING < c_end) dma(c + RING);
         }
     }
 #pragma unroll
@@ -541,11 +578,11 @@ extern "C" int vh_attn_decode_pipe(const float* qkv_ll, const float* kcache, con
                                    const int32_t* cache_len, int B, int n_heads, int S_max, int layer, uint32_t* err,
                                    void* stream) {
     VH_REQUIRE(qkv_ll && kcache && vcache && out_ll && cache_len && err, VH_EINVAL, "vh_attn_decode_pipe: null pointer");
-    VH_REQUIRE(B > 0 && n_heads > 0 && S_max > 0 && layer >= 0 && layer < 64, VH_EINVAL,
-               "vh_attn_decode_pipe: bad dims B=%d h=%d S_max=%d layer=%d", B, n_heads, S_max, layer);
+    VH_REQUIRE(B > 0 && n_heads > 0 && S_max > 0 && S_max % 32 == 0 && layer >= 0 && layer < 64, VH_EINVAL,
+               "vh_attn_decode_pipe: bad dims B=%d h=%d S_max=%d (a multiple of 32) layer=%d", B, n_heads, S_max, layer);
     VH_REQUIRE(vh_aligned16(qkv_ll) && vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(out_ll), VH_EALIGN,
                "vh_attn_decode_pipe: pointers must be 16-byte aligned");
-    hipExtLaunchKernelGGL((attn_decode_pipe_ring_kernel<8, 1>), dim3(1, B * n_heads), dim3(512), PIPE_LDS_RESERVE,
+    hipExtLaunchKernelGGL((attn_decode_pipe_ring_kernel<8, 1>), dim3(1, B * n_heads), dim3(512), PIPE_LDS_BYTES,
                           (hipStream_t)stream, g_attn_ev[0], g_attn_ev[1], 0, qkv_ll, B, kcache, vcache, out_ll, cache_len,
                           n_heads, S_max, layer, err);
     VH_CHECK_LAUNCH("vh_attn_decode_pipe");

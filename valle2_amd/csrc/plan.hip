@@ -87,8 +87,9 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
     if (d->qkv_ll) {
-        VH_REQUIRE(d->pipe_err && d->attn_ll && d->n_layers >= 2 && d->n_layers <= 64 && d->d_model == 512, VH_EINVAL,
-                   "vh_ar_decoder: qkv_ll needs attn_ll, pipe_err, 2 <= n_layers <= 64 and d_model == 512");
+        VH_REQUIRE(d->pipe_err && d->attn_ll && d->n_layers >= 2 && d->n_layers <= 64 && d->d_model == 512 &&
+                       d->S_max % 32 == 0, VH_EINVAL,
+                   "vh_ar_decoder: qkv_ll needs attn_ll, pipe_err, 2 <= n_layers <= 64, d_model == 512 and S_max %% 32 == 0");
         for (int i = 0; i < d->n_layers; ++i)
             VH_REQUIRE(d->layers[i].wqkv_f, VH_EINVAL, "vh_ar_decoder: pipelined attention needs folded weights (layer %d)", i);
     }
