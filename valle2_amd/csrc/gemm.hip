@@ -111,37 +111,6 @@ __device__ __forceinline__ f32x4 ld4_agent(const float* p) {
 // (value, tag) pairs: the consumer of a stage output spins on the DATA itself — a pair is one aligned 64-bit access,
 // so a value is never seen without its tag — instead of waiting at a barrier (NCCL's "LL" protocol): one memory-side
 // hop between producer and consumer instead of the three or more of a counter barrier.
-struct LLQuad { uint64_t p[4]; };
-__device__ __forceinline__ LLQuad ll_load4(const float* ll) {
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(ll);
-    LLQuad r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.p[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return r;
-}
-// the same quad through the caches (two 16-byte loads).  Safe as a FIRST attempt inside a launch: the caches were
-// invalidated at the kernel boundary and nothing of this launch has read these lines before their producers were
-// seen done, so the lines are fetched fresh — and shared by the workgroups of an XCD, which is what makes the
-// hand-over affordable (128 workgroups read the same 16 rows: agent-scope loads fetch every 8 bytes from the
-// memory side again, 10 us per stage).  A straggler's stale element fails the tag check and is then re-read at
-// agent scope.
-__device__ __forceinline__ LLQuad ll_load4_cached(const float* ll) {
-    const f32x4 a = ld4(ll), b = ld4(ll + 4);
-    LLQuad r;
-    r.p[0] = (uint64_t)__float_as_uint(a.x) | (uint64_t)__float_as_uint(a.y) << 32;
-    r.p[1] = (uint64_t)__float_as_uint(a.z) | (uint64_t)__float_as_uint(a.w) << 32;
-    r.p[2] = (uint64_t)__float_as_uint(b.x) | (uint64_t)__float_as_uint(b.y) << 32;
-    r.p[3] = (uint64_t)__float_as_uint(b.z) | (uint64_t)__float_as_uint(b.w) << 32;
-    return r;
-}
-__device__ __forceinline__ bool ll_ready(const LLQuad& r, uint32_t tag) {
-    return (uint32_t)(r.p[0] >> 32) == tag && (uint32_t)(r.p[1] >> 32) == tag && (uint32_t)(r.p[2] >> 32) == tag &&
-           (uint32_t)(r.p[3] >> 32) == tag;
-}
-__device__ __forceinline__ f32x4 ll_value(const LLQuad& r) {
-    return f32x4{__uint_as_float((uint32_t)r.p[0]), __uint_as_float((uint32_t)r.p[1]), __uint_as_float((uint32_t)r.p[2]),
-                 __uint_as_float((uint32_t)r.p[3])};
-}
 __device__ __forceinline__ void ll_store4(float* ll, f32x4 v, uint32_t tag) {
     uint64_t* q = reinterpret_cast<uint64_t*>(ll);
     const uint64_t t = (uint64_t)tag << 32;
@@ -906,16 +875,6 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
     f32x4 xf2[(X64 & 4) ? PW : 1][MT];              // slab 1 of a two-slab operand, added before the MFMAs
-    LLQuad xraw[(COH & 1) ? PW : 1][MT], vraw[(COH & 1) ? NJ : 1];
-    bool ll_first = true;                           // first attempt through the caches, retries at agent scope
-    auto issue_x_ll = [&](int kbase) {              // COH & 1: the activation fragments as (value, tag) pairs
-#pragma unroll
-        for (int c = 0; c < PW; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                xraw[(COH & 1) ? c : 0][mt] = ll_first ? ll_load4_cached(LL_IN(xp[mt] + kbase + 16 * c))
-                                                       : ll_load4(LL_IN(xp[mt] + kbase + 16 * c));
-    };
     auto issue = [&](int kbase) {
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
@@ -941,8 +900,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
         const AT* xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            if (COH & 1) vraw[(COH & 1) ? jj : 0] = ll_first ? ll_load4_cached(LL_IN(xr + 64 * jj)) : ll_load4(LL_IN(xr + 64 * jj));
-            else v[jj] = ld4(xr + 64 * jj);
+            v[jj] = ld4(xr + 64 * jj);                    // (COH & 1: the rows arrive as pairs, read below)
         }
         if (X64 & 4) {
 #pragma unroll
@@ -992,34 +950,45 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
             }
             __syncthreads();
         }
+        // The pairs are read through the caches, as two 16-byte loads per quad whose (value, tag) words are taken apart
+        // at once.  Safe: the caches were invalidated at the kernel boundary and nothing of this launch has read these
+        // lines before the sentinel showed their producers done (and the lines are then shared by the workgroups of an
+        // XCD: agent-scope loads of rows that 128 workgroups share fetch every 8 bytes from the memory side again,
+        // 10 us per stage); a straggler — a line fetched a moment too early fails its tag — is handled by invalidating
+        // the caches and reading again.  The LayerNorm row first (its statistics go to LDS, its registers are free
+        // again), then the fragments: held as raw pairs, all at once, inside a retry loop with two kinds of load, this
+        // block made the persistent kernel need 256 VGPRs and spill 399 more (round 2's first measurements of it).
+        bool ok = true;
+        auto take = [&](const float* ll, f32x4& val) {
+            const f32x4 lo = ld4(ll), hi = ld4(ll + 4);
+            val = f32x4{lo.x, lo.z, hi.x, hi.z};
+            // (no short-circuit: four compares and three ands, not four branches)
+            ok = (int)ok & (int)(__float_as_uint(lo.y) == a.tag_in) & (int)(__float_as_uint(lo.w) == a.tag_in) &
+                 (int)(__float_as_uint(hi.y) == a.tag_in) & (int)(__float_as_uint(hi.w) == a.tag_in);
+        };
+        const int ln_row = w * 4 + g;                                   // ROUNDS == 1 (static_assert above)
+        const AT* ln_xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(ln_row, a.M - 1) * a.lda + 4 * i;
         int spins = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
+#pragma unroll 1
         for (;;) {
-            if (LN) ln_load(0);
-            issue_x_ll(0);
-            bool ok = true;
+            ok = true;
+            if (LN) {
+#pragma unroll
+                for (int jj = 0; jj < NJ; ++jj) take(LL_IN(ln_xr + 64 * jj), v[jj]);
+                ln_reduce(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int c = 0; c < PW; ++c)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) ok = ok && ll_ready(xraw[(COH & 1) ? c : 0][mt], a.tag_in);
-            if (LN) {
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) ok = ok && ll_ready(vraw[(COH & 1) ? jj : 0], a.tag_in);
-            }
-            if (__all(ok)) break;
-            ll_first = false;
+                for (int mt = 0; mt < MT; ++mt) take(LL_IN(xp[mt] + 16 * c), xf[c][mt]);
+            if (__builtin_expect(__all(ok), 1)) break;
             if (++spins > LL_SPIN_LIMIT) {              // bounded: flag the error and go on (garbage out, no hang)
                 if (lane == 0) atomicCAS(a.err_word, 0u, 0x80000000u | (a.tag_in & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff));   // the first timeout stays
                 break;
             }
             __builtin_amdgcn_s_sleep(16);
-        }
-#pragma unroll
-        for (int c = 0; c < PW; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ll_value(xraw[(COH & 1) ? c : 0][mt]);
-        if (LN) {
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) v[jj] = ll_value(vraw[(COH & 1) ? jj : 0]);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop the stale lines
         }
     } else {
         if (LN) ln_load(0);
@@ -1058,7 +1027,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
 
     float mean[MT], rstd[MT];
     if (LN) {
-        ln_reduce(0);
+        if (!(COH & 1)) ln_reduce(0);                       // (pairs: done where the rows were read)
 #pragma unroll 1
         for (int r0 = 1; r0 < ROUNDS; ++r0) {
             ln_load(r0);
@@ -2189,38 +2158,47 @@ __global__ __launch_bounds__(CHAIN_THREADS) void decode_chain_kernel(ChainArgs c
         for (int idx = wg * CHAIN_THREADS + threadIdx.x; idx < items; idx += nwg * CHAIN_THREADS) {
             const int m = idx / groups, n = (idx - m * groups) * 4;
             const int64_t e = (int64_t)m * c.d + n;
-            LLQuad part[16], xmq;
-            int spins = 0;
+            int spins = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
             {   // cheap pre-poll: one pair of the last slice's slab
                 const uint64_t* q = reinterpret_cast<const uint64_t*>(c.slab_ll + 2 * (e + (slices - 1) * stride));
                 while ((uint32_t)(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != tag0 + 3 &&
                        ++spins <= LL_SPIN_LIMIT)
                     __builtin_amdgcn_s_sleep(8);
-                spins = 0;
+                spins = spins > LL_SPIN_LIMIT ? LL_SPIN_LIMIT : 0;
             }
+            // through the caches, (value, tag) words taken apart at once; a straggler: invalidate and read again
+            f32x4 acc, xmv;
+            bool ok;
+            auto take = [&](const float* ll, f32x4& val, uint32_t tag) {
+                const f32x4 lo = ld4(ll), hi = ld4(ll + 4);
+                val = f32x4{lo.x, lo.z, hi.x, hi.z};
+                ok = (int)ok & (int)(__float_as_uint(lo.y) == tag) & (int)(__float_as_uint(lo.w) == tag) &
+                     (int)(__float_as_uint(hi.y) == tag) & (int)(__float_as_uint(hi.w) == tag);
+            };
+#pragma unroll 1
             for (;;) {
-                bool ok = true;
+                ok = true;
+                take(c.slab_ll + 2 * e, acc, tag0 + 3);
+#pragma unroll 1
+                for (int s0 = 1; s0 < slices; s0 += 4) {  // slice order, four slices in flight
+                    f32x4 part[4];
 #pragma unroll
-                for (int s0 = 0; s0 < 16; ++s0)
-                    if (s0 < slices) {
-                        part[s0] = spins ? ll_load4(c.slab_ll + 2 * (e + s0 * stride)) : ll_load4_cached(c.slab_ll + 2 * (e + s0 * stride));
-                        ok = ok && ll_ready(part[s0], tag0 + 3);
-                    }
-                xmq = spins ? ll_load4(c.xm_ll + 2 * e) : ll_load4_cached(c.xm_ll + 2 * e);
-                ok = ok && ll_ready(xmq, tag0 + 1);
-                if (ok) break;
+                    for (int j = 0; j < 4; ++j) take(c.slab_ll + 2 * (e + min(s0 + j, slices - 1) * stride), part[j], tag0 + 3);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (s0 + j < slices) acc += part[j];
+                }
+                take(c.xm_ll + 2 * e, xmv, tag0 + 1);
+                if (__builtin_expect(ok, 1)) break;
                 if (++spins > LL_SPIN_LIMIT) {
-                    __hip_atomic_store(sync + 1, 0xC0000000u | ((tag0 + 3) & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicCAS(sync + 1, 0u, 0xC0000000u | ((tag0 + 3) & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff));
                     break;
                 }
                 __builtin_amdgcn_s_sleep(16);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
-            f32x4 acc = ll_value(part[0]);
-#pragma unroll
-            for (int s0 = 1; s0 < 16; ++s0)
-                if (s0 < slices) acc += ll_value(part[s0]);
             acc += ld4(c.b2 + n);
-            acc += ll_value(xmq);
+            acc += xmv;
             st4(c.x + e, acc);
             ll_store4(c.x_ll + 2 * e, acc, tag0 + 4);
         }
