@@ -239,7 +239,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     backend = os.environ.get('VALLE2_DIST_BACKEND', 'nccl')   # "nccl" is RCCL on ROCm; no-op at N=1
-    dp.init_distributed(backend, dev)
+    try:
+        dp.init_distributed(backend, dev)
+    except Exception as e:                                    # the headline needs no collective: time it anyway
+        log(f'rank {rank}: {backend} process group failed ({type(e).__name__}: {e}); timing over gloo, no training leg')
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        dp.init_distributed('gloo', dev)
+        args.no_train = True
+    # barrier and max-time reduction of the timed region run over a host-side gloo group (the inference path has no
+    # collective of its own); RCCL carries the training leg's gradient all-reduce
+    host_pg = dp.host_group()
 
     rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
     ar_kw = dict(AR)
@@ -265,7 +275,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=host_pg)
         torch.cuda.synchronize()
 
     log(f'rank {rank}/{world}: model ready, warmup {args.warmup}')
@@ -279,7 +289,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     assert int((out[:, frames + 1:] == cfg.eos_token).sum()) == 0, 'EOS appeared in a bench run'
-    elapsed = dp.max_over_ranks(elapsed, dev)
+    elapsed = dp.max_over_ranks(elapsed, dev, group=host_pg)
     ms_per_step = elapsed / args.steps * 1e3
     log(f'{ms_per_step:.1f} ms per generate')
     value = world * rows * new * args.steps / elapsed
@@ -428,7 +438,7 @@ def main():
     watchdog.cancel()
     emit()
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=host_pg)
         dist.destroy_process_group()
 
 

@@ -24,6 +24,10 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     shard = list(dp.shard_range(7, rank, world))
     slow = dp.max_over_ranks(1.0 + rank)
+    assert dp.host_group() is None                        # the default group is gloo already
+    side = dist.new_group(backend='gloo')                 # what bench.py times through when the default group is RCCL
+    assert dp.max_over_ranks(2.0 * rank, group=side) == 2.0 * (world - 1)
+    dist.barrier(group=side)
     g = torch.Generator().manual_seed(rank)
     grads = [torch.randn(5, 3, generator=g), torch.randn(11, generator=g), torch.randn(2, 2, 2, generator=g)]
     mine = [t.clone() for t in grads]

@@ -41,12 +41,24 @@ def shard_range(n_items: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def max_over_ranks(value: float, device='cpu') -> float:
-    """The slowest rank's time (what the benchmark reports)."""
+def host_group():
+    """A second process group over `gloo` (CPU, TCP on the rendezvous address) for the benchmark's barrier and
+    max-time reduction: the inference path has no collective, so its timing should not depend on RCCL coming up.
+    None when there is one rank or the default group is gloo already."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None
+    if dist.get_backend() == 'gloo':
+        return None
+    return dist.new_group(backend='gloo')
+
+
+def max_over_ranks(value: float, device='cpu', group=None) -> float:
+    """The slowest rank's time (what the benchmark reports).  `group`: a host_group() (the tensor then lives on
+    the CPU); default: the default group, tensor on `device`."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    t = torch.tensor([value], dtype=torch.float64, device='cpu' if group is not None else device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
