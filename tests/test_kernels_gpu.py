@@ -624,6 +624,15 @@ def test_pipelined_decode_kernels_in_stream_order(K, S_max):
     close(attn_ll[..., 0], a0.cpu(), atol=2e-6, rtol=0)
     assert bool((attn_ll[..., 1].view(torch.int32) == tag + 1).all())
     close(y1, y0.cpu(), atol=1e-5, rtol=0)
+    # argument errors come back as codes, nothing is launched: a cache block that is not whole 32-key chunks, a layer
+    # the tag has no room for, an out-projection of another width
+    assert lib.vh_attn_decode_pipe(qkv_ll.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), attn_ll.data_ptr(), cl.data_ptr(),
+                                   B, h, S_max - 1, layer, err.data_ptr(), s) != 0
+    assert lib.vh_linear_qkv_folded_pipe(x.data_ptr(), d, folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(),
+                                         kc1.data_ptr(), vc1.data_ptr(), cl.data_ptr(), B, d, h, S_max, 1e-5,
+                                         qkv_ll.data_ptr(), 64, s) != 0
+    assert lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
+                               B, d, 256, cl.data_ptr(), layer, err.data_ptr(), s) != 0
     # a consumer whose pairs never come (tags of another layer) gives up: error word set, no hang
     K.check(lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
                                 B, d, d, cl.data_ptr(), layer + 1, err.data_ptr(), s), 'vh_linear_ll_in')
