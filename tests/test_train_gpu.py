@@ -211,7 +211,8 @@ def test_flat_adamw_matches_torch_adamw_and_clip(max_norm, grad_scale):
     opt = FlatAdamW(mine, **kw)
     ropt = torch.optim.AdamW(ref, eps=1e-8, **kw)
     for p in mine:                                           # parameters live in the flat buffer, 16-B aligned
-        assert p.data_ptr() % 16 == 0 and p.grad.data_ptr() % 16 == 0
+        assert p.data_ptr() % 16 == 0 and p.grad is None     # gradients start released (set_to_none semantics)
+    assert all(opt.grad_view(sl).data_ptr() % 16 == 0 for sl in opt.slots)
     for step in range(6):
         lr = 3e-3 * (1.0 - 0.1 * step)                       # a scheduler changing the group's lr
         opt.param_groups[0]['lr'] = ropt.param_groups[0]['lr'] = lr
@@ -225,7 +226,8 @@ def test_flat_adamw_matches_torch_adamw_and_clip(max_norm, grad_scale):
         torch.testing.assert_close(norm.cpu().reshape(()), ref_norm.cpu().reshape(()), rtol=1e-5, atol=0)
         for p, r in zip(mine, ref):
             torch.testing.assert_close(p.detach().cpu(), r.detach().cpu(), rtol=2e-5, atol=2e-7)
-            assert float(p.grad.abs().sum()) == 0.0          # zero_grad=True cleared the flat gradient
+            assert p.grad is None                            # zero_grad=True: flat gradient cleared, grads released
+        assert float(opt.flat_grad.abs().sum()) == 0.0
     # bitwise reproducible: the same sequence again gives the same bits
     again = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
     opt2 = FlatAdamW(again, **kw)
@@ -252,7 +254,8 @@ def test_flat_adamw_drives_the_model_and_invalidates_folded_weights():
     assert all(p.data_ptr() >= opt.flat_param.data_ptr() for p in model.parameters())
     loss0 = model.training_step({k: v.clone() for k, v in batch.items()})
     loss0.backward()
-    assert all(s[0].grad.data_ptr() == opt.grad_view(s).data_ptr() for s in opt.slots)   # accumulated in place
+    # every first gradient of the step was written straight into its slice and adopted by autograd: no copies
+    assert all(s[0].grad.data_ptr() == opt.grad_view(s).data_ptr() for s in opt.slots)
     opt.step(max_norm=model.config.gradient_clip_val, zero_grad=True)
     sched.step()
     after = engine.folded_layer_norms(model.transformer)

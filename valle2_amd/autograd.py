@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib, kernels
+from . import _lib, kernels, optim
 from ._lib import check, ptr, stream
 
 HEAD_DIM = kernels.HEAD_DIM
@@ -51,10 +51,12 @@ def _dx(dy, w, kp, residual=None, act=kernels.ACT_NONE):
     return kernels.linear_ex(dy, wt, residual=residual, out=out, act=act, K=kp)
 
 
-def _colsum(dy, n):
-    db = torch.zeros(n, device=dy.device, dtype=torch.float32)
+def _colsum(dy, bias):
+    """Column sums of dy, accumulated into the bias' gradient buffer (its flat-gradient slice on the first gradient of a
+    step, optim.grad_out)."""
+    db = optim.grad_out(bias, zero=True)
     check(_lib.lib().vh_colsum(ptr(dy) if dy.is_contiguous() else dy.data_ptr(), dy.stride(0), ptr(db), dy.shape[0],
-                               n, stream()), 'vh_colsum')
+                               db.numel(), stream()), 'vh_colsum')
     return db
 
 
@@ -73,23 +75,23 @@ class LinearFn(torch.autograd.Function):
         kernels.linear(x, w.detach(), None if b is None else b.detach(), residual=residual, out=out)
         if n % 4:
             out = out.contiguous()        # ragged head (N = 1025): hand autograd a dense tensor
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, b)
         ctx.has_b, ctx.has_res = b is not None, residual is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, b = ctx.saved_tensors
         dyp, kp = _kpad(dy)
         dx = dw = None
         if ctx.needs_input_grad[0]:      # dX = dY . W
             dx = _dx(dyp, w, kp)
         if ctx.needs_input_grad[1]:      # dW = dY^T . X      (both operands stored with the token index as rows)
-            dw = torch.empty_like(w)
+            dw = optim.grad_out(w)
             kernels.gemm_tn(dyp, x, out=dw)
         db = None
         if ctx.has_b and ctx.needs_input_grad[2]:
-            db = _colsum(dyp, w.shape[0])
+            db = _colsum(dyp, b)
         return dx, dw, db, (dy if ctx.has_res else None)
 
 
@@ -107,22 +109,22 @@ class FfnFn(torch.autograd.Function):
         kernels.linear_ex(xn, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU)
         out = torch.empty(m, w2.shape[0], device=xn.device, dtype=torch.float32)
         kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=residual, out=out)
-        ctx.save_for_backward(xn, w1, w2, pre, hid)
+        ctx.save_for_backward(xn, w1, w2, pre, hid, b1, b2)
         ctx.has_res = residual is not None
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        xn, w1, w2, pre, hid = ctx.saved_tensors
+        xn, w1, w2, pre, hid, b1, b2 = ctx.saved_tensors
         dy = dy.contiguous()
         d, dff = w2.shape
-        dw2 = torch.empty_like(w2)
+        dw2 = optim.grad_out(w2)
         kernels.gemm_tn(dy, hid, out=dw2)                                   # dW2 = dY^T . hid
-        db2 = _colsum(dy, d)
+        db2 = _colsum(dy, b2)
         dpre = _dx(dy, w2, kernels.pad32(d), residual=pre, act=kernels.ACT_GELU_BWD)   # (dY . W2) * gelu'(pre)
-        dw1 = torch.empty_like(w1)
+        dw1 = optim.grad_out(w1)
         kernels.gemm_tn(dpre, xn, out=dw1)
-        db1 = _colsum(dpre, dff)
+        db1 = _colsum(dpre, b1)
         dxn = _dx(dpre, w1, kernels.pad32(dff)) if ctx.needs_input_grad[0] else None
         return dxn, dw1, db1, dw2, db2, (dy if ctx.has_res else None)
 
@@ -165,7 +167,7 @@ class LayerNormFn(torch.autograd.Function):
         d = x.shape[-1]
         rows = x.numel() // d
         dx = torch.empty_like(x)
-        dg, db = _zeros_like(gamma), _zeros_like(beta)
+        dg, db = optim.grad_out(gamma, zero=True), optim.grad_out(beta, zero=True)
         ds = dt = None
         if s is not None:
             s = s.contiguous()
@@ -212,7 +214,7 @@ class QkvAttentionFn(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = _dx(dqkv, wqkv, 3 * d)
             if ctx.needs_input_grad[1]:
-                dw = torch.empty_like(wqkv)
+                dw = optim.grad_out(wqkv)
                 kernels.gemm_tn(dqkv, x, out=dw)
             return dx, dw, None, None, None, None
         scale = HEAD_DIM ** -0.5
@@ -237,7 +239,7 @@ class QkvAttentionFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _dx(dqkv, wqkv, 3 * d)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(wqkv)
+            dw = optim.grad_out(wqkv)
             kernels.gemm_tn(dqkv, x, out=dw)
         return dx, dw, None, None, None, None
 
@@ -253,7 +255,7 @@ class EmbedSumPeFn(torch.autograd.Function):
         d = tables[0].shape[1]
         out = torch.empty(B, T, d, device=ids.device, dtype=torch.float32)
         kernels.embed_sum_pe(ids, [t.detach() for t in tables], pe, pos0, out)
-        ctx.ids, ctx.shapes = ids, [t.shape for t in tables]
+        ctx.ids, ctx.shapes, ctx.tables = ids, [t.shape for t in tables], tables
         return out
 
     @staticmethod
@@ -266,7 +268,7 @@ class EmbedSumPeFn(torch.autograd.Function):
             if not ctx.needs_input_grad[3 + j]:
                 grads.append(None)
                 continue
-            g = torch.zeros(shp, device=dout.device, dtype=torch.float32)
+            g = optim.grad_out(ctx.tables[j], zero=True)
             col = ids[..., j]
             check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout),
                                           dout.stride(0), 0, ptr(g), int(shp[0]), B, T, d,

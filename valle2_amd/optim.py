@@ -9,18 +9,47 @@ both AdamW moments in ONE flat fp32 buffer each, so that
 
 Parameters that receive no gradient in a step are skipped and keep their own step count, as torch.optim.AdamW
 does for `grad is None` (NAR trains one stage per step, valle_nar.py:76).  "Received a gradient" means: autograd
-accumulated into the parameter's view (post-accumulate hook) or a gradient tensor was assigned to `p.grad`;
-writing into the flat view by hand without either is not seen.
+accumulated a gradient for the parameter (post-accumulate hook) or a gradient tensor was assigned to `p.grad`;
+writing into the flat view by hand without either is not seen.  After zero_grad() — or step(zero_grad=True) — the
+gradients are `None`, as with torch's set_to_none: the backward functions of this package then write each
+parameter's first gradient of the step directly into its slice of the flat buffer (`grad_out`), which autograd
+adopts as `p.grad` without an accumulation launch; later gradients of the same step (gradient accumulation) are
+added onto it in place by autograd.
 
 It subclasses `torch.optim.Optimizer` only for the `param_groups` contract the reference's
 `CosineAnnealingWarmRestarts` scheduler drives (`lr` is read from the group at every step).
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import _lib
 from ._lib import ptr
+
+# parameter storage address -> (weak FlatAdamW, slot index): lets backward write a parameter's FIRST gradient of a step
+# straight into its slice of the flat gradient (grad_out), so that autograd's AccumulateGrad adopts that tensor — no
+# `grad += new` launch per parameter (≈150 per step of the 12-layer models), no zeros fill for the accumulate-type
+# kernels (bias column sums, embedding scatter-adds, LayerNorm weight gradients)
+GRAD_SLOTS = {}
+
+
+def grad_out(param, like=None, zero=False):
+    """Output tensor for `param`'s gradient in a backward function: its slice of a FlatAdamW's flat gradient when this
+    is the parameter's first gradient since the buffer was zeroed (`param.grad is None`), else a fresh tensor.
+    zero=True: the kernel ACCUMULATES into it (the slice is zero after zero_grad(); a fresh tensor is zero-filled)."""
+    ref = param if param is not None else like
+    ent = GRAD_SLOTS.get(param.data_ptr()) if param is not None else None
+    if ent is not None and param.grad is None:
+        opt = ent[0]()
+        if opt is not None and opt._claim(ent[1]):
+            view = opt.grad_view(opt.slots[ent[1]])
+            if zero and not opt._clean[ent[1]]:
+                view.zero_()
+            opt._clean[ent[1]] = False
+            return view
+    return (torch.zeros_like if zero else torch.empty_like)(ref, memory_format=torch.contiguous_format)
 
 ALIGN = 64  # floats: every parameter slot starts on a 256-byte boundary (the GEMM kernels need 16 bytes; the
             # optimizer kernel maps 64-float blocks to slots for per-parameter step counts)
@@ -70,7 +99,11 @@ class FlatAdamW(torch.optim.Optimizer):
                 view = self.flat_param[off:off + n].view_as(p)
                 view.copy_(p)
                 p.data = view                      # the module now computes on the flat buffer
-        self._point_grads()
+        for i, (p, _, _) in enumerate(self.slots):
+            GRAD_SLOTS[p.data_ptr()] = (weakref.ref(self), i)
+        self._claimed = [False] * len(self.slots)  # slice handed to backward as an output this step (grad_out)
+        self._clean = [True] * len(self.slots)     # slice known to be all zero
+        self._release_grads()
 
     def _touch(self, i):
         self._touched[i] = True
@@ -98,25 +131,40 @@ class FlatAdamW(torch.optim.Optimizer):
         p, off, n = slot
         return self.flat_grad[off:off + n].view_as(p)
 
-    def _point_grads(self):
+    def _claim(self, i):
+        if self._claimed[i]:
+            return False
+        self._claimed[i] = True
+        return True
+
+    def _release_grads(self):
+        """After the flat gradient has been zeroed: `p.grad = None` (torch's set_to_none semantics), so that the next
+        backward's first gradient of each parameter is written straight into its slice (grad_out)."""
         for slot in self.slots:
-            slot[0].grad = self.grad_view(slot)
+            slot[0].grad = None
+        self._claimed = [False] * len(self.slots)
 
     def gather_grads(self):
-        """Autograd accumulates in place into the views; a gradient that was replaced (set_to_none,
-        a foreign zero_grad) is copied back into its slice."""
+        """Every gradient into its slice of the flat buffer: autograd either adopted the slice (grad_out) or
+        accumulated into it in place; a gradient tensor that lives elsewhere (assigned from outside, or cloned by
+        autograd) is copied in; a parameter without a gradient contributes zeros."""
         for i, slot in enumerate(self.slots):
             p, view = slot[0], self.grad_view(slot)
             if p.grad is None:
-                view.zero_()
-            elif p.grad.data_ptr() != view.data_ptr():
+                if not self._clean[i]:
+                    view.zero_()
+                    self._clean[i] = True
+                continue
+            if p.grad.data_ptr() != view.data_ptr():
                 view.copy_(p.grad)
                 self._touched[i] = True            # a gradient assigned from outside counts as present
-            p.grad = view
+                p.grad = view
+            self._clean[i] = False
 
-    def zero_grad(self, set_to_none: bool = False):
+    def zero_grad(self, set_to_none: bool = True):
         self.flat_grad.zero_()
-        self._point_grads()
+        self._clean = [True] * len(self.slots)
+        self._release_grads()
 
     # ---- the step -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -152,6 +200,9 @@ class FlatAdamW(torch.optim.Optimizer):
             float(g['weight_decay']), self.steps, float(grad_scale), float(max_norm), int(zero_grad),
             ptr(self._ws), ptr(self.grad_norm), ptr(block_slot), ptr(slot_step),
             torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
+        if zero_grad:                              # the kernel cleared the flat gradient
+            self._clean = [True] * len(self.slots)
+            self._release_grads()
         from . import engine
         engine.bump_weights_epoch()                # the update bypasses torch's version counters
         return self.grad_norm
