@@ -190,6 +190,20 @@ def pick_n_split(rows_x_heads: int) -> int:
     return max(1, min(16, -(-256 // rows_x_heads)))
 
 
+_CAPTURE_STREAMS = {}
+
+
+def _capture_stream(device_index):
+    """ONE side stream per device for every graph capture of the process (capture enqueues nothing, so decoders can
+    share it): a fresh torch.cuda.Stream() per decoder walks through torch's stream pool, and every new stream that
+    is used becomes another hardware queue — which also decides where a later stream of another priority lands
+    (pipelined attention: the placement of its queue)."""
+    st = _CAPTURE_STREAMS.get(device_index)
+    if st is None:
+        st = _CAPTURE_STREAMS[device_index] = torch.cuda.Stream(device=device_index)
+    return st
+
+
 class ArDecoder:
     """The AR decode loop of valle/models/valle_ar.py:141-171 for B independent rows, one token
     per row per step, the whole step enqueued natively and replayed as a hipGraph."""
@@ -303,7 +317,7 @@ class ArDecoder:
         L = _lib.lib()
         if self.use_graph:
             if not self._captured:
-                cap = torch.cuda.Stream()
+                cap = _capture_stream(torch.cuda.current_device())
                 cap.wait_stream(torch.cuda.current_stream())
                 check(L.vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
                 torch.cuda.current_stream().wait_stream(cap)
