@@ -1,0 +1,41 @@
+"""Soak: the same configs[1] generate N times per decode form; every run must return the first run's tokens and, for
+the stream-ordered default, the same last-step logits bit for bit (developer tool).  usage: soak_generate.py [n=60]"""
+import os
+import sys
+import tempfile
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+os.chdir(tempfile.mkdtemp())
+from valle2_amd import ConfigValle, engine, get_model_class, synth  # noqa: E402
+
+
+def main(n=60):
+    cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm='LayerNorm',
+                      top_k=1, num_beams=32, max_audio_len=512)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=0, rich=False), cfg)
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    utts = [synth.synth_utterance(cfg, 128, 128, 767, seed=1234 + u) for u in range(32)]
+    texts = [torch.cat([u[0], u[2]]).cuda() for u in utts]
+    firsts = [u[1][:, 0].cuda() for u in utts]
+    ref = None
+    for pipe in (False, True):
+        engine.PIPELINED_ATTENTION = pipe
+        bad, times = 0, []
+        for i in range(n):
+            out = m.generate_batch(texts, firsts)
+            times.append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
+            if ref is None:
+                ref = out.clone()
+            elif not torch.equal(out, ref):
+                bad += 1
+        print(f'pipe={pipe}: {n} generates, {bad} differing from the first; decode step min {min(times):.1f} '
+              f'median {sorted(times)[n // 2]:.1f} max {max(times):.1f} us', flush=True)
+
+
+if __name__ == '__main__':
+    main(*[int(a) for a in sys.argv[1:]])
