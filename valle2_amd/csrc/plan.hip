@@ -3,6 +3,9 @@
 // primitives so that what the tests check piecewise is exactly what the composites run.
 #include <stdarg.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "vh_common.h"
@@ -129,7 +132,6 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
     if (dec->side_graph_n) (void)hipGraphDestroy(dec->side_graph_n);
     if (dec->ev_fork) (void)hipEventDestroy(dec->ev_fork);
     if (dec->ev_join) (void)hipEventDestroy(dec->ev_join);
-    if (dec->side) (void)hipStreamDestroy(dec->side);
     delete dec;
 }
 
@@ -297,7 +299,18 @@ static int pipe_side_stream(vh_ar_decoder* dec, hipStream_t s) {
     // the LOWER priority where there is a choice ("least"): the attention workgroups that wait for a CU must never
     // hold up the dispatch of the QKV launch the resident ones are waiting for
     dec->side_prio = prio == least ? greatest : least;
-    HIP_TRY(hipStreamCreateWithPriority(&dec->side, hipStreamNonBlocking, dec->side_prio));
+    // ONE attention stream per (device, priority) for the life of the process, shared by every decoder: where the
+    // runtime puts a stream's hardware queue is decided when the stream is first used and depends on how many queues
+    // exist by then — created once, early, it keeps its place; and a generate no longer pays
+    // for creating and destroying a stream.  Decoders use it one after the other (single caller thread).
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, hipStream_t> shared;
+    int device = 0;
+    HIP_TRY(hipGetDevice(&device));
+    std::lock_guard<std::mutex> lock(mu);
+    hipStream_t& slot = shared[{device, dec->side_prio}];
+    if (!slot) HIP_TRY(hipStreamCreateWithPriority(&slot, hipStreamNonBlocking, dec->side_prio));
+    dec->side = slot;
     return VH_OK;
 }
 
