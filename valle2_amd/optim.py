@@ -108,6 +108,16 @@ class FlatAdamW(torch.optim.Optimizer):
     def _touch(self, i):
         self._touched[i] = True
 
+    def __del__(self):
+        # drop this optimizer's entries from the address registry (an address can be reused by another tensor)
+        try:
+            for p, _, _ in self.slots:
+                ent = GRAD_SLOTS.get(p.data_ptr())
+                if ent is not None and ent[0]() in (self, None):
+                    del GRAD_SLOTS[p.data_ptr()]
+        except Exception:
+            pass
+
     def _block_map(self):
         if self._block_slot is None:
             m = torch.empty(self.numel // ALIGN, dtype=torch.int32)
