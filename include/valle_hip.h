@@ -72,7 +72,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
                                        for the remainder); 1 = one graph launch per step */
        VH_TUNE_PIPE_MODE = 7,       /* pipelined decode attention (desc.qkv_ll): 0 (default) = attention on the decoder's second
                                      * stream; 1 = same kernels in stream order on the caller's stream (A/B of the kernels alone) */
-       VH_TUNE_COUNT = 8 };
+       VH_TUNE_CHAIN_GRID = 8,      /* vh_decode_chain: workgroups of the persistent launch (0 = one per CU, at most 256);
+                                     * diagnostic (tools/probe_chain_xcd.py runs it on the CUs of one XCD) */
+       VH_TUNE_COUNT = 9 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------

@@ -2105,6 +2105,11 @@ __global__ __launch_bounds__(CHAIN_THREADS) void decode_chain_kernel(ChainArgs c
     long long* stamps = sync[2] ? reinterpret_cast<long long*>(sync + 64) + (size_t)wg * 16 : nullptr;
 #define CHAIN_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
     CHAIN_STAMP(0);
+    if (stamps && threadIdx.x == 0) {                 // which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        stamps[6] = xcc & 0xf;
+    }
     // ---- S1: out-projection + bias + residual -> xm (LL, tag 1).  (d/16) column blocks x row groups of 8 (or 16) rows.
     {
         GemmArgs a{};
@@ -2276,7 +2281,9 @@ extern "C" int vh_decode_chain(const float* attn, float* x, float* q, const floa
     c.proj = proj; c.logits = logits; c.ldl = ldl; c.V = V;
     c.B = B; c.d = d_model; c.dff = dff; c.n_heads = n_heads; c.S_max = S_max; c.layer = layer; c.eps = ln_eps; c.sync = sync;
     // one workgroup per CU: all of them resident at once (consumers spin on their producers' data)
-    const dim3 grid(n_cu > 256 ? 256 : n_cu);
+    // (VH_TUNE_CHAIN_GRID: diagnostic — fewer workgroups, e.g. the 32 CUs of one XCD behind a CU-masked stream)
+    const int cap = vh_tuning(VH_TUNE_CHAIN_GRID) > 0 ? vh_tuning(VH_TUNE_CHAIN_GRID) : 256;
+    const dim3 grid(n_cu > cap ? cap : n_cu);
     const int mt = (B + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     if (mt == 1) hipLaunchKernelGGL((decode_chain_kernel<1>), grid, dim3(CHAIN_THREADS), 0, s, c);
