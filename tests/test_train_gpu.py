@@ -280,6 +280,39 @@ def test_flat_adamw_drives_the_model_and_invalidates_folded_weights():
     assert opt2.param_groups[0]['lr'] == opt.param_groups[0]['lr']
 
 
+def test_flat_adamw_gradient_accumulation_adds_onto_the_adopted_slices():
+    """Two backward passes without zero_grad in between (accumulate_grad_batches = 2): the first writes every gradient
+    straight into its slice of the flat buffer (autograd adopts the slice), the second is added onto it in place — the
+    flat gradient is the sum of the two passes' gradients computed separately, and every p.grad is still its slice."""
+    from tests.test_models_gpu import build
+    kw, sd, batch = C.ar_train_inputs()
+    model = build('ValleAR', kw, sd)                          # eval mode: dropout off, the passes are repeatable
+    opt = model.configure_optimizers()['optimizer']
+    b1 = {k: v.clone() for k, v in batch.items()}
+    b2 = {k: v.clone() for k, v in batch.items()}
+    b2['codes'] = (b2['codes'] + 7) % 1000                     # a different micro-batch of the same shape
+    singles = []
+    for b in (b1, b2):
+        opt.zero_grad()
+        assert all(p.grad is None for p in model.parameters())
+        model.training_step({k: v.clone() for k, v in b.items()}).backward()
+        singles.append(opt.flat_grad.clone())
+    # the same gradients as a model without the flat optimizer produces (plain autograd accumulation)
+    plain = build('ValleAR', kw, sd)
+    plain.training_step({k: v.clone() for k, v in b1.items()}).backward()
+    got = {n: opt.grad_view(sl) for sl in opt.slots for n, p in model.named_parameters() if p is sl[0]}
+    opt.zero_grad()
+    model.training_step({k: v.clone() for k, v in b1.items()}).backward()
+    for n, p in plain.named_parameters():
+        torch.testing.assert_close(got[n], p.grad, rtol=1e-5, atol=1e-7)
+    opt.zero_grad()
+    model.training_step(b1).backward()
+    model.training_step(b2).backward()
+    assert all(s[0].grad.data_ptr() == opt.grad_view(s).data_ptr() for s in opt.slots)
+    torch.testing.assert_close(opt.flat_grad, singles[0] + singles[1], rtol=1e-5, atol=1e-6)
+    assert float(singles[0].abs().sum()) > 0 and not torch.equal(singles[0], singles[1])
+
+
 # ---- attention backward kernels (vh_attn_rows_bwd) directly against torch autograd -----------------------
 @pytest.mark.parametrize('B,h,T,mode', [(2, 2, 70, 'prefix'), (3, 2, 300, 'prefix'), (2, 4, 257, 'full'),
                                          (1, 2, 129, 'explicit'), (2, 1, 33, 'full')])
