@@ -453,12 +453,15 @@ int vh_categorical_rows(const float* logits, int ld, int V, int rows, float temp
  * count per parameter and skips parameters whose grad is None (NAR trains one stage per step: the other
  * stages' heads and embeddings receive nothing, valle_nar.py:76).  block_slot (n / 64 int32, device) maps
  * each 64-float block to its parameter slot, slot_step (device) holds the slot's own step count for this
- * update, 0 = skip the slot entirely (no decay, no moments, no move).  Needs n % 64 == 0. */
+ * update, 0 = skip the slot entirely (no decay, no moments, no move).  Needs n % 64 == 0.
+ * guard (optional, one int32 on the device): nonzero when the update launch starts = nothing is touched (the error
+ * flag of the range-checking kernels: a step that saw a bad id never reaches the parameters, and the host can read
+ * the flag a step later instead of synchronising every step). */
 size_t vh_adamw_ws_bytes(void);
 int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   float max_norm, int zero_grad, void* workspace, float* norm_out, const int32_t* block_slot,
-                  const int32_t* slot_step, void* stream);
+                  const int32_t* slot_step, const int32_t* guard, void* stream);
 
 /* ---- training forward / backward products on the LDS-DMA tile machine --------------------------
  * vh_linear_ex = vh_linear (same tile kernels, M of any size) with the two epilogues training needs:

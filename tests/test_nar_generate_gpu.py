@@ -151,8 +151,9 @@ def test_out_of_range_ids_raise_index_error_like_the_reference():
     before = opt.flat_param.clone()
     with torch.enable_grad():
         ar.training_step(b).backward()
+    opt.step()                               # the update launch sees the flag and leaves everything untouched ...
     with pytest.raises(IndexError, match='target'):
-        opt.step()
+        opt.check_errors()                   # ... and the host raises when it looks (the next step does so by itself)
     assert torch.equal(opt.flat_param, before), 'a step with a poisoned batch must not touch the parameters'
     opt.zero_grad()
     b['target'][0, 2] = 5

@@ -129,7 +129,7 @@ SIGNATURES = {
     'vh_adamw_ws_bytes': (C.c_size_t, []),
     'vh_adamw_flat': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_float, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p,
-                                c_f32p, c_i32p, c_i32p, C.c_void_p]),
+                                c_f32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     'vh_ar_decoder_create': (C.c_void_p, [C.POINTER(VhArDecoderDesc)]),
     'vh_ar_decoder_destroy': (None, [C.c_void_p]),
     'vh_ar_decoder_step': (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -235,11 +235,12 @@ def err_flag(device) -> torch.Tensor:
     return _err_flags[idx]
 
 
-def raise_device_errors(device=None):
-    """Synchronises, then raises IndexError if a kernel saw an out-of-range id since the last call."""
+def raise_device_errors(device=None, code=None):
+    """Synchronises, then raises IndexError if a kernel saw an out-of-range id since the last call.  `code`: a flag
+    value already read (asynchronously) from `device`'s flag — no synchronisation then."""
     flags = list(_err_flags.values()) if device is None else [err_flag(device)]
     for f in flags:
-        code = int(f.item())
+        code = int(f.item()) if code is None else int(code)
         if code:
             f.zero_()
             what = []

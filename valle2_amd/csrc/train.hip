@@ -386,7 +386,11 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          float grad_scale, float max_norm, int zero_grad,
                                                          float* __restrict__ norm_out,
                                                          const int32_t* __restrict__ block_slot,
-                                                         const int32_t* __restrict__ slot_step) {
+                                                         const int32_t* __restrict__ slot_step,
+                                                         const int32_t* __restrict__ guard) {
+    // a device-side error flag raised earlier in this step (an id outside its table, ...): leave everything as it is —
+    // the host reads the flag later, without a synchronisation per step, and raises
+    if (guard && *guard) return;
     // total gradient norm: 1024 partials, 4 per thread, fixed order
     __shared__ double s[4];
     double acc = 0.0;
@@ -433,7 +437,7 @@ extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* e
                              float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                              float grad_scale, float max_norm, int zero_grad, void* workspace,
                              float* norm_out, const int32_t* block_slot, const int32_t* slot_step,
-                             void* stream) {
+                             const int32_t* guard, void* stream) {
     VH_REQUIRE((block_slot == nullptr) == (slot_step == nullptr), VH_EINVAL,
                "vh_adamw_flat: block_slot and slot_step go together");
     VH_REQUIRE(!block_slot || n % 64 == 0, VH_EINVAL, "vh_adamw_flat: per-slot steps need n %% 64 == 0");
@@ -454,7 +458,7 @@ extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* e
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
     hipLaunchKernelGGL(adamw_flat_kernel, dim3(blocks), dim3(256), 0, s, param, grad, exp_avg, exp_avg_sq, n4,
                        partials, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale,
-                       max_norm, zero_grad, norm_out, block_slot, slot_step);
+                       max_norm, zero_grad, norm_out, block_slot, slot_step, guard);
     VH_CHECK_LAUNCH("vh_adamw_flat");
     return VH_OK;
 }

@@ -101,12 +101,26 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.data = view                      # the module now computes on the flat buffer
         for i, (p, _, _) in enumerate(self.slots):
             GRAD_SLOTS[p.data_ptr()] = (weakref.ref(self), i)
+        self._flag_host = self._flag_event = None  # asynchronous copy of the device error flag (check_errors)
         self._claimed = [False] * len(self.slots)  # slice handed to backward as an output this step (grad_out)
         self._clean = [True] * len(self.slots)     # slice known to be all zero
         self._release_grads()
 
     def _touch(self, i):
         self._touched[i] = True
+
+    def check_errors(self, wait=True):
+        """Raise the IndexError of a step whose kernels saw an out-of-range id (that step's update was not applied, nor
+        any later one).  wait=False: only look at a flag copy that has already arrived... the copy of the previous
+        step has, by the time the next step's backward is over; wait=True (end of training, tests): synchronise."""
+        if self._flag_event is None:
+            return
+        if wait or self._flag_event.query():
+            self._flag_event.synchronize()
+            self._flag_event = None
+            code = int(self._flag_host[0])
+            if code:
+                _lib.raise_device_errors(self.flat_param.device, code=code)
 
     def __del__(self):
         # drop this optimizer's entries from the address registry (an address can be reused by another tensor)
@@ -185,9 +199,12 @@ class FlatAdamW(torch.optim.Optimizer):
         if closure is not None:
             raise _lib.VhError('FlatAdamW.step: closures are not supported')
         self.gather_grads()
-        # ids / targets already resident on the device are range-checked by the kernels: a bad one must not
-        # reach the parameters (one host read of a 4-byte flag per step; backward has finished by now)
-        _lib.raise_device_errors(self.flat_param.device)
+        # ids / targets already resident on the device are range-checked by the kernels: a bad one must not reach the
+        # parameters.  The update launch checks the flag itself (`guard`) and leaves everything untouched when it is
+        # set; the host reads the flag through an asynchronous copy and raises at the NEXT step (or check_errors()),
+        # so there is no host synchronisation per step and the next forward is enqueued while this step still runs.
+        self.check_errors(wait=False)
+        flag = _lib.err_flag(self.flat_param.device)
         g = self.param_groups[0]
         lib = _lib.lib()
         if self._ws is None:
@@ -208,8 +225,13 @@ class FlatAdamW(torch.optim.Optimizer):
             ptr(self.flat_param), ptr(self.flat_grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), self.numel,
             float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']),
             float(g['weight_decay']), self.steps, float(grad_scale), float(max_norm), int(zero_grad),
-            ptr(self._ws), ptr(self.grad_norm), ptr(block_slot), ptr(slot_step),
+            ptr(self._ws), ptr(self.grad_norm), ptr(block_slot), ptr(slot_step), ptr(flag),
             torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
+        if self._flag_host is None:
+            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._flag_host.copy_(flag, non_blocking=True)
+        self._flag_event = torch.cuda.Event()
+        self._flag_event.record()
         if zero_grad:                              # the kernel cleared the flat gradient
             self._clean = [True] * len(self.slots)
             self._release_grads()

@@ -63,7 +63,7 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
             reducer.enabled = last                       # accumulate locally, exchange once per step
             loss = model.training_step(batch)
             (loss / accum).backward()                    # buckets are all-reduced as they complete
-            losses.append(float(loss.detach()))
+            losses.append(loss.detach())                 # stays on the device: no host synchronisation per step
             if not last:
                 continue
             reducer.finish()
@@ -72,7 +72,7 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
             optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
             step += 1
             if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
-                log(f'step {step}: train/loss {sum(losses[-accum:]) / accum:.4f} '
+                log(f'step {step}: train/loss {float(sum(losses[-accum:])) / accum:.4f} '
                     f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
             if step >= config.max_steps:
                 break
@@ -82,7 +82,8 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
         scheduler.step()
         if one_shot or seen == 0:
             break
-    return model, losses
+    optimizer.check_errors()          # a device-side range error of the last step (earlier ones raise at the next step)
+    return model, [float(x) for x in losses]
 
 
 if __name__ == '__main__':
