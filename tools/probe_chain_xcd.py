@@ -84,8 +84,9 @@ def main(rows=32):
         n = grid if grid else 256
         st = sync[64:].view(torch.int64).view(256, 16)[:n].cpu()
         xcc = sorted(set(int(v) for v in st[:, 6]))
+        rr = sum(int(st[i, 6]) == i % 8 for i in range(n))
         stages = (st[:, 1:6] - st[:, 0:5]).double() / 100.0
-        print(f'{name:44s} {ms.value / (reps * L) * 1e3:7.2f} us per launch; error word {err:#x}; XCDs {xcc}; '
+        print(f'{name:44s} {ms.value / (reps * L) * 1e3:7.2f} us per launch; error word {err:#x}; XCDs {xcc} (workgroup i on XCD i % 8: {rr}/{n}); '
               f'stages (median us) ' + ' '.join(f'{float(stages[:, i].median()):.1f}' for i in range(5)), flush=True)
 
     full = (1 << 256) - 1
