@@ -65,15 +65,13 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
        VH_TUNE_TILE_DMA = 4,        /* large-M GEMM operand staging: 0 (default) = LDS-DMA when K % 32 == 0,
                                        1 = always through registers, 2 = LDS-DMA whenever eligible */
        VH_TUNE_REDUCE_BLOCK = 3,    /* threads per workgroup of the split-K reduce: 64, 128 (default), 256 */
-       VH_TUNE_SPLITK_FIXUP = 5,    /* wide-K decode GEMM split over K: 0 (default) = slabs + reduce kernel; 2 = one launch,
-                                       the last K slice to arrive sums the slabs (measured slower: three dependent
-                                       memory-side round trips cost more than a kernel boundary) */
+       VH_TUNE_FFN_FUSED = 5,       /* decode step FeedForward: 0 (default) = vh_ffn_decode (one launch split over dim_feedforward
+                                       + the slab reduce) when the weights are folded, 1 = linear_1 and linear_2 as separate
+                                       launches (vh_linear_folded + vh_linear_ws) */
        VH_TUNE_GRAPH_STEPS = 6,     /* decode graph: 0 (default) = replay in graphs of 8 consecutive steps (+ single-step graphs
                                        for the remainder); 1 = one graph launch per step */
-       VH_TUNE_PIPE_MODE = 7,       /* pipelined decode attention (desc.qkv_ll): 0 (default) = attention on the decoder's second
-                                     * stream; 1 = same kernels in stream order on the caller's stream (A/B of the kernels alone) */
-       VH_TUNE_CHAIN_GRID = 8,      /* vh_decode_chain: workgroups of the persistent launch (0 = one per CU, at most 256);
-                                     * diagnostic (tools/probe_chain_xcd.py runs it on the CUs of one XCD) */
+       VH_TUNE_FFN_SLICE = 7,       /* vh_ffn_decode: hidden columns per workgroup, 0 (default) = chosen from the shape, else 16 / 32 / 64 */
+       VH_TUNE_FFN_ROWS = 8,        /* vh_ffn_decode: rows per workgroup, 0 (default) = chosen from the shape, else 8 / 16 */
        VH_TUNE_COUNT = 9 };
 int vh_set_tuning(int knob, int value);
 
@@ -119,11 +117,7 @@ int vh_linear(const float* A, int lda, const float* W, const float* bias, const 
  * slice order by a second small kernel (bitwise reproducible; no floating-point atomics).  The same
  * is done for M > 64 when the (M,N) grid has at most 256 tiles of 128x128 and K >= 1024 (one
  * utterance through the NAR stack, a short prefill): K slices in the second grid dimension of the
- * tile kernel.  (vh_set_tuning(VH_TUNE_SPLITK_FIXUP, 2) selects a single-launch form for M <= 64 — a
- * slice publishes its slab with write-through stores, takes a ticket on its column block's arrival
- * counter and the last slice to arrive sums the slabs — measured 1 us per layer slower than the two
- * launches; its counters are the first 4096 bytes of the workspace, so ZERO THE WORKSPACE ONCE before
- * its first use; every call leaves them zero again.)
+ * tile kernel.
  * Falls back to vh_linear when the shape does not split or workspace == NULL. */
 size_t vh_linear_ws_bytes(int M, int N, int K);
 int vh_linear_ws(const float* A, int lda, const float* W, const float* bias, const float* residual,
@@ -155,78 +149,26 @@ int vh_ln_fold(const float* W, const float* gamma, const float* beta, const floa
 int vh_linear_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
                      const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
                      int act, float ln_eps, void* stream);
-int vh_linear_qkv_folded(const void* A, int a_form, int lda, const float* Wf, const float* c1,
-                         const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
-                         const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
-                         float ln_eps, int64_t a_slab_stride, void* stream);
-/* Pipelined decode form of vh_linear_qkv_folded (one new row per sequence, T = 1): q, and the K / V rows in
- * addition to their cache write, are published as (value, tag) pairs — qkv_ll[which][b][c] = 2 floats, which = 0 q,
- * 1 k, 2 v; tag = ((cache_len[0] + 1) * 64 + layer) * 8 + 5 — for a vh_attn_decode_pipe launch that is ALREADY
- * RUNNING on another stream and spins on them.  No plain q output.  layer < 64; cache_len[0] must advance between
- * steps; the caller zeroes qkv_ll before a sequence of steps whose first cache_len[0] may repeat an old one. */
-int vh_linear_qkv_folded_pipe(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
-                              float* kcache, float* vcache, const int32_t* cache_len, int B, int d_model, int n_heads,
-                              int S_max, float ln_eps, float* qkv_ll, int layer, void* stream);
-/* a_form: 0 = A is fp32 rows; 1 = fp64 accumulator rows (below); 2 = the TWO-SLAB form of the residual
- * stream: row r = A[r] + A[a_slab_stride + r] (two fp32 slabs, added in the operand load).
- *
- * Two-slab residual stream (decode step, the default when dim_feedforward % 2048 == 0): linear_2 — the one
- * GEMM of a decode step whose K is too long for one workgroup per column block — runs as two K slices that
- * leave their partial sums in two slabs (slice 0 carries bias + residual) instead of slabs + a reduce
- * launch; the consumers add the two on load:
- *   vh_linear_to_x2(A = hidden, W2, b2, residual = x_mid, slabs)            linear_2 → slabs[0], slabs[1]
- *   vh_linear_qkv_folded(A = slabs, a_form = 2, ...)                         LN1 + QKV of the next layer
- *   vh_linear_x2(A = attn, a_two = 0, ..., residual = slabs, r_two = 1, ...) out-projection + residual → x_mid
- *   vh_linear_x2(A = slabs, a_two = 1, ..., residual = NULL, r_two = 0, ...) the head after the last layer
- * One launch less per layer (modules.py:277-279 residual adds; valle_ar.py:143-158).  Sums are in a fixed
- * order: bitwise reproducible.  M <= 64, N % 16 == 0; K % 2048 == 0 for vh_linear_to_x2, K <= 1024 else. */
-int vh_linear_to_x2(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
-                    float* slabs, int lds, int64_t slab_stride, int M, int N, int K, void* stream);
-int vh_linear_x2(const float* A, int a_two, int lda, const float* W, const float* bias, const float* residual,
-                 int r_two, int ldr, int64_t slab_stride, float* out, int ldo, int M, int N, int K, void* stream);
+int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                         float* q_out, int ldq, float* kcache, float* vcache, const int32_t* cache_len, int B,
+                         int T, int d_model, int n_heads, int S_max, float ln_eps, void* stream);
 
-/* ---- residual stream in fp64 accumulator form (decode path, M <= 64) -------------------------
- * linear_2 at M <= 64 is split over K (one CU pulls ~25 GB/s, see vh_linear_ws).  Instead of slabs
- * plus a reduce launch, vh_linear_acc64 lets every K slice add its partial sums onto an fp64 copy
- * of the residual stream with hardware atomics:   acc[m,n] += sum_k A[m,k] W[n,k]  (+ bias[n] +
- * residual[m,n], added once).  Every addend is first rounded to a multiple of 2^-32, so while
- * |values| < 2^19 the fp64 sums are exact and the result is independent of arrival order:
- * bitwise reproducible, and closer to the real sum than an fp32 reduction.  acc (M,N) ldacc doubles
- * must hold zeros (or an earlier such sum) on entry.  N % 16 == 0, K % 128 == 0.
- * Consumers of the fp64 rows:
- *   vh_linear_qkv_folded(A = acc, a_form = 1, ...)                 LN1 + QKV of the next layer
- *   vh_linear_x64(A = acc, a_f64 = 1, ..., residual64 = NULL, ...) plain Linear on the rows (head)
- *   vh_linear_x64(A fp32, a_f64 = 0, ..., residual64 = acc, ...)   out = A W^T + bias + acc, and the
- *       rows of acc are CLEARED as they are read (N % 16 == 0), ready for the next vh_linear_acc64
- *   vh_greedy_step / vh_sample_step (x_next64)                     write the next embedding in this form
- * (valle/models/modules.py:277-279 residual adds; valle_ar.py:143-158). */
-int vh_linear_acc64(const float* A, int lda, const float* W, const float* bias, const float* residual,
-                    int ldr, double* acc, int ldacc, int M, int N, int K, void* stream);
-int vh_linear_x64(const void* A, int a_f64, int lda, const float* W, const float* bias,
-                  double* residual64, int ldr, float* out, int ldo, int M, int N, int K, void* stream);
-
-/* ---- persistent decode chain --------------------------------------------------------------------
- * Everything of a decode step between two attention launches as ONE launch of one workgroup per CU with no
- * barrier between the stages: a stage's output travels as (value, tag) pairs — one aligned 64-bit agent-scope
- * access each — and its consumers spin on the data itself (one memory-side hop per hand-over):
- *   x_mid = x + attn Wo^T + bo ; hid = gelu(LN2(x_mid) W1^T + b1) (folded: w1f, w1c1, w1c2) ;
- *   x = hid W2^T + b2 + x_mid (K slices of 256 summed in slice order) ;
- *   then EITHER LN1 + QKV of the next layer (folded: wqf, qc1, qc2; q -> q, K/V rows appended at cache_len[b])
- *   OR the head: logits = x proj^T (valle/models/modules.py:146-157,171,221,271-279; valle_ar.py:158).
- * The stages are the code of vh_linear / vh_linear_folded / vh_linear_ws / vh_linear_qkv_folded: results are
- * bit-identical to those launches.  attn, x (B, d_model) fp32 rows (x is updated in place); workspace of
- * vh_decode_chain_ws_bytes(), ZEROED ONCE by the caller; `layer` (< 64) and cache_len[0] (which must advance
- * between decode steps) make the tags unique per launch; sync: 64 + 32 x 256 uint32 zeroed once ([1] error word:
- * nonzero after a wait timed out — every wait is bounded, a launch whose workgroups are not all resident ends
- * with the word set instead of hanging; [2] nonzero: every workgroup leaves 6 wall-clock stamps at word
- * 64 + 32 wg).  B <= 64, d_model = 512, dff % 256 == 0, dff <= 4096. */
-size_t vh_decode_chain_ws_bytes(int B, int d_model, int dff);
-int vh_decode_chain(const float* attn, float* x, float* q, const float* wo, const float* bo, const float* w1f,
-                    const float* w1c1, const float* w1c2, const float* w2, const float* b2, const float* wqf,
-                    const float* qc1, const float* qc2, float* kcache, float* vcache, const int32_t* cache_len,
-                    const float* proj, float* logits, int ldl, int V, int B, int d_model, int dff, int n_heads,
-                    int S_max, int layer, float ln_eps, void* workspace, size_t workspace_bytes, uint32_t* sync,
-                    void* stream);
+/* ---- FeedForward + residual of the decode step as one launch split over dim_feedforward --------
+ * replaces FeedForward.forward + the residual add of EncoderLayer.forward (valle/models/modules.py:215-221,
+ * :278-279) for M <= 64 rows:   out = x + b2 + GELU(LN2(x) W1^T + b1) W2^T
+ * with (w1f, c1, c2) = vh_ln_fold(W1, ln2_gamma, ln2_beta, b1).  Workgroup (slice, row group) owns SW
+ * consecutive hidden columns and up to 16 rows: it computes that (rows x SW) tile of the hidden activation
+ * (folded LayerNorm, exact-erf GELU), keeps it in LDS, multiplies it by W2[:, slice]^T and leaves a raw
+ * (rows x d_model) partial in slab `slice` of the workspace — linear_1 -> linear_2 never crosses a kernel
+ * boundary and the (M, dff) hidden activation never exists in memory.  A second small launch adds the slabs
+ * in slice order (bitwise reproducible, no atomics) with b2 and the residual x.  out may alias x.
+ * x (M, d_model) ldx; w1f (dff, d_model); w2 (d_model, dff) as stored; c1, c2 (dff); b2 (d_model) | NULL.
+ * Supported: M <= 64, d_model in {128, 256, 512, 1024}, dff % 16 == 0, dff / 16 <= 1024 slices.
+ * workspace: vh_ffn_decode_ws_bytes(M, d_model, dff) bytes (no initialisation needed). */
+size_t vh_ffn_decode_ws_bytes(int M, int d_model, int dff);
+int vh_ffn_decode(const float* x, int ldx, const float* w1f, const float* c1, const float* c2, const float* w2,
+                  const float* b2, float* out, int ldo, int M, int d_model, int dff, float ln_eps,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- K7+K8a: multi-row attention (prefill / NAR / training forward) -------------------------
  * replaces merge_masks + F.scaled_dot_product_attention (valle/models/modules.py:160-167,
@@ -272,22 +214,6 @@ size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
 int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
                    int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,
                    int n_split, void* partial, void* stream);
-/* Decode attention that may be launched BEFORE its query exists (modules.py:134-139 with T = 1), on another stream
- * than the launches that feed and consume it: every workgroup (one per (b, head), one per CU, <= 128 VGPRs so that
- * the GEMM launches it waits for fit beside it) requests the first 256 cached keys / values, then waits — bounded; on
- * a timeout err[0] becomes 0xA0000000 | layer, the output is garbage and later launches stop waiting (err: the block
- * of vh_ar_decoder_desc.pipe_err) — for the pairs vh_linear_qkv_folded_pipe publishes with the (cache_len[0], layer)
- * tag; cache_len is re-read at agent scope while waiting (its update by the previous step's sample launch may still
- * be pending when this launch starts).  Attends keys 0 .. cache_len[b] with the newest K / V row taken from the
- * pairs, and publishes the output as pairs, out_ll[b][c] (tag + 1), for vh_linear_ll_in. */
-int vh_attn_decode_pipe(const float* qkv_ll, const float* kcache, const float* vcache, float* out_ll,
-                        const int32_t* cache_len, int B, int n_heads, int S_max, int layer, uint32_t* err, void* stream);
-/* out = A W^T + bias + residual (modules.py:171,277) where A (M, K) arrives as the pairs a vh_attn_decode_pipe launch
- * of the same (cache_len[0], layer) publishes, possibly AFTER this launch started: the weights are requested first, the
- * wait for the pairs is bounded (err[0] = 0x80000000 | ... on a timeout).  M <= 64, N % 16 == 0, K == 512. */
-int vh_linear_ll_in(const float* a_ll, const float* W, const float* bias, const float* residual, int ldr, float* out,
-                    int ldo, int M, int N, int K, const int32_t* cache_len, int layer, uint32_t* err, void* stream);
-
 /* ---- K12/K13: greedy sampling + decode-state update + next-token embedding ------------------
  * replaces topk_sampling(top_k=1) (valle/models/utils.py:46-68: argmax, lowest index on ties),
  * the EOS bookkeeping valle/models/valle_ar.py:167-171 and the re-embedding :143-144 for the
@@ -296,13 +222,12 @@ int vh_linear_ll_in(const float* a_ll, const float* W, const float* bias, const 
  *   p = audio_pos[b]; tok = (codes[b][p-1]==eos) ? eos : argmax(logits[b,:V]); codes[b][p] = tok;
  *   if (tok==eos) eos_count[p - (pos_base?pos_base[b]:0)] += 1;
  *   x_next[b,:] = audio_emb[tok,:] + pe[p*d + :]; audio_pos[b] = p+1; cache_len[b] += 1.
- * x_next (fp32) and x_next64 (the fp64 accumulator form, see vh_linear_acc64) may each be NULL, not both.
  * eos_count[s] == B means every row had finished at step s (the reference's break, :169-170);
  * the host polls it every few steps instead of synchronising every step. */
 int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
                    int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
-                   float* x_next, double* x_next64, int B, int d, void* stream);
+                   float* x_next, int B, int d, void* stream);
 
 /* ---- K12 (stochastic): temperature / top-k / top-p sampling + the same state update ----------
  * replaces topk_sampling (valle/models/utils.py:46-68) incl. the published semantics of
@@ -316,11 +241,11 @@ int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, floa
                    float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
                    int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
-                   float* x_next, double* x_next64, int B, int d, void* stream);
+                   float* x_next, int B, int d, void* stream);
 
 /* ---- composite: one AR decode step / hipGraph replay ----------------------------------------
- * The ~5 launches per layer of one decode step (LN1+QKV+append, decode attention, out-proj+
- * residual, LN2+FFN1+GELU, FFN2+residual) plus head GEMM and vh_greedy_step, enqueued natively
+ * The 5 launches per layer of one decode step (LN1+QKV+append, decode attention, out-proj+
+ * residual, FeedForward slices, slab reduce + residual) plus head GEMM and vh_greedy_step, enqueued natively
  * (valle/models/valle_ar.py:141-171 with modules.py:336-352).  */
 typedef struct {
     const float *ln1_g, *ln1_b, *wqkv, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2;
@@ -350,32 +275,10 @@ typedef struct {
     float top_p, temperature;
     uint64_t seed;
     float *sum_logprobs;              /* (B) or NULL */
-    /* optional: residual stream kept in fp64 accumulator form between layers (vh_linear_acc64): x64
-     * (B,d) doubles + xmid (B,d) floats; needs the folded weights in every layer.  NULL → fp32 x with
-     * the split-K workspace + reduce launch.  On entry of a step the token embedding is in x64 then. */
-    double *x64;
-    float *xmid;
-    /* optional (default in valle2_amd when dim_feedforward % 2048 == 0 and the weights are folded): the
-     * residual stream between layers in the two-slab form, xs = 2 x (B, d) floats (slab stride B*d) — no
-     * split-K workspace, no reduce launch.  Ignored when x64 is set. */
-    float *xs;
-    /* optional: the GEMM chain of every layer as one persistent launch (vh_decode_chain): workspace of
-     * vh_decode_chain_ws_bytes(B, d_model, dff) and the sync block (both zeroed once).  Needs folded weights.
-     * Takes precedence over x64 / xs. */
-    float *chain_ws;
-    size_t chain_ws_bytes;
-    uint32_t *chain_sync;
-    /* optional: pipelined decode attention (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe + vh_linear_ll_in): qkv_ll
-     * = 3 x (B, d_model) (value, tag) pairs = 6*B*d_model floats, zeroed by the caller before every generate; pipe_err =
-     * 16 + 512 uint32, zero ([0] error word; [1] nonzero: workgroup 0 of every attention launch leaves three
-     * wall-clock stamps — start, inputs arrived, end — as uint64 at word 16 + 8 * layer).  The decoder then owns a second
-     * stream and a second set of graphs: the attention launches of a run of steps go there, back to back, so layer
-     * l+1's attention starts (and requests its first keys) as soon as layer l's has finished; the two streams meet
-     * only at the ends of vh_ar_decoder_step / _replay, in between they hand data over through the pairs.  Needs folded
-     * weights, d_model == 512, 2 <= n_layers <= 64, S_max % 32 == 0; ignored with x64 / xs / chain_ws. */
-    float *qkv_ll;
-    float *attn_ll;                   /* (B, d_model) pairs = 2*B*d_model floats, zeroed likewise: the attention output */
-    uint32_t *pipe_err;
+    /* optional: workspace of vh_ffn_decode_ws_bytes(B, d_model, dff) bytes; with it and folded weights in every
+     * layer the FeedForward of a layer is vh_ffn_decode (two launches instead of three). */
+    void *ffn_ws;
+    size_t ffn_ws_bytes;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

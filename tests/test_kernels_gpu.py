@@ -325,92 +325,6 @@ def test_decode_gemm_row_groups_are_bit_identical(K, M):
     close(outs[0][3], F.gelu(ref), atol=5e-5)
 
 
-# ---- residual stream in fp64 accumulator form (vh_linear_acc64 and its consumers) --------------------
-@pytest.mark.parametrize('M,N,K_', [(32, 512, 2048), (5, 64, 512), (64, 128, 128), (17, 512, 4096), (32, 96, 1280)])
-def test_linear_acc64_exact_atomics(K, M, N, K_):
-    a = torch.randn(M, K_, generator=g(90))
-    w = 0.05 * torch.randn(N, K_, generator=g(91))
-    bias, res = torch.randn(N, generator=g(92)), torch.randn(M, N, generator=g(93))
-    ref = a.double() @ w.double().T + bias.double() + res.double()
-    ad, wd, bd, rd = a.to(DEV), w.to(DEV), bias.to(DEV), res.to(DEV)
-    runs = []
-    for _ in range(3):
-        acc = torch.zeros(M, N, device=DEV, dtype=torch.float64)
-        K.linear_acc64(ad, wd, acc, bd, rd)
-        runs.append(acc)
-    torch.testing.assert_close(runs[0].cpu(), ref, atol=3e-5, rtol=1e-6)
-    # exact sums of grid-rounded addends: independent of the arrival order of the K slices
-    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
-    assert torch.equal(runs[0] * 2 ** 32, torch.round(runs[0] * 2 ** 32))      # multiples of 2^-32
-    # accumulates onto what is there (no bias / residual the second time)
-    K.linear_acc64(ad, wd, runs[0])
-    torch.testing.assert_close(runs[0].cpu(), ref + a.double() @ w.double().T, atol=6e-5, rtol=1e-6)
-    # integer data: exact
-    ai = torch.randint(-3, 4, (M, K_), generator=g(94)).float()
-    wi = torch.randint(-3, 4, (N, K_), generator=g(95)).float()
-    acc = torch.zeros(M, N, device=DEV, dtype=torch.float64)
-    K.linear_acc64(ai.to(DEV), wi.to(DEV), acc)
-    assert torch.equal(acc.cpu(), (ai.double() @ wi.double().T))
-
-
-@pytest.mark.parametrize('M,N,K_', [(32, 512, 512), (3, 64, 128), (64, 128, 256)])
-def test_linear_x64_consumes_and_clears_the_residual(K, M, N, K_):
-    a = torch.randn(M, K_, generator=g(96))
-    w = 0.05 * torch.randn(N, K_, generator=g(97))
-    bias = torch.randn(N, generator=g(98))
-    res64 = torch.randn(M, N, generator=g(99), dtype=torch.float64)
-    ref = (a.double() @ w.double().T + bias.double() + res64).float()
-    rd = res64.to(DEV)
-    out = K.linear_x64(a.to(DEV), w.to(DEV), bias.to(DEV), residual64=rd)
-    close(out, ref, atol=3e-5)
-    assert int(rd.count_nonzero()) == 0
-
-
-@pytest.mark.parametrize('M,N,K_', [(32, 1025, 512), (4, 100, 128), (33, 48, 1024)])
-def test_linear_x64_fp64_rows(K, M, N, K_):
-    a64 = torch.randn(M, K_, generator=g(100), dtype=torch.float64)
-    w = 0.05 * torch.randn(N, K_, generator=g(101))
-    out = K.linear_x64(a64.to(DEV), w.to(DEV))
-    close(out, (a64.float().double() @ w.double().T).float(), atol=3e-5)
-    ai = torch.randint(-3, 4, (M, K_), generator=g(102)).double()
-    wi = torch.randint(-3, 4, (N, K_), generator=g(103)).float()
-    assert torch.equal(K.linear_x64(ai.to(DEV), wi.to(DEV)).cpu(), (ai @ wi.double().T).float())
-
-
-def test_linear_x64_argument_checks(K):
-    from valle2_amd._lib import VhError
-    w = torch.randn(64, 128, device=DEV)
-    a = torch.randn(4, 128, device=DEV)
-    with pytest.raises(VhError, match='exactly one'):
-        K.linear_x64(a, w)                                   # neither operand in fp64 form
-    with pytest.raises(VhError, match='exactly one'):
-        K.linear_x64(a.double(), w, residual64=torch.zeros(4, 64, device=DEV, dtype=torch.float64))
-    with pytest.raises(VhError, match='decode path'):
-        K.linear_x64(torch.randn(65, 128, device=DEV).double(), w)
-    with pytest.raises(VhError, match='decode path'):
-        K.linear_acc64(torch.randn(4, 128, device=DEV), torch.randn(60, 128, device=DEV),
-                       torch.zeros(4, 60, device=DEV, dtype=torch.float64))
-
-
-def test_qkv_folded_from_fp64_rows_matches_fp32_rows(K):
-    B, h, S_max = 6, 2, 9
-    d = 64 * h
-    x = torch.randn(B, d, generator=g(104)) + 0.2
-    w = 0.1 * torch.randn(3 * d, d, generator=g(105))
-    gm, bt = 1 + 0.2 * torch.randn(d, generator=g(106)), 0.2 * torch.randn(d, generator=g(107))
-    folded = K.ln_fold(w.to(DEV), gm.to(DEV), bt.to(DEV))
-    cl = torch.tensor([3, 0, 8, 1, 5, 2], dtype=torch.int32, device=DEV)
-    outs = []
-    for xx in (x.to(DEV), x.double().to(DEV)):
-        kc = torch.zeros(B, h, S_max, 64, device=DEV)
-        vc = torch.zeros_like(kc)
-        qo = torch.empty(B, d, device=DEV)
-        K.linear_qkv_folded(xx, folded, qo, kc, vc, B, 1, h, cache_len=cl)
-        outs.append((qo, kc, vc))
-    for u, v in zip(*outs):
-        assert torch.equal(u, v)       # fp32 → fp64 → fp32 is exact: identical arithmetic
-
-
 @pytest.mark.parametrize('rows,d', [(1, 128), (37, 512), (5, 1024), (3, 2048), (9, 132)])
 def test_layernorm(K, rows, d):
     x = 3 * torch.randn(rows, d, generator=g(15)) + 1
@@ -562,84 +476,6 @@ def test_attn_decode_ring_kernels_short_and_ragged_rows(K, variant, S_max):
     close(out, ref, atol=3e-5)
 
 
-@pytest.mark.parametrize('S_max', [64, 320, 1120])
-def test_pipelined_decode_kernels_in_stream_order(K, S_max):
-    """vh_linear_qkv_folded_pipe -> vh_attn_decode_pipe -> vh_linear_ll_in on ONE stream (every wait finds its pairs
-    already there) against vh_linear_qkv_folded -> vh_attn_decode (8-wave ring) -> vh_linear: q and the K / V rows bit for
-    bit, the attention output and the out-projection to rounding (the same chunk order per wave, but the compiler
-    contracts the two kernels' multiply-adds differently: atol 2e-6 / 1e-5); ragged lengths at
-    chunk edges with NaN / Inf beyond every row's length; a stale tag (wrong layer) times out into the error word."""
-    from valle2_amd import _lib
-    lib = _lib.lib()
-    B, h, d = 32, 8, 512
-    gen = g(90 + S_max)
-    x = torch.randn(B, d, generator=gen).to(DEV)
-    wqkv = (0.05 * torch.randn(3 * d, d, generator=gen)).to(DEV)
-    gamma, beta = (1 + 0.1 * torch.randn(d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV)
-    wo, bo = (0.05 * torch.randn(d, d, generator=gen)).to(DEV), (0.1 * torch.randn(d, generator=gen)).to(DEV)
-    folded = K.ln_fold(wqkv, gamma, beta)
-    edges = [1, 2, 5, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1087]
-    lens = torch.tensor([min(S_max, edges[i % len(edges)] + (i // len(edges))) for i in range(B)], dtype=torch.int32)
-    lens[0] = min(S_max, 300)                                  # cache_len[0] carries the step of the tags
-    kc = torch.randn(B, h, S_max, 64, generator=gen)
-    vc = torch.randn(B, h, S_max, 64, generator=gen)
-    for b in range(B):
-        kc[b, :, int(lens[b]) - 1:] = float('nan')             # the newest row (len - 1) comes from the QKV launch
-        vc[b, :, int(lens[b]) - 1:] = float('inf')
-    cl = (lens - 1).to(DEV)
-    s = K.stream()
-    # reference chain: plain kernels
-    kc0, vc0 = kc.to(DEV), vc.to(DEV)
-    q0 = torch.empty(B, d, device=DEV)
-    K.linear_qkv_folded(x, folded, q0, kc0, vc0, B, 1, h, cache_len=cl)
-    a0 = torch.empty(B, d, device=DEV)
-    lib.vh_set_tuning(0, 7)
-    try:
-        K.attn_decode(q0, kc0, vc0, a0, cl, 1, 1, None)
-    finally:
-        lib.vh_set_tuning(0, 0)
-    y0 = K.linear(a0, wo, bias=bo, residual=x)
-    # pipelined kernels, in stream order
-    kc1, vc1 = kc.to(DEV), vc.to(DEV)
-    qkv_ll = torch.zeros(3, B, d, 2, device=DEV)
-    attn_ll = torch.zeros(B, d, 2, device=DEV)
-    err = torch.zeros(16 + 512, device=DEV, dtype=torch.int32)
-    y1 = torch.full((B, d), float('nan'), device=DEV)
-    layer = 3
-    K.check(lib.vh_linear_qkv_folded_pipe(x.data_ptr(), d, folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(),
-                                          kc1.data_ptr(), vc1.data_ptr(), cl.data_ptr(), B, d, h, S_max, 1e-5,
-                                          qkv_ll.data_ptr(), layer, s), 'vh_linear_qkv_folded_pipe')
-    K.check(lib.vh_attn_decode_pipe(qkv_ll.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), attn_ll.data_ptr(), cl.data_ptr(),
-                                    B, h, S_max, layer, err.data_ptr(), s), 'vh_attn_decode_pipe')
-    K.check(lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
-                                B, d, d, cl.data_ptr(), layer, err.data_ptr(), s), 'vh_linear_ll_in')
-    torch.cuda.synchronize()
-    assert int(err[0]) == 0
-    bits = lambda t: t.view(torch.int32)                       # NaN-proof equality
-    assert torch.equal(bits(kc1), bits(kc0)) and torch.equal(bits(vc1), bits(vc0)), 'K / V rows of the new position'
-    assert torch.equal(qkv_ll[0, :, :, 0], q0), 'published q'
-    tag = ((int(cl[0]) + 1) * 64 + layer) * 8 + 5
-    assert bool((qkv_ll[..., 1].view(torch.int32) == tag).all())
-    assert bool(torch.isfinite(attn_ll[..., 0]).all()), 'garbage beyond a row\'s length leaked into the attention output'
-    close(attn_ll[..., 0], a0.cpu(), atol=2e-6, rtol=0)
-    assert bool((attn_ll[..., 1].view(torch.int32) == tag + 1).all())
-    close(y1, y0.cpu(), atol=1e-5, rtol=0)
-    # argument errors come back as codes, nothing is launched: a cache block that is not whole 32-key chunks, a layer
-    # the tag has no room for, an out-projection of another width
-    assert lib.vh_attn_decode_pipe(qkv_ll.data_ptr(), kc1.data_ptr(), vc1.data_ptr(), attn_ll.data_ptr(), cl.data_ptr(),
-                                   B, h, S_max - 1, layer, err.data_ptr(), s) != 0
-    assert lib.vh_linear_qkv_folded_pipe(x.data_ptr(), d, folded[0].data_ptr(), folded[1].data_ptr(), folded[2].data_ptr(),
-                                         kc1.data_ptr(), vc1.data_ptr(), cl.data_ptr(), B, d, h, S_max, 1e-5,
-                                         qkv_ll.data_ptr(), 64, s) != 0
-    assert lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
-                               B, d, 256, cl.data_ptr(), layer, err.data_ptr(), s) != 0
-    # a consumer whose pairs never come (tags of another layer) gives up: error word set, no hang
-    K.check(lib.vh_linear_ll_in(attn_ll.data_ptr(), wo.data_ptr(), bo.data_ptr(), x.data_ptr(), d, y1.data_ptr(), d,
-                                B, d, d, cl.data_ptr(), layer + 1, err.data_ptr(), s), 'vh_linear_ll_in')
-    torch.cuda.synchronize()
-    assert (int(err[0]) & 0xffffffff) >> 28 == 0x8
-
-
 def test_linear_qkv_scatter(K):
     B, T, h = 3, 5, 2
     d = 64 * h
@@ -704,56 +540,101 @@ def test_greedy_step(K):
     assert dv['apos'].cpu().tolist() == [5] * B and dv['clen'].cpu().tolist() == [11, 12, 13, 14, 15]
     assert dv['cnt'].cpu()[4].item() == 2 and dv['cnt'].cpu().sum().item() == 2
     assert torch.equal(x.cpu(), emb[exp] + pe[4, 0])
-    # the same step writing the fp64 accumulator form of the embedding
-    dv2 = {k: v.to(DEV) for k, v in dict(codes=codes, apos=apos, clen=clen, cnt=cnt).items()}
-    x64 = torch.empty(B, d, device=DEV, dtype=torch.float64)
-    K.greedy_step(dv['logits'], V, eos, dv2['codes'], dv2['cnt'], dv['emb'], dv['pe'], dv2['apos'],
-                  dv2['clen'], x64)
-    assert torch.equal(x64.cpu(), (emb[exp] + pe[4, 0]).double())
-    assert torch.equal(dv2['codes'], dv['codes'])
 
 
-@pytest.mark.parametrize('M', [1, 8, 20, 32, 64])
-def test_two_slab_residual_stream_primitives(K, M):
-    """vh_linear_to_x2 / vh_linear_x2 / vh_linear_qkv_folded(a_form=2): linear_2 as two K slices kept apart, the
-    consumers adding the slabs on load.  Against torch fp32 on the CPU; slab sums reproducible bit for bit."""
-    g = torch.Generator().manual_seed(M)
-    d, dff, h = 512, 2048, 8   # noqa: E741
-    hid = torch.randn(M, dff, generator=g)
-    w2, b2 = 0.05 * torch.randn(d, dff, generator=g), 0.1 * torch.randn(d, generator=g)
-    xmid = torch.randn(M, d, generator=g)
-    slabs = torch.empty(2, M, d, device=DEV)
-    K.linear_to_x2(hid.to(DEV), w2.to(DEV), slabs, bias=b2.to(DEV), residual=xmid.to(DEV))
-    x_ref = F.linear(hid, w2, b2) + xmid
-    close(slabs.sum(0), x_ref, atol=5e-5)
-    close(slabs[1], F.linear(hid[:, dff // 2:], w2[:, dff // 2:]), atol=5e-5)      # slice 1: raw partial
-    again = torch.empty_like(slabs)
-    K.linear_to_x2(hid.to(DEV), w2.to(DEV), again, bias=b2.to(DEV), residual=xmid.to(DEV))
-    assert torch.equal(again, slabs)
-    x = slabs.sum(0)                                                  # what every consumer should see
-    # out-projection with the residual in two-slab form
-    attn, wo, bo = torch.randn(M, d, generator=g), 0.05 * torch.randn(d, d, generator=g), 0.1 * torch.randn(d, generator=g)
-    o = K.linear_x2(attn.to(DEV), wo.to(DEV), bias=bo.to(DEV), residual=slabs)
-    close(o, F.linear(attn, wo, bo) + x.cpu(), atol=5e-5)
-    assert torch.equal(o, K.linear(attn.to(DEV), wo.to(DEV), bo.to(DEV), residual=x.contiguous()))
-    # head on two-slab rows (ragged N = 1025)
-    wh = 0.05 * torch.randn(1025, d, generator=g)
-    lg = K.linear_x2(slabs, wh.to(DEV))
-    close(lg, F.linear(x.cpu(), wh), atol=5e-5)
-    assert torch.equal(lg, K.linear(x.contiguous(), wh.to(DEV)))
-    # folded LayerNorm + QKV on two-slab rows == the same kernel on the summed rows
-    wq = 0.05 * torch.randn(3 * d, d, generator=g)
-    gm, bt = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
-    folded = K.ln_fold(wq.to(DEV), gm.to(DEV), bt.to(DEV))
-    outs = []
-    for a in (slabs, x.contiguous()):
-        q = torch.empty(M, d, device=DEV)
-        kc, vc = torch.zeros(M, h, 4, 64, device=DEV), torch.zeros(M, h, 4, 64, device=DEV)
-        cl = torch.full((M,), 2, device=DEV, dtype=torch.int32)
-        K.linear_qkv_folded(a, folded, q, kc, vc, M, 1, h, cache_len=cl)
-        outs.append((q, kc, vc))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
-    ref = F.linear(F.layer_norm(x.cpu(), (d,), gm, bt, 1e-5), wq)
-    close(outs[0][0], ref[:, :d], atol=1e-4)
-    close(outs[0][1][:, :, 2].reshape(M, d), ref[:, d:2 * d], atol=1e-4)
+def _ffn_ref(x, gm, bt, w1, b1, w2, b2):
+    return x + F.linear(F.gelu(F.linear(F.layer_norm(x, (x.shape[1],), gm, bt, 1e-5), w1, b1)), w2, b2)
+
+
+@pytest.mark.parametrize('M,d,dff', [(32, 512, 2048), (1, 512, 2048), (5, 512, 2048), (20, 512, 2048), (64, 512, 2048),
+                                     (4, 128, 512), (16, 128, 512), (8, 1024, 4096), (33, 256, 1024), (9, 512, 80),
+                                     (32, 512, 2064)])
+def test_ffn_decode_matches_torch(K, M, d, dff):
+    """vh_ffn_decode (FeedForward + residual of a decode step as one launch split over dim_feedforward + the slab
+    reduce, modules.py:215-221,278-279) against torch fp32 on the CPU: atol 1e-4 on O(1) rows; in place (out = x);
+    repeated launches bit-identical (slabs summed in slice order, no atomics); every slice width / row grouping."""
+    from valle2_amd import _lib
+    lib = _lib.lib()
+    gen = g(300 + M + d + dff)
+    x = torch.randn(M, d, generator=gen) + 0.2
+    gm, bt = 1 + 0.1 * torch.randn(d, generator=gen), 0.1 * torch.randn(d, generator=gen)
+    w1, b1 = 0.05 * torch.randn(dff, d, generator=gen), 0.1 * torch.randn(dff, generator=gen)
+    w2, b2 = 0.05 * torch.randn(d, dff, generator=gen), 0.1 * torch.randn(d, generator=gen)
+    ref = _ffn_ref(x, gm, bt, w1, b1, w2, b2)
+    folded = K.ln_fold(w1.to(DEV), gm.to(DEV), bt.to(DEV), b1.to(DEV))
+    w2d, b2d = w2.to(DEV), b2.to(DEV)
+    out = K.ffn_decode(x.to(DEV), folded, w2d, b2d)
+    close(out, ref, atol=1e-4)
+    assert torch.equal(out, K.ffn_decode(x.to(DEV), folded, w2d, b2d)), 'not reproducible'
+    xi = x.to(DEV)
+    K.ffn_decode(xi, folded, w2d, b2d, out=xi)                       # in place on the residual stream
+    assert torch.equal(xi, out)
+    close(K.ffn_decode(x.to(DEV), folded, w2d, None), ref - b2, atol=1e-4)
+    # the unfused composition of the same step (folded linear_1 + GELU, split-K linear_2 + residual)
+    hid = K.linear_folded(x.to(DEV), folded, act=1)
+    two = K.linear_ws(hid, w2d, b2d, residual=x.to(DEV))
+    close(out, two.cpu(), atol=5e-5)
+    try:
+        for sw in (16, 32, 64):
+            for rows in (8, 16):
+                if dff % sw:
+                    continue
+                lib.vh_set_tuning(7, sw)
+                lib.vh_set_tuning(8, rows)
+                o = K.ffn_decode(x.to(DEV), folded, w2d, b2d)
+                close(o, ref, atol=1e-4)
+    finally:
+        lib.vh_set_tuning(7, 0)
+        lib.vh_set_tuning(8, 0)
+
+
+def test_ffn_decode_integer_exact_and_strided(K):
+    """Integer-valued operands come out exactly whatever the slice / wave / part summation order (MFMA layout check);
+    x and out as column blocks of wider buffers (row strides > d)."""
+    M, d, dff = 19, 256, 512
+    gen = g(411)
+    # LayerNorm folded with gamma = 1, beta = 0 on rows whose mean is 0 and variance is 1 exactly: x = +-1 balanced
+    x = torch.ones(M, d)
+    x[:, ::2] = -1
+    x = x[:, torch.randperm(d, generator=gen)]
+    w1 = torch.randint(-2, 3, (dff, d), generator=gen).float()
+    b1 = torch.randint(-2, 3, (dff,), generator=gen).float()
+    w2 = torch.randint(-2, 3, (d, dff), generator=gen).float()
+    b2 = torch.randint(-2, 3, (d,), generator=gen).float()
+    folded = K.ln_fold(w1.to(DEV), torch.ones(d, device=DEV), torch.zeros(d, device=DEV), b1.to(DEV))
+    big_in = torch.full((M, d + 64), 7.0, device=DEV)
+    big_in[:, 32:32 + d] = x.to(DEV)
+    big_out = torch.full((M, d + 128), -3.0, device=DEV)
+    K.ffn_decode(big_in[:, 32:32 + d], folded, w2.to(DEV), b2.to(DEV), out=big_out[:, 64:64 + d])
+    rs = 1.0 / (1.0 + 1e-5) ** 0.5                                   # rstd of a unit-variance row
+    hid = F.gelu((x @ w1.T) * rs + b1)
+    ref = x + hid @ w2.T + b2
+    close(big_out[:, 64:64 + d], ref, atol=2e-3, rtol=1e-5)           # hid is O(100): fp32 rounding of the GELU products
+    assert bool((big_out[:, :64] == -3.0).all()) and bool((big_out[:, 64 + d:] == -3.0).all())
+    # exactness of the second product: a hidden tile of small integers survives phase 2 bit for bit
+    w1z = torch.zeros(dff, d)
+    b1i = torch.randint(0, 4, (dff,), generator=gen).float() * 8.0   # gelu(8k) == 8k in fp32 for k >= 1, gelu(0) = 0
+    fz = K.ln_fold(w1z.to(DEV), torch.ones(d, device=DEV), torch.zeros(d, device=DEV), b1i.to(DEV))
+    out = K.ffn_decode(x.to(DEV), fz, w2.to(DEV), b2.to(DEV))
+    assert torch.equal(out.cpu(), x + (F.gelu(b1i)[None, :] @ w2.T) + b2)
+
+
+def test_ffn_decode_argument_checks(K):
+    from valle2_amd._lib import VhError
+    d, dff = 512, 2048
+    w1 = torch.randn(dff, d, device=DEV)
+    folded = K.ln_fold(w1, torch.ones(d, device=DEV), torch.zeros(d, device=DEV))
+    w2 = torch.randn(d, dff, device=DEV)
+    with pytest.raises(VhError, match='unsupported shape|M=65'):
+        K.ffn_decode(torch.randn(65, d, device=DEV), folded, w2)
+    with pytest.raises(VhError, match='w2'):
+        K.ffn_decode(torch.randn(4, d, device=DEV), folded, w2[:, :1024].contiguous())
+    with pytest.raises(VhError, match='workspace'):
+        K.ffn_decode(torch.randn(4, d, device=DEV), folded, w2, workspace=torch.empty(16, device=DEV))
+    w1s = torch.randn(64, 192, device=DEV)                           # d_model outside the kernel's set
+    fs = K.ln_fold(w1s, torch.ones(192, device=DEV), torch.zeros(192, device=DEV))
+    with pytest.raises(VhError, match='d_model'):
+        K.ffn_decode(torch.randn(4, 192, device=DEV), fs, torch.randn(192, 64, device=DEV),
+                     workspace=torch.empty(1 << 16, device=DEV))
+
+

@@ -235,16 +235,15 @@ def test_ar_generate_golden(which, graph):
     tokens_match(out, gold['tokens'], gold['margin'])
 
 
-@pytest.mark.parametrize('fold,acc64,x2,chain', [(False, False, False, False), (True, False, False, False),
-                                                 (True, True, False, False), (True, False, True, False),
-                                                 (True, False, False, True)])
-def test_ar_generate_golden_every_decode_engine(fold, acc64, x2, chain):
-    """The decode step has five forms of its GEMM chain (LayerNorm in the operand load + split-K reduce; folded
-    LayerNorm; folded + fp64 accumulator residual stream; folded + two-slab residual stream; folded + the whole
-    chain as one persistent launch with grid barriers).  Each must reproduce the reference's greedy tokens."""
-    from valle2_amd import engine
-    old = engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN
-    engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN = fold, acc64, x2, chain
+@pytest.mark.parametrize('fold,fused', [(False, False), (True, False), (True, True)])
+def test_ar_generate_golden_every_decode_engine(fold, fused):
+    """The decode step has three forms of its GEMM chain: LayerNorm in the operand load + linear_1 + split-K linear_2
+    + reduce; the same with the LayerNorm folded into the weights; folded + the FeedForward as one launch split over
+    dim_feedforward (vh_ffn_decode, the default).  Each must reproduce the reference's greedy tokens."""
+    from valle2_amd import _lib, engine
+    old = engine.FOLD_LAYERNORM
+    engine.FOLD_LAYERNORM = fold
+    _lib.lib().vh_set_tuning(5, 0 if fused else 1)
     try:
         for which in ('tiny', 'mid'):
             gold = load_golden(f'ar_generate_{which}')
@@ -252,47 +251,17 @@ def test_ar_generate_golden_every_decode_engine(fold, acc64, x2, chain):
             m = build('ValleAR', kw, sd)
             out = m.generate(*[u.to(DEV) for u in utt])
             tokens_match(out, gold['tokens'], gold['margin'])
-            if which == 'mid':                     # 12L/512d, dff = 2048: every form is available
-                assert m.last_generate_stats['two_slab'] == (x2 and not acc64)
-                assert m.last_generate_stats['chain'] == chain
+            assert m.last_generate_stats['ffn_fused'] == fold      # the workspace exists whenever the weights are folded
     finally:
-        engine.FOLD_LAYERNORM, engine.ACC64_RESIDUAL, engine.TWO_SLAB_RESIDUAL, engine.PERSISTENT_CHAIN = old
-
-
-def test_persistent_chain_is_bit_identical_to_one_launch_per_stage():
-    """vh_decode_chain runs the stages' own code (same fragments, same summation order): the generated tokens AND
-    the last step's logits must equal the launch-per-stage decoder's bit for bit; graph replay == eager; ragged rows."""
-    from valle2_amd import engine, synth
-    kw = dict(C.MID, norm='LayerNorm', num_beams=5, top_k=1, max_audio_len=40)
-    cfg = C.cfg_of(kw)
-    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True), cfg)
-    m = build('ValleAR', kw, sd)
-    g = torch.Generator().manual_seed(8)
-    texts = [torch.randint(0, 256, (n,), generator=g).to(DEV) for n in (30, 17, 44, 30, 9)]
-    firsts = [torch.randint(0, 1024, (n,), generator=g).to(DEV) for n in (50, 61, 20, 50, 33)]
-    old = engine.PERSISTENT_CHAIN
-    outs = {}
-    try:
-        for chain in (False, True):
-            engine.PERSISTENT_CHAIN = chain
-            for graph in (True, False):
-                outs[(chain, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
-                assert m.last_generate_stats['chain'] == chain
-    finally:
-        engine.PERSISTENT_CHAIN = old
-    ref = outs[(False, True)]
-    for k, v in outs.items():
-        assert torch.equal(v, ref), f'chain={k[0]} graph={k[1]} differs from the launch-per-stage graph decoder'
-
+        engine.FOLD_LAYERNORM = old
+        _lib.lib().vh_set_tuning(5, 0)
 
 
 @pytest.mark.parametrize('rows', [5, 40])
-def test_pipelined_attention_same_tokens(rows):
-    """VALLE2_PIPE: the attention launches run on the decoder's second stream, a layer early, and take q / k / v from
-    (value, tag) pairs (vh_linear_qkv_folded_pipe + vh_attn_decode_pipe + vh_linear_ll_in).  Same chunk order per wave as
-    the 8-wave ring kernel: the generated tokens must equal the stream-ordered decoder's, graph and eager,
-    ragged rows, and with more (row, head) workgroups than CUs (40 rows x 8 heads = 320)."""
-    from valle2_amd import engine, synth
+def test_fused_feedforward_same_tokens_graph_and_eager(rows):
+    """vh_ffn_decode against the three-launch FeedForward inside the decoder: ragged rows, graph replay and eager
+    stepping, more rows than one row group (40): the greedy tokens of a 40-step generate must be the same."""
+    from valle2_amd import _lib, synth
     kw = dict(C.MID, norm='LayerNorm', num_beams=rows, top_k=1, max_audio_len=40)
     cfg = C.cfg_of(kw)
     sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=3, rich=True), cfg)
@@ -302,22 +271,19 @@ def test_pipelined_attention_same_tokens(rows):
     pl = [(50, 61, 20, 50, 33)[i % 5] + i // 5 for i in range(rows)]
     texts = [torch.randint(0, 256, (n,), generator=g).to(DEV) for n in tl]
     firsts = [torch.randint(0, 1024, (n,), generator=g).to(DEV) for n in pl]
-    from valle2_amd import _lib
-    old = engine.PIPELINED_ATTENTION
     outs = {}
     try:
-        for pipe, mode in ((False, 0), (True, 0), (True, 1)):       # mode 1: the same kernels on ONE stream
-            engine.PIPELINED_ATTENTION = pipe
-            _lib.lib().vh_set_tuning(7, mode)
+        for unfused in (0, 1):
+            _lib.lib().vh_set_tuning(5, unfused)
             for graph in (True, False):
-                outs[(pipe, mode, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
-                assert m.last_generate_stats['pipe'] == pipe
+                outs[(unfused, graph)] = m.generate_batch(texts, firsts, use_graph=graph)
     finally:
-        engine.PIPELINED_ATTENTION = old
-        _lib.lib().vh_set_tuning(7, 0)
-    ref = outs[(False, 0, True)]
-    for k, v in outs.items():
-        assert torch.equal(v, ref), f'pipe={k[0]} mode={k[1]} graph={k[2]} differs from the stream-ordered graph decoder'
+        _lib.lib().vh_set_tuning(5, 0)
+    assert torch.equal(outs[(0, True)], outs[(0, False)]), 'fused FeedForward: graph replay differs from eager steps'
+    assert torch.equal(outs[(1, True)], outs[(1, False)])
+    # the two forms sum in different orders: equal tokens wherever the decision is not a rounding-level tie
+    same = (outs[(0, True)] == outs[(1, True)]).float().mean().item()
+    assert same == 1.0, f'fused and three-launch FeedForward agree on {same:.4f} of the tokens'
 
 
 def test_generate_batch_distinct_rows_vs_oracle():

@@ -10,7 +10,7 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 os.chdir(tempfile.mkdtemp())
-from valle2_amd import ConfigValle, engine, get_model_class, synth  # noqa: E402
+from valle2_amd import ConfigValle, get_model_class, synth  # noqa: E402
 
 
 def main(rounds=8):
@@ -23,28 +23,30 @@ def main(rounds=8):
     utts = [synth.synth_utterance(cfg, 128, 128, 767, seed=1234 + u) for u in range(32)]
     texts = [torch.cat([u[0], u[2]]).cuda() for u in utts]
     firsts = [u[1][:, 0].cuda() for u in utts]
-    base = dict(TWO_SLAB_RESIDUAL=False, ACC64_RESIDUAL=False, PERSISTENT_CHAIN=False, PIPELINED_ATTENTION=False)
-    forms = {'default': dict(base),
-             'two-slab': dict(base, TWO_SLAB_RESIDUAL=True),
-             'pipelined attention': dict(base, PIPELINED_ATTENTION=True),
-             'pipelined kernels in stream order': dict(base, PIPELINED_ATTENTION=True, _pipe_mode=1)}
+    # name -> {tuning knob: value} (include/valle_hip.h: 5 = FeedForward fused / three launches, 7 = slice width,
+    # 8 = rows per workgroup, 0 = decode attention variant)
+    forms = {'default': {},
+             'ffn three launches': {5: 1},
+             'ffn fused 32 x 16 rows': {7: 32, 8: 16},
+             'ffn fused 16 x 16 rows': {7: 16, 8: 16},
+             'ffn fused 64 x 8 rows': {7: 64, 8: 8}}
     if len(sys.argv) > 1:
         forms = {k: v for k, v in forms.items() if k == 'default' or any(a in k for a in sys.argv[1:])}
     res = {k: [] for k in forms}
     outs = {}
+    from valle2_amd import _lib
+    lib = _lib.lib()
     for r in range(rounds + 1):
-        for name, flags in forms.items():
-            from valle2_amd import _lib
-            _lib.lib().vh_set_tuning(0, flags.get('_variant', 0))
-            _lib.lib().vh_set_tuning(7, flags.get('_pipe_mode', 0))
-            for k, v in flags.items():
-                if not k.startswith('_'):
-                    setattr(engine, k, v)
+        for name, knobs in forms.items():
+            for k in (0, 5, 7, 8):
+                lib.vh_set_tuning(k, knobs.get(k, 0))
             out = m.generate_batch(texts, firsts)
             torch.cuda.synchronize()
             if r:
                 res[name].append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
             outs[name] = out
+    for k in (0, 5, 7, 8):
+        lib.vh_set_tuning(k, 0)
     for name, v in res.items():
         print(f'{name:46s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')
     print('same tokens:', all(bool(torch.equal(outs['default'], o)) for o in outs.values()))

@@ -103,9 +103,8 @@ def bench_gemm():
     lib = _lib.lib()
     fq = [K.ln_fold(wqkv[l], g, b) for l in range(L)]
     f1 = [K.ln_fold(w1[l], g, b, b1) for l in range(L)]
-    x64 = torch.randn(B, d, device=DEV, dtype=torch.float64)
-    acc = torch.zeros(B, d, device=DEV, dtype=torch.float64)
-    xmid = torch.randn(B, d, device=DEV)
+    b2 = torch.zeros(d, device=DEV)
+    ffn_ws = K.ffn_decode_ws(B, d, dff, DEV)
     wh = 0.02 * torch.randn(1025, d, device=DEV)
     logits = torch.empty(B, 1028, device=DEV)
 
@@ -115,7 +114,31 @@ def bench_gemm():
             fn()
             lib.vh_set_tuning(knob, 0)
         return run
+    def tuned2(sw, rows, fn):
+        def run():
+            lib.vh_set_tuning(7, sw)
+            lib.vh_set_tuning(8, rows)
+            fn()
+            lib.vh_set_tuning(7, 0)
+            lib.vh_set_tuning(8, 0)
+        return run
+
+    def ffn():
+        l = nxt()
+        K.ffn_decode(x, f1[l], w2[l], b2, out=o1, workspace=ffn_ws)
+
+    def ffn_three():
+        l = nxt()
+        K.linear_folded(x, f1[l], out=o2, act=1)
+        K.linear_ws(o2, w2[l], b2, x, out=o1, workspace=ws2)
     cases = {
+        'ffn fused (default plan)': ffn,
+        'ffn fused slice 32 x 8 rows': tuned2(32, 8, ffn),
+        'ffn fused slice 32 x 16 rows': tuned2(32, 16, ffn),
+        'ffn fused slice 16 x 16 rows': tuned2(16, 16, ffn),
+        'ffn fused slice 16 x 8 rows': tuned2(16, 8, ffn),
+        'ffn fused slice 64 x 8 rows': tuned2(64, 8, ffn),
+        'ffn three launches (ffn1 fold + ffn2 split-K + reduce)': ffn_three,
         'qkv fold': lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
         'qkv fold, no row groups': tuned(2, 2, lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl)),
         'ffn1 fold, no row groups': tuned(2, 2, lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1)),
@@ -123,22 +146,18 @@ def bench_gemm():
         'head f32 rows, no row groups': tuned(2, 2, lambda: K.linear(x, wh, out=logits[:, :1025])),
         'out-proj, 16-row groups': tuned(2, 3, lambda: K.linear(x, wo[nxt()], bo, o1, out=o1)),
         'head f32 rows, 16-row groups': tuned(2, 3, lambda: K.linear(x, wh, out=logits[:, :1025])),
-        'qkv fold f64 rows': lambda: K.linear_qkv_folded(x64, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
         'ffn1 fold': lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1),
-        'out-proj, residual64 consumed': lambda: K.linear_x64(x, wo[nxt()], bo, residual64=acc, out=o1),
-        'ffn2 acc64 (N=512,K=2048)': lambda: K.linear_acc64(hid, w2[nxt()], acc, bo, xmid),
-        'head f64 rows (N=1025)': lambda: K.linear_x64(x64, wh, out=logits[:, :1025]),
         'head f32 rows (N=1025)': lambda: K.linear(x, wh, out=logits[:, :1025]),
         'qkv+ln   (N=1536,K=512)': lambda: K.linear_qkv(x, wqkv[nxt()], q, kc, vc, B, 1, 8, cache_len=cl, ln=ln),
         'out-proj (N=512,K=512)': lambda: K.linear(x, wo[nxt()], bo, o1, out=o1),
         'ffn1+ln  (N=2048,K=512)': lambda: K.linear(x, w1[nxt()], b1, out=o2, act=1, ln=ln),
         'ffn2     (N=512,K=2048)': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
-        'ffn2-splitk one launch (last slice sums)': tuned(5, 2, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
         'ffn2-splitk two launches': lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2),
-        'ffn2 no split, 8-row groups x 16 waves': lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1),
         'ffn2 no split, no row groups': tuned(2, 2, lambda: K.linear(hid, w2[nxt()], bo, o1, out=o1)),
         'ffn2-splitk reduce=64thr, two launches': tuned(3, 64, lambda: K.linear_ws(hid, w2[nxt()], bo, o1, out=o1, workspace=ws2)),
     }
+    if len(sys.argv) > 2:
+        cases = {k: v for k, v in cases.items() if any(a in k for a in sys.argv[2:])}
     # graph-captured so the Python/ctypes launch cost is out of the picture
     for name, fn in cases.items():
         fn()

@@ -43,9 +43,7 @@ class VhArDecoderDesc(C.Structure):
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
-        ('sum_logprobs', C.c_void_p), ('x64', C.c_void_p), ('xmid', C.c_void_p), ('xs', C.c_void_p),
-        ('chain_ws', C.c_void_p), ('chain_ws_bytes', C.c_size_t), ('chain_sync', C.c_void_p),
-        ('qkv_ll', C.c_void_p), ('attn_ll', C.c_void_p), ('pipe_err', C.c_void_p),
+        ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t),
     ]
 
 
@@ -84,22 +82,12 @@ SIGNATURES = {
                              C.c_void_p]),
     'vh_linear_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
-    'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
+    'vh_linear_qkv_folded': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int,
                                        c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
-                                       C.c_float, C.c_int64, C.c_void_p]),
-    'vh_decode_chain_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    'vh_decode_chain': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                  c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, c_f32p, c_f32p, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
-                                  C.c_size_t, C.c_void_p, C.c_void_p]),
-    'vh_linear_to_x2': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64,
-                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'vh_linear_x2': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64,
-                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'vh_linear_acc64': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
-                                  C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    'vh_linear_x64': (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
-                                C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                                       C.c_float, C.c_void_p]),
+    'vh_ffn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_ffn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                                C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_size_t, C.c_void_p]),
     'vh_attn_rows': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
                                c_u8p, C.c_void_p]),
@@ -110,20 +98,14 @@ SIGNATURES = {
                                    c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
     'vh_attn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    'vh_linear_qkv_folded_pipe': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int,
-                                           C.c_int, C.c_int, C.c_int, C.c_float, c_f32p, C.c_int, C.c_void_p]),
-    'vh_attn_decode_pipe': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i32p, C.c_int, C.c_int, C.c_int,
-                                     C.c_int, C.c_void_p, C.c_void_p]),
-    'vh_linear_ll_in': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
-                                 c_i32p, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
-                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, c_f32p, C.c_int, C.c_int,
+                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int,
                                  C.c_void_p]),
     'vh_sample_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
                                  c_i64p, C.c_int64, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p,
-                                 c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+                                 c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_categorical_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_uint64, C.c_uint32,
                                       c_i64p, C.c_int64, c_f32p, C.c_void_p]),
     'vh_adamw_ws_bytes': (C.c_size_t, []),
@@ -240,14 +222,14 @@ def raise_device_errors(device=None, code=None):
     value already read (asynchronously) from `device`'s flag — no synchronisation then."""
     flags = list(_err_flags.values()) if device is None else [err_flag(device)]
     for f in flags:
-        code = int(f.item()) if code is None else int(code)
-        if code:
+        c = int(f.item()) if code is None else int(code)
+        if c:
             f.zero_()
             what = []
-            if code & DEVERR_EMBED_ID:
+            if c & DEVERR_EMBED_ID:
                 what.append('a token / codec id outside its embedding table (nn.Embedding raises IndexError; '
                             'e.g. EOS/BOS inside NAR `codes`, a text id >= vocab_size)')
-            if code & DEVERR_TARGET:
+            if c & DEVERR_TARGET:
                 what.append('a cross-entropy target outside [0, V) (ignore_index is not supported: the collate '
                             'format pads with 0)')
             raise IndexError('index out of range on the HIP device: ' + '; '.join(what))

@@ -223,16 +223,14 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
     }
 }
 
-// Ring variant (round 2).  What the burst kernel leaves on the table: tools/probe_read_bw.hip shows that plain
-// streaming READS reach 8.0-8.1 TB/s on this part when every CU keeps >= 256 KB of non-temporal loads in flight all
-// the time (16 x 16 B per thread x 1024 threads), against 6.5 TB/s with half of that — the 6.29 TB/s "copy rate"
-// round 1 took for the ceiling is a read+write figure.  The burst kernel has 256 KB in flight only at the moment
-// its 16 waves have all just issued; each wave then waits for its whole burst, reduces it, and only then asks
-// again, and its very first request waits for a dependent load of cache_len[b].  Here a wave owns a ring of D
-// register sets of 32 keys each: D-1 bursts are always outstanding while one is reduced, and the first D-1 bursts
-// are issued BEFORE the context length is known (addresses clamped inside the cache allocation; what lies beyond
-// the row's length is masked once the length has arrived), so the stream starts with the kernel.
-// NW waves x D sets x 16 KB in flight per CU: 8 x 3 = 384 KB (232 VGPRs, 2 waves per SIMD).
+// Ring variant (round 2).  The burst kernel has its 256 KB per CU in flight only at the moment its 16 waves have
+// all just issued; each wave then waits for its whole burst, reduces it, and only then asks again, and its very first
+// request waits for a dependent load of cache_len[b].  Here a wave owns a ring of D register sets of 32 keys each:
+// D-1 bursts are always outstanding while one is reduced, and the first D-1 bursts are issued BEFORE the context
+// length is known (addresses clamped inside the cache allocation; what lies beyond the row's length is masked once
+// the length has arrived), so the stream starts with the kernel.  The read ceiling of this part is 6.3-6.5 TB/s
+// for any read-only kernel (tools/probe_read_bw.hip, corrected: its first version dropped loop remainders and
+// reported 8 TB/s); the 8 x 2 ring reaches 6.0-6.1 TB/s inside the decode step.
 template <int NW, int D, int CK = 32, bool NOCOMP = false>
 __global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ kc,
@@ -359,235 +357,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
 
 static thread_local hipEvent_t g_attn_ev[2] = {nullptr, nullptr};
 void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop) { g_attn_ev[0] = start; g_attn_ev[1] = stop; }
-
-// Pipelined variant of the ring kernel (opt-in, round 2): launched on a side stream as soon as the PREVIOUS layer's
-// attention has finished, i.e. while that layer's GEMM chain is still running.  It requests both of its register
-// sets (64 keys per wave, 512 per (b, head)) at once — those K/V rows were written by earlier decode steps — and
-// then waits for its inputs of THIS step, which the QKV launch at the end of the chain publishes as (value, tag)
-// pairs (vh_linear_qkv_folded_pipe): the query row and the newest K / V row (the cache row at position len - 1 is
-// not read: it may not be visible yet).  No kernel boundary between the QKV launch and this kernel, and 40 % of a
-// 1280-key stream is already in registers when q arrives.  Every wait is bounded (err word, garbage out, no hang).
-#define PIPE_SPIN_LIMIT 200000
-#define PIPE_LDS_BYTES (8 * 16 * 1024)     // the LDS key / value set: 16 KB per wave
-struct LLQ { uint64_t p[4]; };
-__device__ __forceinline__ LLQ pipe_ld(const float* ll) {
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(ll);
-    LLQ r;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.p[j] = __hip_atomic_load(q + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return r;
-}
-__device__ __forceinline__ bool pipe_ok(const LLQ& r, uint32_t tag) {
-    return (uint32_t)(r.p[0] >> 32) == tag && (uint32_t)(r.p[1] >> 32) == tag && (uint32_t)(r.p[2] >> 32) == tag &&
-           (uint32_t)(r.p[3] >> 32) == tag;
-}
-__device__ __forceinline__ f32x4 pipe_val(const LLQ& r) {
-    return f32x4{__uint_as_float((uint32_t)r.p[0]), __uint_as_float((uint32_t)r.p[1]), __uint_as_float((uint32_t)r.p[2]),
-                 __uint_as_float((uint32_t)r.p[3])};
-}
-
-template <int NW, int D>      // D = 1 (one register set + the LDS set)
-__global__ __launch_bounds__(NW * 64, 4) void attn_decode_pipe_ring_kernel(
-    const float* __restrict__ qkv_ll, int B, const float* __restrict__ kc, const float* __restrict__ vc,
-    float* __restrict__ out_ll, const int32_t* cache_len, int n_heads, int S_max, int layer, uint32_t* __restrict__ err) {
-    constexpr int LPS = 8;
-    __shared__ float s_m[NW], s_l[NW];
-    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
-    // One workgroup per CU (the 128 KB LDS set, PIPE_LDS_BYTES, sees to that) and at most 128 VGPRs: the waiting
-    // workgroups must leave registers, wave slots and 29 KB of LDS for the GEMM chain they wait for.
-    __shared__ __attribute__((aligned(16))) float s_in[3][HD];       // q, newest k, newest v of this (b, head)
-    __shared__ int s_len;
-    __shared__ uint32_t s_tag;
-    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, in an SGPR
-    const int c16 = lane & 15, g = lane >> 4;
-    const int d_model = n_heads * HD;
-    const float* kb = kc + (int64_t)bh * S_max * HD + 4 * c16;
-    const float* vb = vc + (int64_t)bh * S_max * HD + 4 * c16;
-    f32x4 kf[D][LPS], vf[D][LPS];
-    // S_max % 32 == 0 (host check): a chunk of 32 keys never crosses the end of a (b, head) cache block, so the 16
-    // rows a lane reads are its chunk base + constant offsets; chunks requested before the length is known are
-    // clamped to the last one of the block (wave-uniform) and never reduced.
-    const int c_last = S_max / 32 - 1;
-    auto load = [&](int c, f32x4 (&kq)[LPS], f32x4 (&vq)[LPS]) {
-        const int64_t r0 = (int64_t)(min(c, c_last) * 32 + g) * HD;
-#pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            kq[i] = ld4_stream(kb + r0 + 4 * i * HD);
-            vq[i] = ld4_stream(vb + r0 + 4 * i * HD);
-        }
-    };
-    // A second set of 32 keys per wave lives in LDS (16 KB per wave, written by LDS-DMA: no registers): slot
-    // [i][lane] holds what register kq[i] / vq[i] of that lane would hold, so the reduction reads its own 16 bytes.
-    extern __shared__ __attribute__((aligned(16))) float pipe_dyn[];
-    float* const my_k = pipe_dyn + w * 4096;
-    float* const my_v = my_k + 2048;
-    typedef __attribute__((address_space(3))) void* lds_vp;
-    typedef const __attribute__((address_space(1))) void* glb_vp;
-    auto dma = [&](int c) {
-        const int64_t r0 = (int64_t)(min(c, c_last) * 32 + g) * HD;
-#pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            __builtin_amdgcn_global_load_lds((glb_vp)(kb + r0 + 4 * i * HD), (lds_vp)(my_k + i * 256), 16, 0, 2);   // aux 2 = nt
-            __builtin_amdgcn_global_load_lds((glb_vp)(vb + r0 + 4 * i * HD), (lds_vp)(my_v + i * 256), 16, 0, 2);
-        }
-    };
-    // diagnostics (err[1] != 0): workgroup 0 leaves wall-clock stamps (start, inputs arrived, end) per layer
-    const bool stamps = err[1] != 0 && bh == 0 && tid == 0;
-    unsigned long long* st = reinterpret_cast<unsigned long long*>(err) + 8 + layer * 4;
-    if (stamps) st[0] = wall_clock64();
-    // Before anything of this step is known: 64 keys per wave, 256 KB per workgroup.  (Pacing these requests — they
-    // are a 64 MB burst chip-wide, beside the latency-bound GEMM launches — changed nothing: 577-583 us per step
-    // for gaps of 0 to 1280 cycles between row pairs, profiles/r2_ab_decode_pipe.log.)
-#pragma unroll
-    for (int j = 0; j < D; ++j) load(w + j * NW, kf[j], vf[j]);
-    dma(w + D * NW);
-    // This step's inputs.  Lane 0 of wave 0 watches ONE pair (512 workgroups polling whole rows would flood the
-    // memory system the GEMM chain is using); once it carries the tag, lanes 0-47 of that wave fetch q / k / v
-    // (16 lanes x 4 floats each) until every pair does, and hand them to the other waves through LDS.  The other
-    // waves park at the barrier with their K/V requests in flight.
-    // cache_len belongs to the other stream: the sample step that closes the previous decode step may not have run
-    // when this launch starts, so the tag is rebuilt from a fresh agent-scope read on every poll (the pairs of this
-    // layer's previous step carry the previous position, those of the previous layer this step another layer).
-    if (w == 0) {
-        const int64_t plane = (int64_t)B * d_model;
-        const int64_t e0 = (int64_t)b * d_model + head * HD;
-        int budget = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 0 : PIPE_SPIN_LIMIT;
-        const uint64_t* sentinel = reinterpret_cast<const uint64_t*>(qkv_ll + 2 * (2 * plane + e0 + HD - 1));
-        uint32_t tag;
-        for (;;) {
-            const int c0 = __hip_atomic_load(cache_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tag = ((uint32_t)(c0 + 1) * 64u + (uint32_t)layer) * 8u + 5u;
-            if ((uint32_t)(__hip_atomic_load(sentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) == tag) break;
-            if (--budget <= 0) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        const int which = min(lane >> 4, 2);
-        const float* src = qkv_ll + 2 * (which * plane + e0 + 4 * c16);
-        LLQ r = pipe_ld(src);
-        while (!__all(pipe_ok(r, tag)) && budget > 0) {
-            __builtin_amdgcn_s_sleep(2);
-            r = pipe_ld(src);
-            --budget;
-        }
-        if (budget <= 0 && lane == 0)
-            atomicCAS(err, 0u, 0xA0000000u | (uint32_t)(tag & 0xfffffu) << 8 | (uint32_t)(bh & 0xff));   // the first timeout stays
-        if (lane < 48) st4(&s_in[which][4 * c16], pipe_val(r));
-        if (lane == 0) {
-            s_len = __hip_atomic_load(cache_len + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-            s_tag = tag + 1;                     // stage 6: this launch's output
-        }
-    }
-    __syncthreads();
-    if (stamps) st[1] = wall_clock64();
-    const int len = s_len;                       // keys 0 .. len-1, the newest one from the pairs
-    const int c_end = (len + 31) >> 5;
-    const float qscale = 0.125f * LOG2E;
-    const f32x4 q4 = ld4(&s_in[0][4 * c16]) * qscale;
-
-    float m = NEG_INF, l = 0.f;
-    f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    // one 32-key chunk into the running softmax; getk(i) / getv(i): this lane's 16 bytes of key row key0 + 4 i.
-    // Interior chunks (wave-uniform test) take the path without masks; the last one masks keys >= len and takes the
-    // row this step appended from the pairs (kept in LDS until then: 8 registers the interior path does not pay for).
-    auto reduce_t = [&](int c, auto getk, auto getv, auto whole_c) {
-        constexpr bool WHOLE = decltype(whole_c)::value;
-        const int key0 = c * 32 + g;
-        f32x4 knew = {0.f, 0.f, 0.f, 0.f}, vnew = {0.f, 0.f, 0.f, 0.f};
-        if (!WHOLE) { knew = ld4(&s_in[1][4 * c16]); vnew = ld4(&s_in[2][4 * c16]); }
-        float sc[LPS];
-        float cmax = NEG_INF;
-#pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            f32x4 kk = getk(i);
-            if (!WHOLE && key0 + 4 * i == len - 1) kk = knew;
-            const f32x4 t = kk * q4;
-            const float dd = row16_sum((t.x + t.y) + (t.z + t.w));
-            sc[i] = (WHOLE || key0 + 4 * i < len) ? dd : NEG_INF;
-            cmax = fmaxf(cmax, sc[i]);
-        }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-        const float m_new = fmaxf(m, cmax);
-        const float alpha = vh_exp2(m - m_new);
-        o *= alpha;
-        l *= alpha;
-#pragma unroll
-        for (int i = 0; i < LPS; ++i) {
-            const float p = vh_exp2(sc[i] - m_new);
-            l += p;
-            f32x4 vv = getv(i);
-            if (!WHOLE) {
-                if (key0 + 4 * i == len - 1) vv = vnew;
-                if (key0 + 4 * i >= len) vv = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            o += vv * p;
-        }
-        m = m_new;
-    };
-    auto reduce = [&](int c, auto getk, auto getv) {
-        if (c * 32 + 32 <= len - 1) reduce_t(c, getk, getv, std::true_type{});
-        else reduce_t(c, getk, getv, std::false_type{});
-    };
-    // Ring of D register sets + the LDS set, NW chunks apart: while one is reduced the others are in flight.
-    constexpr int RING = (D + 1) * NW;
-    for (int c0 = w; c0 < c_end; c0 += RING) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            const int c = c0 + j * NW;
-            if (c < c_end) {
-                reduce(c, [&](int i) { return kf[j][i]; }, [&](int i) { return vf[j][i]; });
-                if (c + RING < c_end) load(c + RING, kf[j], vf[j]);          // refill the set just consumed
-            }
-        }
-        const int c = c0 + D * NW;
-        if (c < c_end) {
-            reduce(c, [&](int i) { return ld4(my_k + i * 256 + lane * 4); }, [&](int i) { return ld4(my_v + i * 256 + lane * 4); });
-            if (c + RING < c_end) dma(c + RING);
-        }
-    }
-#pragma unroll
-    for (int sh = 16; sh <= 32; sh <<= 1) {
-        o.x += __shfl_xor(o.x, sh, 64); o.y += __shfl_xor(o.y, sh, 64);
-        o.z += __shfl_xor(o.z, sh, 64); o.w += __shfl_xor(o.w, sh, 64);
-        l += __shfl_xor(l, sh, 64);
-    }
-    if (lane < 16) st4(&s_o[w][4 * c16], o);
-    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
-    __syncthreads();
-    if (tid < HD) {
-        float M = s_m[0];
-#pragma unroll
-        for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
-            L += s_l[k] * wgt;
-            O += s_o[k][tid] * wgt;
-        }
-        // the output goes out as (value, tag) pairs too: its consumer (vh_linear_ll_in) is already waiting
-        const uint64_t pr = ((uint64_t)s_tag << 32) | __float_as_uint(O / L);
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(out_ll) + (int64_t)b * d_model + head * HD + tid, pr,
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (stamps) st[2] = wall_clock64();
-}
-
-extern "C" int vh_attn_decode_pipe(const float* qkv_ll, const float* kcache, const float* vcache, float* out_ll,
-                                   const int32_t* cache_len, int B, int n_heads, int S_max, int layer, uint32_t* err,
-                                   void* stream) {
-    VH_REQUIRE(qkv_ll && kcache && vcache && out_ll && cache_len && err, VH_EINVAL, "vh_attn_decode_pipe: null pointer");
-    VH_REQUIRE(B > 0 && n_heads > 0 && S_max > 0 && S_max % 32 == 0 && layer >= 0 && layer < 64, VH_EINVAL,
-               "vh_attn_decode_pipe: bad dims B=%d h=%d S_max=%d (a multiple of 32) layer=%d", B, n_heads, S_max, layer);
-    VH_REQUIRE(vh_aligned16(qkv_ll) && vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(out_ll), VH_EALIGN,
-               "vh_attn_decode_pipe: pointers must be 16-byte aligned");
-    hipExtLaunchKernelGGL((attn_decode_pipe_ring_kernel<8, 1>), dim3(1, B * n_heads), dim3(512), PIPE_LDS_BYTES,
-                          (hipStream_t)stream, g_attn_ev[0], g_attn_ev[1], 0, qkv_ll, B, kcache, vcache, out_ll, cache_len,
-                          n_heads, S_max, layer, err);
-    VH_CHECK_LAUNCH("vh_attn_decode_pipe");
-    return VH_OK;
-}
 
 __global__ __launch_bounds__(64) void attn_decode_combine_kernel(
     const float* __restrict__ partial, float* __restrict__ out, int ldo, int n_heads, int n_split) {

@@ -154,9 +154,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(
     const float* __restrict__ logits, int ldl, int V, int eos, int64_t* __restrict__ codes,
     int64_t codes_stride, int32_t* __restrict__ eos_count, const int32_t* __restrict__ pos_base,
     const float* __restrict__ audio_emb, const float* __restrict__ pe,
-    int32_t* __restrict__ audio_pos, int32_t* __restrict__ cache_len, float* __restrict__ x_next,
-    double* __restrict__ x_next64,
-    int d) {
+    int32_t* __restrict__ audio_pos, int32_t* __restrict__ cache_len, float* __restrict__ x_next, int d) {
     __shared__ float s_val[4];
     __shared__ int s_idx[4];
     __shared__ int s_tok;
@@ -194,13 +192,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(
     const float* pr = pe + (int64_t)pos * d;          // only the new row (modules.py:337 keeps it)
     for (int c = tid * 4; c < d; c += 1024) {
         const f32x4 e = ld4(er + c) + ld4(pr + c);
-        if (x_next) st4(x_next + (int64_t)b * d + c, e);
-        if (x_next64) {              // fp64 accumulator form of the residual stream (vh_linear_acc64)
-            typedef double d64x2 __attribute__((ext_vector_type(2)));
-            double* o = x_next64 + (int64_t)b * d + c;
-            *reinterpret_cast<d64x2*>(o) = d64x2{(double)e.x, (double)e.y};
-            *reinterpret_cast<d64x2*>(o + 2) = d64x2{(double)e.z, (double)e.w};
-        }
+        st4(x_next + (int64_t)b * d + c, e);
     }
     if (tid == 0) {
         audio_pos[b] = pos + 1;
@@ -211,16 +203,16 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(
 extern "C" int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
                               int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
                               const float* audio_emb, const float* pe, int32_t* audio_pos,
-                              int32_t* cache_len, float* x_next, double* x_next64, int B, int d, void* stream) {
-    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && (x_next || x_next64),
+                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next,
                VH_EINVAL, "vh_greedy_step: null pointer");
     VH_REQUIRE(B > 0 && V > 0 && ldl >= V && d > 0 && d % 4 == 0, VH_EINVAL,
                "vh_greedy_step: bad dims B=%d V=%d ldl=%d d=%d", B, V, ldl, d);
-    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next) && vh_aligned16(x_next64), VH_EALIGN,
+    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next), VH_EALIGN,
                "vh_greedy_step: audio_emb/pe/x_next must be 16-byte aligned");
     hipLaunchKernelGGL(greedy_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl,
                        V, eos, codes, codes_stride, eos_count, pos_base, audio_emb, pe, audio_pos,
-                       cache_len, x_next, x_next64, d);
+                       cache_len, x_next, d);
     VH_CHECK_LAUNCH("vh_greedy_step");
     return VH_OK;
 }
@@ -262,7 +254,7 @@ __global__ __launch_bounds__(256) void sample_step_kernel(
     uint64_t seed, int64_t* __restrict__ codes, int64_t codes_stride, int32_t* __restrict__ eos_count,
     const int32_t* __restrict__ pos_base, float* __restrict__ sum_logprobs,
     const float* __restrict__ audio_emb, const float* __restrict__ pe, int32_t* __restrict__ audio_pos,
-    int32_t* __restrict__ cache_len, float* __restrict__ x_next, double* __restrict__ x_next64, int d, int npow2) {
+    int32_t* __restrict__ cache_len, float* __restrict__ x_next, int d, int npow2) {
     __shared__ float s_val[SAMPLE_MAXV];
     __shared__ int s_idx[SAMPLE_MAXV];
     __shared__ int s_hist[256];
@@ -455,13 +447,7 @@ __global__ __launch_bounds__(256) void sample_step_kernel(
     const float* pr = pe + (int64_t)pos * d;
     for (int c = tid * 4; c < d; c += 1024) {
         const f32x4 e = ld4(er + c) + ld4(pr + c);
-        if (x_next) st4(x_next + (int64_t)b * d + c, e);
-        if (x_next64) {              // fp64 accumulator form of the residual stream (vh_linear_acc64)
-            typedef double d64x2 __attribute__((ext_vector_type(2)));
-            double* o = x_next64 + (int64_t)b * d + c;
-            *reinterpret_cast<d64x2*>(o) = d64x2{(double)e.x, (double)e.y};
-            *reinterpret_cast<d64x2*>(o + 2) = d64x2{(double)e.z, (double)e.w};
-        }
+        st4(x_next + (int64_t)b * d + c, e);
     }
     if (tid == 0) {
         audio_pos[b] = pos + 1;
@@ -473,19 +459,19 @@ extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int 
                               float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
                               int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
                               const float* audio_emb, const float* pe, int32_t* audio_pos,
-                              int32_t* cache_len, float* x_next, double* x_next64, int B, int d, void* stream) {
-    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && (x_next || x_next64),
+                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+    VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next,
                VH_EINVAL, "vh_sample_step: null pointer");
     VH_REQUIRE(B > 0 && V > 0 && V <= SAMPLE_MAXV && ldl >= V && d > 0 && d % 4 == 0, VH_EINVAL,
                "vh_sample_step: bad dims B=%d V=%d (<= %d) ldl=%d d=%d", B, V, SAMPLE_MAXV, ldl, d);
     VH_REQUIRE(temperature > 0.f, VH_EINVAL, "vh_sample_step: temperature must be positive");
-    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next) && vh_aligned16(x_next64), VH_EALIGN,
+    VH_REQUIRE(vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next), VH_EALIGN,
                "vh_sample_step: audio_emb/pe/x_next must be 16-byte aligned");
     int npow2 = 2;
     while (npow2 < V) npow2 <<= 1;
     hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
                        eos, top_k, top_p, 1.0f / temperature, seed, codes, codes_stride, eos_count,
-                       pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, x_next64, d, npow2);
+                       pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, d, npow2);
     VH_CHECK_LAUNCH("vh_sample_step");
     return VH_OK;
 }

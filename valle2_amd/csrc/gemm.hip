@@ -10,8 +10,9 @@
 //                         as the A operand so a lane's 4 results are 4 consecutive output columns; K over
 //                         the waves of a workgroup, reduced through LDS in fixed order; one workgroup per
 //                         (16 columns, 8..16 rows); LayerNorm in the operand load or folded into the
-//                         weights (vh_ln_fold); split-K slabs + splitk_reduce_kernel for K > 1024; the
-//                         opt-in fp64 accumulator form (exact atomics).  Latency-bound.
+//                         weights (vh_ln_fold); split-K slabs + splitk_reduce_kernel for K > 1024.
+//                         Latency-bound.
+//   * ffn_decode_kernel   FeedForward of the decode step as ONE launch split over dim_feedforward (ffn.hip).
 //   * gemm_skinny_kernel  the guarded generic version for K off the fast shapes.
 //
 // MFMA operand maps used (cdna_hip_programming.md §3):
@@ -40,19 +41,6 @@ struct GemmArgs {
     int T, S_max, d_model, n_heads;
     float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
     int ldx;
-    // flag-in-data ("LL") hand-over between the stages of the persistent decode chain (COH bits of skinny_body):
-    // an LL buffer holds (value, tag) pairs, 8 bytes each, written and read as single 64-bit accesses at agent
-    // scope; logical element p of the fp32 matrix that starts at *_org lives at ll_* + 2 (p - *_org)
-    const float* ll_in; const float* a_org; uint32_t tag_in;
-    float* ll_out; const float* out_org; uint32_t tag_out;
-    uint32_t* err_word;
-    // pipelined decode (EPI_QKV with ll_out set): q and the newest K / V row also go out as (value, tag) pairs,
-    // [q | k | v] x (ll_rows, d_model); tag = ((cl0[0] + 1) * 64 + tag_out) * 8 + 5 (tag_out carries the layer)
-    const int32_t* cl0; int ll_rows;
-    int64_t s2;   // two-slab form of the residual stream (X64 bits 2/3, EPI_SLAB2): element offset of slab 1
-    float* slab;  // EPI_FIXUP: partial sums [slice][M][lds] and one arrival counter per column block
-    int lds;
-    int* counters;
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
 #ifdef VH_STAMPS
@@ -70,56 +58,7 @@ struct GemmArgs {
 #define STAMP(k)
 #endif
 
-enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2, EPI_ACC64 = 3,
-       EPI_FIXUP = 4 /* split-K slabs + the last-arriving slice of a column block sums them (skinny kernel) */,
-       EPI_SLAB2 = 5 /* two K slices, each leaves its partial (slice 0: + bias + residual) in its own slab */ };
-
-// ---- accumulator form of the residual stream (decode step) ---------------------------------------
-// The split-K slices of linear_2 add their partial sums straight onto an fp64 copy of the residual
-// stream with hardware atomics, and the add is made EXACT: every addend is first rounded to a multiple
-// of 2^-32 ((v + 1.5·2^20) − 1.5·2^20 in fp64), so as long as |sum| < 2^21 the 53-bit sums carry no
-// rounding at all and the result does not depend on arrival order — bitwise reproducible without the
-// separate reduce launch.  Consumers read the fp64 rows (X64 & 1) or consume-and-clear them as a
-// residual (X64 & 2).
-#define VH_GRID_MAGIC 1572864.0
-__device__ __forceinline__ f32x4 ld4(const double* p) {
-    typedef double d64x2 __attribute__((ext_vector_type(2)));
-    const d64x2 lo = *reinterpret_cast<const d64x2*>(p), hi = *reinterpret_cast<const d64x2*>(p + 2);
-    return f32x4{(float)lo.x, (float)lo.y, (float)hi.x, (float)hi.y};
-}
-
-// Agent-scope relaxed accesses (global_store / global_load with sc1): written through to / read from the
-// memory side, past the per-XCD L2s, so workgroups on different XCDs exchange data INSIDE one launch without the
-// full-cache fences (__threadfence() = buffer_wbl2 + buffer_inv: measured 24 us per launch here, every wave of
-// 256 workgroups writing back and invalidating a whole L2).  Ordering is by s_waitcnt vmcnt(0) (gfx9 counts
-// stores in vmcnt) + the ticket atomic.
-__device__ __forceinline__ void st4_agent(float* p, f32x4 v) {
-    uint64_t* q = reinterpret_cast<uint64_t*>(p);
-    const uint64_t lo = ((uint64_t)__float_as_uint(v.y) << 32) | __float_as_uint(v.x);
-    const uint64_t hi = ((uint64_t)__float_as_uint(v.w) << 32) | __float_as_uint(v.z);
-    __hip_atomic_store(q, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ f32x4 ld4_agent(const float* p) {
-    const uint64_t* q = reinterpret_cast<const uint64_t*>(p);
-    const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return f32x4{__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)),
-                 __uint_as_float((uint32_t)hi), __uint_as_float((uint32_t)(hi >> 32))};
-}
-
-// (value, tag) pairs: the consumer of a stage output spins on the DATA itself — a pair is one aligned 64-bit access,
-// so a value is never seen without its tag — instead of waiting at a barrier (NCCL's "LL" protocol): one memory-side
-// hop between producer and consumer instead of the three or more of a counter barrier.
-__device__ __forceinline__ void ll_store4(float* ll, f32x4 v, uint32_t tag) {
-    uint64_t* q = reinterpret_cast<uint64_t*>(ll);
-    const uint64_t t = (uint64_t)tag << 32;
-    __hip_atomic_store(q, t | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, t | __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 2, t | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 3, t | __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-#define LL_SPIN_LIMIT 40000
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2 };
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
 template <int EPI>
@@ -818,39 +757,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //     2 = folded (vh_ln_fold): the products run on the raw rows against W∘gamma while the statistics
 //         are computed beside them, and the epilogue applies rstd·(acc − mean·c1) + c2 — no
 //         statistics → normalise → MFMA dependency, one workgroup barrier instead of two.
-// X64: bit 0 = the A operand is the fp64 accumulator form (lda in doubles); bit 1 = the residual is
-//      the fp64 accumulator form (ldr in doubles) and is cleared once read, ready for the next
-//      EPI_ACC64 launch.  EPI_ACC64: a.out is that fp64 buffer (ldo in doubles); slice 0 also adds the
-//      fp32 bias and residual.
-//      bit 2 = the A operand is the TWO-SLAB form of the residual stream (row = slab0[row] + slab1[row],
-//      slab 1 at element offset a.s2): linear_2 runs as two K slices whose partials stay apart
-//      (EPI_SLAB2; slice 0 carries bias + residual) and the consumers add the two on load — no reduce
-//      launch in the decode step; bit 3 = the residual is in that form.
-// Virtual block coordinates: the body runs as a kernel of its own (gemm_skinny_fast: the launch grid) or as one
-// stage of the persistent decode-chain kernel (decode_chain_kernel: work items mapped onto resident workgroups).
-struct VB { int x, y, z, ny, nz; };
-
-// COH (decode_chain_kernel): bit 0 = the A operand rows were produced by OTHER workgroups of the SAME launch and
-// are read in the flag-in-data form (spin until every pair carries a.tag_in; the weights are requested first, so
-// their latency hides under the wait); bit 1 = the results go out in that form (a.tag_out) for later stages.
-#define LL_IN(p) (a.ll_in + 2 * (reinterpret_cast<const float*>(p) - a.a_org))
-#define STX(p, v) do { if (COH & 2) ll_store4(a.ll_out + 2 * ((p) - a.out_org), (v), a.tag_out); else st4((p), (v)); } while (0)
-
-template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64, int COH>
-__device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) {
-    using AT = typename std::conditional<(X64 & 1) != 0, double, float>::type;
-    // Row groups (vb.nz > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
+template <int MT, int NW, int EPI, int PW, int LN, int NJ>
+__device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
+    // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
-    int row0 = 0;                                          // first row of this workgroup's group in the whole problem
-    if (vb.nz > 1) {
-        const int r0 = vb.z * a.rg_rows;
-        row0 = r0;
-        a.A = reinterpret_cast<const float*>(reinterpret_cast<const AT*>(a.A) + (int64_t)r0 * a.lda);
-        if (a.res) {
-            if (X64 & 2) a.res = reinterpret_cast<const float*>(reinterpret_cast<const double*>(a.res) + (int64_t)r0 * a.ldr);
-            else a.res += (int64_t)r0 * a.ldr;
-        }
+    if (gridDim.z > 1) {
+        const int r0 = blockIdx.z * a.rg_rows;
+        a.A += (int64_t)r0 * a.lda;
+        if (a.res) a.res += (int64_t)r0 * a.ldr;
         a.out += (int64_t)r0 * a.ldo;
         if (EPI == EPI_QKV) {                 // T == 1 (host check): row = batch index
             a.kc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
@@ -863,27 +778,22 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    const int n0 = vb.x * 16;
-    const int koff = vb.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
+    const int n0 = blockIdx.x * 16;
+    const int koff = blockIdx.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
     const float* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
-    const AT* xp[MT];
+    const float* xp[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        xp[mt] = reinterpret_cast<const AT*>(a.A) + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
+    for (int mt = 0; mt < MT; ++mt) xp[mt] = a.A + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
     const float* gp = LN == 1 ? ln.gamma + koff : nullptr;
     const float* bp = LN == 1 ? ln.beta + koff : nullptr;
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
-    f32x4 xf2[(X64 & 4) ? PW : 1][MT];              // slab 1 of a two-slab operand, added before the MFMAs
     auto issue = [&](int kbase) {
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
             wf[c] = ld4(wp + kbase + 16 * c);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (!(COH & 1)) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
-                if (X64 & 4) xf2[c][mt] = ld4(xp[mt] + a.s2 + kbase + 16 * c);
-            }
+            for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
             if (LN == 1) {
                 gm[c] = ld4(gp + kbase + 16 * c);
                 bt[c] = ld4(bp + kbase + 16 * c);
@@ -897,15 +807,9 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
     f32x4 v[NJ];
     auto ln_load = [&](int r0) {
         const int row = (r0 * NW + w) * 4 + g;
-        const AT* xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
+        const float* xr = a.A + (int64_t)min(row, a.M - 1) * a.lda + 4 * i;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            v[jj] = ld4(xr + 64 * jj);                    // (COH & 1: the rows arrive as pairs, read below)
-        }
-        if (X64 & 4) {
-#pragma unroll
-            for (int jj = 0; jj < NJ; ++jj) v[jj] += ld4(xr + a.s2 + 64 * jj);
-        }
+        for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
     };
     auto ln_reduce = [&](int r0) {
         // DPP row g of the wave reduces activation row 4*w + g (two-pass mean / centred variance)
@@ -924,76 +828,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
         if (i == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
     };
     STAMP(0);
-    if (COH & 1) {
-        // weights first (no dependence on this launch's producers), then wait for the activation pairs
-        static_assert(!(COH & 1) || ((!LN || (16 * MT + 4 * NW - 1) / (4 * NW) == 1)), "LL inputs: one LayerNorm round");
-        issue(0);
-        // Cheap pre-poll by ONE wave: a sentinel pair per 16-column block of the K range this workgroup reads (the
-        // grain of the producing stage's work items), first and last row — 64 loads per workgroup and iteration
-        // instead of every lane re-reading all of its fragments (that storm, 6 M loads per iteration chip-wide,
-        // starved the producers).  The validated load below still checks every pair it uses.
-        {
-            if (w == 0) {
-                const int k_lo = vb.y * a.k_len, nblk = (LN ? a.K : a.k_len) / 16;     // LN reads whole rows
-                const int blk = lane & 31, rsel = lane >> 5;
-                const float* sp = reinterpret_cast<const float*>(a.A) + (int64_t)(rsel ? a.M - 1 : 0) * a.lda +
-                                  (LN ? 0 : k_lo) + 16 * min(blk, nblk - 1);
-                const uint64_t* q = reinterpret_cast<const uint64_t*>(LL_IN(sp));
-                // an earlier timeout is final: later waits give up at once (the results are void anyway)
-                int spins = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
-                for (;;) {
-                    const uint64_t pr = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((uint32_t)(pr >> 32) == a.tag_in)) break;
-                    if (++spins > LL_SPIN_LIMIT) break;             // the validated load below reports the timeout
-                    __builtin_amdgcn_s_sleep(8);
-                }
-            }
-            __syncthreads();
-        }
-        // The pairs are read through the caches, as two 16-byte loads per quad whose (value, tag) words are taken apart
-        // at once.  Safe: the caches were invalidated at the kernel boundary and nothing of this launch has read these
-        // lines before the sentinel showed their producers done (and the lines are then shared by the workgroups of an
-        // XCD: agent-scope loads of rows that 128 workgroups share fetch every 8 bytes from the memory side again,
-        // 10 us per stage); a straggler — a line fetched a moment too early fails its tag — is handled by invalidating
-        // the caches and reading again.  The LayerNorm row first (its statistics go to LDS, its registers are free
-        // again), then the fragments: held as raw pairs, all at once, inside a retry loop with two kinds of load, this
-        // block made the persistent kernel need 256 VGPRs and spill 399 more (round 2's first measurements of it).
-        bool ok = true;
-        auto take = [&](const float* ll, f32x4& val) {
-            const f32x4 lo = ld4(ll), hi = ld4(ll + 4);
-            val = f32x4{lo.x, lo.z, hi.x, hi.z};
-            // (no short-circuit: four compares and three ands, not four branches)
-            ok = (int)ok & (int)(__float_as_uint(lo.y) == a.tag_in) & (int)(__float_as_uint(lo.w) == a.tag_in) &
-                 (int)(__float_as_uint(hi.y) == a.tag_in) & (int)(__float_as_uint(hi.w) == a.tag_in);
-        };
-        const int ln_row = w * 4 + g;                                   // ROUNDS == 1 (static_assert above)
-        const AT* ln_xr = reinterpret_cast<const AT*>(a.A) + (int64_t)min(ln_row, a.M - 1) * a.lda + 4 * i;
-        int spins = __hip_atomic_load(a.err_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
-#pragma unroll 1
-        for (;;) {
-            ok = true;
-            if (LN) {
-#pragma unroll
-                for (int jj = 0; jj < NJ; ++jj) take(LL_IN(ln_xr + 64 * jj), v[jj]);
-                ln_reduce(0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int c = 0; c < PW; ++c)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) take(LL_IN(xp[mt] + 16 * c), xf[c][mt]);
-            if (__builtin_expect(__all(ok), 1)) break;
-            if (++spins > LL_SPIN_LIMIT) {              // bounded: flag the error and go on (garbage out, no hang)
-                if (lane == 0) atomicCAS(a.err_word, 0u, 0x80000000u | (a.tag_in & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff));   // the first timeout stays
-                break;
-            }
-            __builtin_amdgcn_s_sleep(16);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // drop the stale lines
-        }
-    } else {
-        if (LN) ln_load(0);
-        issue(0);
-    }
+    if (LN) ln_load(0);
+    issue(0);
     // Epilogue operands (bias / residual / cache position) are fetched NOW by the lanes that will
     // finalise (wave w finalises m-tile w): loaded in the epilogue they would add one more
     // dependent memory round trip to a kernel that is nothing but round trips.
@@ -1005,21 +841,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
         if (LN == 2) {                       // c2 carries the bias
             e_c1 = ld4(ln.c1 + en);
             e_bias = ld4(ln.c2 + en);
-        } else if ((EPI == EPI_PLAIN || EPI == EPI_FIXUP) && a.bias) e_bias = ld4(a.bias + en);
-        if (EPI == EPI_FIXUP && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
-        if (EPI == EPI_PLAIN && a.res) {
-            if (X64 & 2) e_res = ld4(reinterpret_cast<const double*>(a.res) + (int64_t)em * a.ldr + en);
-            else e_res = ld4(a.res + (int64_t)em * a.ldr + en);
-            if (X64 & 8) e_res += ld4(a.res + a.s2 + (int64_t)em * a.ldr + en);
-        }
-        if (EPI == EPI_SLAB2 && vb.y == 0) {
-            if (a.bias) e_bias = ld4(a.bias + en);
-            if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
-        }
-        if (EPI == EPI_ACC64 && vb.y == 0) {
-            if (a.bias) e_bias = ld4(a.bias + en);
-            if (a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
-        }
+        } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
+        if (EPI == EPI_PLAIN && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
         if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1027,7 +850,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
 
     float mean[MT], rstd[MT];
     if (LN) {
-        if (!(COH & 1)) ln_reduce(0);                       // (pairs: done where the rows were read)
+        ln_reduce(0);
 #pragma unroll 1
         for (int r0 = 1; r0 < ROUNDS; ++r0) {
             ln_load(r0);
@@ -1063,12 +886,6 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
                                     ld4(ln.ada_shift + koff + kbase + 16 * c);
                 }
         }
-        if (X64 & 4) {
-#pragma unroll
-            for (int c = 0; c < PW; ++c)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[c][mt] += xf2[c][mt];
-        }
 #pragma unroll
         for (int c = 0; c < PW; ++c)
 #pragma unroll
@@ -1096,25 +913,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
             sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
             if (EPI == EPI_QKV) sacc += e_bias;
         }
-        if (EPI == EPI_ACC64) {
-            if (fin) {                       // N % 16 == 0 (host check): every column group is whole
-                double* dst = reinterpret_cast<double*>(a.out) + (int64_t)em * a.ldo + en;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // e_bias / e_res are zero except in slice 0
-                    const double t = (double)sacc[j] + ((double)e_bias[j] + (double)e_res[j]);
-                    unsafeAtomicAdd(dst + j, (t + VH_GRID_MAGIC) - VH_GRID_MAGIC);
-                }
-            }
-        } else if (EPI == EPI_SLAB2) {
-            // slice vb.y's partial into its own slab; slice 0 carries bias + residual (zeros otherwise)
-            if (fin) st4(a.out + (int64_t)vb.y * a.s2 + (int64_t)em * a.ldo + en, (sacc + e_bias) + e_res);
-        } else if (EPI == EPI_FIXUP) {
-            // raw partial of K slice vb.y (N % 16 == 0 and every row group whole or guarded by fin)
-            if (fin) st4_agent(a.slab + ((int64_t)vb.y * a.M + em) * a.lds + en, sacc);
-        } else if (EPI == EPI_PARTIAL && (COH & 2)) {    // slab of K slice vb.y, read back by other workgroups of this launch
-            if (fin) STX(a.out + ((int64_t)vb.y * a.M + em) * a.ldo + en, sacc);
-        } else if (!fin || EPI == EPI_PARTIAL) {
+        if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
             sacc += e_bias;
@@ -1122,85 +921,32 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const VB vb) 
                 sacc.x = gelu_erf(sacc.x); sacc.y = gelu_erf(sacc.y);
                 sacc.z = gelu_erf(sacc.z); sacc.w = gelu_erf(sacc.w);
             }
-            STX(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
-            if ((X64 & 2) && a.res) {        // the accumulator row segment is consumed: clear it
-                typedef double d64x2 __attribute__((ext_vector_type(2)));
-                double* rp = reinterpret_cast<double*>(const_cast<float*>(a.res)) + (int64_t)em * a.ldr + en;
-                *reinterpret_cast<d64x2*>(rp) = d64x2{0.0, 0.0};
-                *reinterpret_cast<d64x2*>(rp + 2) = d64x2{0.0, 0.0};
-            }
+            st4(a.out + (int64_t)em * a.ldo + en, sacc + e_res);
         } else {  // EPI_QKV with the cache position already in a register
             const int which = en / a.d_model, c = en - which * a.d_model;
-            if (EPI == EPI_QKV && a.ll_out && a.cl0) {         // pipelined decode: publish through the (value, tag) block
-                const uint32_t ptag = ((uint32_t)(a.cl0[0] + 1) * 64u + a.tag_out) * 8u + 5u;
-                ll_store4(a.ll_out + 2 * (((int64_t)which * a.ll_rows + row0 + em) * a.d_model + c), sacc, ptag);
-            }
             if (which == 0) {
-                if (!(EPI == EPI_QKV && a.ll_out && a.cl0)) STX(a.out + (int64_t)em * a.ldo + c, sacc);
+                st4(a.out + (int64_t)em * a.ldo + c, sacc);
             } else {
                 const int head = c / VH_HEAD_DIM, e = c - head * VH_HEAD_DIM;
                 const int b = em / a.T, t = em - b * a.T;
                 float* base = which == 1 ? a.kc : a.vc;
-                STX(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
+                st4(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
             }
-        }
-    }
-    if (EPI == EPI_FIXUP) {
-        // Split-K without a second launch: every slice publishes its slab (release), takes a ticket on its
-        // column block's counter, and the LAST slice to arrive adds all slabs IN SLICE ORDER — the sum does not
-        // depend on who is last, so the result is bitwise reproducible — and applies bias + residual.  No slice
-        // waits for another (no spinning): a workgroup that is not last simply ends.
-        __shared__ int s_ticket;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): this wave's write-through slab stores are done
-        __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(a.counters + vb.x, 1);
-        __syncthreads();
-        if (s_ticket != vb.ny - 1) return;
-        if (tid == 0) a.counters[vb.x] = 0;          // ready for the next launch (graph replay)
-        if (tid < MT * 64 && fin) {
-            const float* p = a.slab + (int64_t)em * a.lds + en;
-            const int64_t stride = (int64_t)a.M * a.lds;
-            f32x4 part[16];
-#pragma unroll
-            for (int sidx = 0; sidx < 16; ++sidx)
-                part[sidx] = sidx < vb.ny ? ld4_agent(p + sidx * stride) : f32x4{0.f, 0.f, 0.f, 0.f};
-            f32x4 tot = part[0];
-#pragma unroll
-            for (int sidx = 1; sidx < 16; ++sidx) tot += part[sidx];
-            tot += e_bias;
-            if (a.act == VH_ACT_GELU_ERF) {
-                tot.x = gelu_erf(tot.x); tot.y = gelu_erf(tot.y); tot.z = gelu_erf(tot.z); tot.w = gelu_erf(tot.w);
-            }
-            st4(a.out + (int64_t)em * a.ldo + en, tot + e_res);
         }
     }
     STAMP(5);
 }
 
 
-template <int MT, int NW, int EPI, int PW, int LN, int NJ, int X64 = 0>
+template <int MT, int NW, int EPI, int PW, int LN, int NJ>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
                                                             int hM, int hN, GemmArgs a, LnFuse ln) {
     // The operands every wave needs for its first loads travel as leading scalar arguments: with
     // -mllvm -amdgpu-kernarg-preload-count the command processor places them in SGPRs at dispatch, so the
     // weight / activation loads are issued without first waiting for a kernarg s_load round trip.
     a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
-    skinny_body<MT, NW, EPI, PW, LN, NJ, X64, 0>(a, ln, VB{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
-                                                                (int)gridDim.y, (int)gridDim.z});
+    skinny_body<MT, NW, EPI, PW, LN, NJ>(a, ln);
 }
-
-// Pipelined decode: the out-projection whose A rows — the attention output — arrive as (value, tag) pairs from a
-// vh_attn_decode_pipe launch that runs on ANOTHER stream: this launch requests its weights, then waits (bounded) for
-// the pairs.  a.tag_in carries the layer on entry; the step comes from cache_len[0] (stable on this stream).
-template <int NW, int PW>
-__global__ __launch_bounds__(NW * 64) void gemm_skinny_ll_in(const float* hW, int hK, int hM, int hN, const int32_t* cl0,
-                                                             GemmArgs a, LnFuse ln) {
-    a.W = hW; a.K = hK; a.k_len = hK; a.M = hM; a.N = hN;
-    a.tag_in = ((uint32_t)(cl0[0] + 1) * 64u + a.tag_in) * 8u + 6u;
-    skinny_body<1, NW, EPI_PLAIN, PW, 0, 1, 0, 1>(a, ln, VB{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z,
-                                                            (int)gridDim.y, (int)gridDim.z});
-}
-
 // =============================================================================================
 // Split-K for the wide-K skinny GEMM (linear_2: K = dff).  One workgroup can pull only ~20-30 GB/s
 // through its L1, and with K = 2048 a 16-column workgroup needs the whole (M, K) activation block
@@ -1254,11 +1000,9 @@ static int splitk_plan(int M, int N, int K) {
     return splits >= 2 ? splits : 0;
 }
 
-#define VH_WS_COUNTER_BYTES 4096   // arrival counters of the single-launch split-K (one int per column block)
-
 extern "C" size_t vh_linear_ws_bytes(int M, int N, int K) {
     const int splits = splitk_plan(M, N, K);
-    return splits ? VH_WS_COUNTER_BYTES + (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
+    return splits ? (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
 }
 
 // =============================================================================================
@@ -1291,11 +1035,8 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
 #define SKINNY_ARGS(g) (g).A, (g).W, (g).lda, (g).K, (g).k_len, (g).M, (g).N
 
 template <int EPI>
-static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, int x64 = 0) {
+static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s) {
     if (a.M == 0) return VH_OK;
-    VH_REQUIRE(x64 == 0 || (a.M <= 64 && a.K <= 1024 && a.K % 128 == 0), VH_EUNSUPPORTED,
-               "%s: the fp64 accumulator / two-slab forms are the decode path: M <= 64, K <= 1024, K %% 128 == 0 "
-               "(M=%d K=%d)", name, a.M, a.K);
     const bool train_epi = a.aux != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
         const int mt = (a.M + 15) / 16;
@@ -1305,68 +1046,24 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool fold = ln.c1 != nullptr;
         // one workgroup per (16 columns, 16 rows) instead of (16 columns, all rows): see the kernel
         const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && (!wide || a.K % 2048 == 0) &&
-                               EPI != EPI_PARTIAL && EPI != EPI_ACC64 && (EPI != EPI_QKV || a.T == 1);
+                               EPI != EPI_PARTIAL && (EPI != EPI_QKV || a.T == 1);
         GemmArgs ag = a;                  // groups of 16 rows, or of 8 while that keeps the grid within the CUs
-        const int slices = EPI == EPI_SLAB2 ? 2 : 1;
         if (rowgroups) {
-            ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) * slices <= 256) ? 8 : 16;
+            ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) <= 256) ? 8 : 16;
             grid.z = (a.M + ag.rg_rows - 1) / ag.rg_rows;
         }
-        if constexpr (EPI == EPI_SLAB2) {   // two K slices of k_len = K / 2 (a multiple of 1024): 16 waves x 4 steps per pass
-            grid.y = 2;
-            if (rowgroups || mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
-            else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
-            else hipLaunchKernelGGL((gemm_skinny_fast<4, 16, EPI_SLAB2, 4, 0, 1, 0>), grid, dim3(1024), 0, s, SKINNY_ARGS(ag), ag, ln);
-            VH_CHECK_LAUNCH(name);
-            return VH_OK;
-        }
         // ---- compact fast path: K = 16*NW*PW*passes
-#define SFX(MT, NW, PW, LN, NJ, X) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, X>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln)
-#define SF(MT, NW, PW, LN, NJ) SFX(MT, NW, PW, LN, NJ, 0)
-#define SFX_MT(NW, PW, LN, NJ, X)                                              \
+#define SF(MT, NW, PW, LN, NJ) \
+    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln)
+#define SF_MT(NW, PW, LN, NJ)                                                  \
     do {                                                                       \
-        if (rowgroups) SFX(1, NW, PW, LN, NJ, X);                              \
-        else if (mt == 1) SFX(1, NW, PW, LN, NJ, X);                           \
-        else if (mt == 2) SFX(2, NW, PW, LN, NJ, X);                           \
-        else SFX(4, NW, PW, LN, NJ, X);                                        \
+        if (rowgroups) SF(1, NW, PW, LN, NJ);                                  \
+        else if (mt == 1) SF(1, NW, PW, LN, NJ);                               \
+        else if (mt == 2) SF(2, NW, PW, LN, NJ);                               \
+        else SF(4, NW, PW, LN, NJ);                                            \
         VH_CHECK_LAUNCH(name);                                                 \
         return VH_OK;                                                          \
     } while (0)
-#define SF_MT(NW, PW, LN, NJ) SFX_MT(NW, PW, LN, NJ, 0)
-        // ---- fp64 accumulator form of the residual stream (x64: 1 = A operand, 2 = consumed residual)
-        if (x64) {
-            if constexpr (EPI == EPI_QKV) {
-                VH_REQUIRE((x64 == 1 || x64 == 4) && fold, VH_EUNSUPPORTED,
-                           "%s: fp64 / two-slab rows need the folded LayerNorm", name);
-                if (x64 == 1) {
-                    if (a.K == 128) SFX_MT(8, 1, 2, 2, 1);
-                    if (a.K == 256) SFX_MT(8, 2, 2, 4, 1);
-                    if (a.K == 512) SFX_MT(8, 4, 2, 8, 1);
-                    if (a.K == 1024) SFX_MT(8, 4, 2, 16, 1);
-                } else {
-                    if (a.K == 128) SFX_MT(8, 1, 2, 2, 4);
-                    if (a.K == 256) SFX_MT(8, 2, 2, 4, 4);
-                    if (a.K == 512) SFX_MT(8, 4, 2, 8, 4);
-                    if (a.K == 1024) SFX_MT(8, 4, 2, 16, 4);
-                }
-            } else if constexpr (EPI == EPI_PLAIN) {
-                VH_REQUIRE(!has_ln, VH_EUNSUPPORTED, "%s: fp64 / two-slab rows or residual without LayerNorm only", name);
-#define X_BY_K(X)                                      \
-    do {                                               \
-        if (a.K % 512 == 0) SFX_MT(8, 4, 0, 1, X);     \
-        if (a.K % 256 == 0) SFX_MT(8, 2, 0, 1, X);     \
-        SFX_MT(8, 1, 0, 1, X);                         \
-    } while (0)
-                if (x64 == 1) X_BY_K(1);
-                else if (x64 == 2) X_BY_K(2);
-                else if (x64 == 4) X_BY_K(4);
-                else if (x64 == 8) X_BY_K(8);
-#undef X_BY_K
-            }
-            vh_set_error("%s: no fp64-form kernel for K=%d", name, a.K);
-            return VH_EUNSUPPORTED;
-        }
         if (has_ln) {  // K <= 1024 (check_gemm); statistics need K = 64*NJ
             if (fold) {
                 if (a.K == 128) SF_MT(8, 1, 2, 2);
@@ -1393,9 +1090,7 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             if (a.K % 1024 == 0) SF_MT(16, 4, 0, 1);
         }
 #undef SF_MT
-#undef SFX_MT
 #undef SF
-#undef SFX
         // ---- generic guarded kernel for every other K (multiple of 16)
 #define SK(MT, NW, CH, LN) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI, CH, LN>), grid, dim3(NW * 64), 0, s, a, ln)
@@ -1449,38 +1144,6 @@ extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float
                VH_EINVAL, "vh_linear_ex: ldo/ldr/ldp");
     if (int rc = check_gemm("vh_linear_ex", a, ln)) return rc;
     return launch_gemm<EPI_PLAIN>("vh_linear_ex", a, ln, (hipStream_t)stream);
-}
-
-// ---- two-slab form of the residual stream (decode step; see gemm_skinny_fast) ----------------------
-extern "C" int vh_linear_to_x2(const float* A, int lda, const float* W, const float* bias, const float* residual,
-                               int ldr, float* slabs, int lds, int64_t slab_stride, int M, int N, int K,
-                               void* stream) {
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = slabs; a.ldo = lds;
-    a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K / 2; a.s2 = slab_stride;
-    LnFuse none{};
-    VH_REQUIRE(M <= 64 && N % 16 == 0 && K % 2048 == 0, VH_EUNSUPPORTED,
-               "vh_linear_to_x2: decode path only: M <= 64, N %% 16 == 0, K %% 2048 == 0 (M=%d N=%d K=%d)", M, N, K);
-    VH_REQUIRE(lds >= N && (!residual || ldr >= N) && slab_stride >= (int64_t)M * lds && slab_stride % 4 == 0,
-               VH_EINVAL, "vh_linear_to_x2: lds/ldr/slab_stride");
-    if (int rc = check_gemm("vh_linear_to_x2", a, none)) return rc;
-    return launch_gemm<EPI_SLAB2>("vh_linear_to_x2", a, none, (hipStream_t)stream);
-}
-
-extern "C" int vh_linear_x2(const float* A, int a_two, int lda, const float* W, const float* bias,
-                            const float* residual, int r_two, int ldr, int64_t slab_stride, float* out, int ldo,
-                            int M, int N, int K, void* stream) {
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
-    a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K; a.s2 = slab_stride;
-    LnFuse none{};
-    VH_REQUIRE((a_two != 0) != (r_two != 0), VH_EINVAL,
-               "vh_linear_x2: exactly one of the operand rows and the residual is in the two-slab form");
-    VH_REQUIRE(!r_two || residual, VH_EINVAL, "vh_linear_x2: r_two without a residual");
-    VH_REQUIRE(ldo >= N && (!residual || ldr >= N) && slab_stride % 4 == 0 && slab_stride > 0, VH_EINVAL,
-               "vh_linear_x2: ldo/ldr/slab_stride");
-    if (int rc = check_gemm("vh_linear_x2", a, none)) return rc;
-    return launch_gemm<EPI_PLAIN>("vh_linear_x2", a, none, (hipStream_t)stream, a_two ? 4 : 8);
 }
 
 extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int ldq,
@@ -1566,122 +1229,24 @@ extern "C" int vh_linear_folded(const float* A, int lda, const float* Wf, const 
     return launch_gemm<EPI_PLAIN>("vh_linear_folded", a, ln, (hipStream_t)stream);
 }
 
-extern "C" int vh_linear_qkv_folded(const void* A, int a_form, int lda, const float* Wf, const float* c1,
-                                    const float* c2, float* q_out, int ldq, float* kcache, float* vcache,
+extern "C" int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                                    float* q_out, int ldq, float* kcache, float* vcache,
                                     const int32_t* cache_len, int B, int T, int d_model, int n_heads,
-                                    int S_max, float ln_eps, int64_t a_slab_stride, void* stream) {
-    VH_REQUIRE(a_form == 0 || a_form == 1 || a_form == 2, VH_EINVAL, "vh_linear_qkv_folded: a_form=%d", a_form);
-    VH_REQUIRE(a_form != 2 || (a_slab_stride > 0 && a_slab_stride % 4 == 0), VH_EINVAL,
-               "vh_linear_qkv_folded: the two-slab form needs a_slab_stride");
+                                    int S_max, float ln_eps, void* stream) {
     VH_REQUIRE(kcache && vcache, VH_EINVAL, "vh_linear_qkv_folded: null cache");
     VH_REQUIRE(B >= 0 && T >= 0 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
                "vh_linear_qkv_folded: d_model=%d must equal n_heads=%d x %d", d_model, n_heads, VH_HEAD_DIM);
     VH_REQUIRE(S_max >= T && ldq >= d_model, VH_EINVAL, "vh_linear_qkv_folded: S_max=%d < T=%d or ldq", S_max, T);
     VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache), VH_EALIGN, "vh_linear_qkv_folded: cache alignment");
     GemmArgs a{};
-    a.A = reinterpret_cast<const float*>(A); a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq;
+    a.A = A; a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq;
     a.M = B * T; a.N = 3 * d_model;
     a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE; a.kc = kcache; a.vc = vcache; a.cache_len = cache_len;
     a.T = T > 0 ? T : 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
     LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
     if (int rc = check_gemm("vh_linear_qkv_folded", a, ln)) return rc;
     if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
-    a.s2 = a_slab_stride;
-    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream, a_form == 1 ? 1 : (a_form == 2 ? 4 : 0));
-}
-
-// pipelined decode: the folded QKV launch that also publishes q and the newest K / V row as (value, tag) pairs
-extern "C" int vh_linear_qkv_folded_pipe(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
-                                         float* kcache, float* vcache, const int32_t* cache_len, int B, int d_model,
-                                         int n_heads, int S_max, float ln_eps, float* qkv_ll, int layer, void* stream) {
-    VH_REQUIRE(kcache && vcache && cache_len && qkv_ll, VH_EINVAL, "vh_linear_qkv_folded_pipe: null pointer");
-    VH_REQUIRE(B > 0 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM && layer >= 0 && layer < 64, VH_EUNSUPPORTED,
-               "vh_linear_qkv_folded_pipe: d_model=%d n_heads=%d layer=%d", d_model, n_heads, layer);
-    VH_REQUIRE(vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(qkv_ll), VH_EALIGN,
-               "vh_linear_qkv_folded_pipe: alignment");
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = Wf; a.out = qkv_ll; a.ldo = d_model;       // a.out unused for q in this form
-    a.M = B; a.N = 3 * d_model; a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE;
-    a.kc = kcache; a.vc = vcache; a.cache_len = cache_len; a.T = 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
-    a.ll_out = qkv_ll; a.cl0 = cache_len; a.ll_rows = B; a.tag_out = (uint32_t)layer;
-    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
-    if (int rc = check_gemm("vh_linear_qkv_folded_pipe", a, ln)) return rc;
-    if (int rc = check_folded("vh_linear_qkv_folded_pipe", a, ln)) return rc;
-    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded_pipe", a, ln, (hipStream_t)stream, 0);
-}
-
-extern "C" int vh_linear_ll_in(const float* a_ll, const float* W, const float* bias, const float* residual, int ldr,
-                               float* out, int ldo, int M, int N, int K, const int32_t* cache_len, int layer,
-                               uint32_t* err, void* stream) {
-    VH_REQUIRE(a_ll && W && out && cache_len && err, VH_EINVAL, "vh_linear_ll_in: null pointer");
-    VH_REQUIRE(M > 0 && M <= 64 && N > 0 && N % 16 == 0 && K == 512 && layer >= 0 && layer < 64, VH_EUNSUPPORTED,
-               "vh_linear_ll_in: decode path only: M <= 64, N %% 16 == 0, K == 512 (M=%d N=%d K=%d)", M, N, K);
-    GemmArgs a{};
-    a.A = a_ll; a.a_org = a_ll; a.ll_in = a_ll; a.lda = K;     // a.A is only an origin: element p lives at ll_in + 2 p
-    a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out; a.ldo = ldo;
-    a.M = M; a.N = N; a.K = K; a.k_len = K; a.act = VH_ACT_NONE;
-    a.tag_in = (uint32_t)layer; a.err_word = err;
-    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    if (int rc = check_gemm("vh_linear_ll_in", a, none)) return rc;
-    dim3 grid(N / 16);
-    a.rg_rows = ((int)grid.x * ((M + 7) / 8) <= 256) ? 8 : 16;
-    grid.z = (M + a.rg_rows - 1) / a.rg_rows;
-    hipLaunchKernelGGL((gemm_skinny_ll_in<8, 4>), grid, dim3(512), 0, (hipStream_t)stream, W, K, M, N, cache_len, a, none);
-    VH_CHECK_LAUNCH("vh_linear_ll_in");
-    return VH_OK;
-}
-
-// ---- fp64 accumulator form -----------------------------------------------------------------------
-extern "C" int vh_linear_acc64(const float* A, int lda, const float* W, const float* bias,
-                               const float* residual, int ldr, double* acc, int ldacc, int M, int N, int K,
-                               void* stream) {
-    GemmArgs a{};
-    a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr;
-    a.out = reinterpret_cast<float*>(acc); a.ldo = ldacc; a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE;
-    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    VH_REQUIRE(M <= 64 && N % 16 == 0 && K % 128 == 0, VH_EUNSUPPORTED,
-               "vh_linear_acc64: decode path only: M <= 64, N %% 16 == 0, K %% 128 == 0 (M=%d N=%d K=%d)", M, N, K);
-    VH_REQUIRE(ldacc >= N && ldacc % 2 == 0 && (!residual || ldr >= N), VH_EINVAL, "vh_linear_acc64: ldacc/ldr");
-    const int splits = splitk_plan(M, N, K);
-    a.k_len = splits ? K / splits : K;
-    a.ldo = 4;   // check_gemm looks at fp32 leading dimensions; the real one is restored below
-    if (int rc = check_gemm("vh_linear_acc64", a, none)) return rc;
-    a.ldo = ldacc;
-    if (M == 0) return VH_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const int mt = (M + 15) / 16;
-#define ACC(MT, NW, PW) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI_ACC64, PW, 0, 1>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(a), a, none)
-#define ACC_MT(NW, PW) do { if (mt == 1) ACC(1, NW, PW); else if (mt == 2) ACC(2, NW, PW); else ACC(4, NW, PW); } while (0)
-    if (splits) {           // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
-        dim3 grid((N + 15) / 16, splits);
-        ACC_MT(4, 4);
-    } else {
-        dim3 grid((N + 15) / 16, 1);
-        if (K % 512 == 0) ACC_MT(8, 4);
-        else if (K % 256 == 0) ACC_MT(8, 2);
-        else ACC_MT(8, 1);
-    }
-#undef ACC_MT
-#undef ACC
-    VH_CHECK_LAUNCH("vh_linear_acc64");
-    return VH_OK;
-}
-
-extern "C" int vh_linear_x64(const void* A, int a_f64, int lda, const float* W, const float* bias,
-                             double* residual64, int ldr, float* out, int ldo, int M, int N, int K,
-                             void* stream) {
-    GemmArgs a{};
-    a.A = reinterpret_cast<const float*>(A); a.lda = lda; a.W = W; a.bias = bias;
-    a.res = reinterpret_cast<const float*>(residual64); a.ldr = ldr; a.out = out;
-    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K;
-    LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    VH_REQUIRE((a_f64 != 0) != (residual64 != nullptr), VH_EUNSUPPORTED,
-               "vh_linear_x64: exactly one of the A rows / the residual is in fp64 accumulator form");
-    VH_REQUIRE(ldo >= N && (!residual64 || (ldr >= N && N % 16 == 0)), VH_EINVAL,
-               "vh_linear_x64: ldo/ldr < N, or a consumed residual with N %% 16 != 0");
-    if (int rc = check_gemm("vh_linear_x64", a, none)) return rc;
-    return launch_gemm<EPI_PLAIN>("vh_linear_x64", a, none, (hipStream_t)stream, a_f64 ? 1 : 2);
+    return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream);
 }
 
 extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,
@@ -1699,7 +1264,7 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     if (M == 0) return VH_OK;
     const int lds_ = (N + 3) / 4 * 4;
     GemmArgs part{};
-    float* slabs = (float*)((char*)workspace + VH_WS_COUNTER_BYTES);
+    float* slabs = (float*)workspace;
     part.A = A; part.lda = lda; part.W = W; part.out = slabs; part.ldo = lds_; part.M = M;
     part.N = N; part.K = K; part.act = VH_ACT_NONE; part.k_len = K / splits;
     LnFuse none{nullptr, nullptr, nullptr, nullptr, 0.f};
@@ -1726,24 +1291,10 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     }
     dim3 grid((N + 15) / 16, splits);
     const int mt = (M + 15) / 16;
-    // one launch: the last slice of a column block to arrive sums the slabs (N % 16 == 0: whole column groups;
-    // the counters live in the first VH_WS_COUNTER_BYTES of the workspace, zero before the first call and
-    // left zero by every call)
-    if (N % 16 == 0 && (int)grid.x * (int)sizeof(int) <= VH_WS_COUNTER_BYTES && splits <= 16 &&
-        vh_tuning(VH_TUNE_SPLITK_FIXUP) == 2) {
-        GemmArgs fx = part;
-        fx.slab = slabs; fx.lds = lds_; fx.counters = (int*)workspace;
-        fx.bias = bias; fx.res = residual; fx.ldr = ldr; fx.out = out; fx.ldo = ldo; fx.act = act;
-        if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
-        else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
-        else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_FIXUP, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(fx), fx, none);
-        VH_CHECK_LAUNCH("vh_linear_ws");
-        return VH_OK;
-    }
     // each slice: 4 waves x 4 k-steps of 16 = 256 k per pass
-    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
-    else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
-    else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, false, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
+    if (mt == 1) hipLaunchKernelGGL((gemm_skinny_fast<1, 4, EPI_PARTIAL, 4, 0, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
+    else if (mt == 2) hipLaunchKernelGGL((gemm_skinny_fast<2, 4, EPI_PARTIAL, 4, 0, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
+    else hipLaunchKernelGGL((gemm_skinny_fast<4, 4, EPI_PARTIAL, 4, 0, 1>), grid, dim3(256), 0, s, SKINNY_ARGS(part), part, none);
     const int items = M * (lds_ / 4);
     // small workgroups: the slabs (splits x 64 KB) are pulled through as many CUs as possible
     const int rb = vh_tuning(VH_TUNE_REDUCE_BLOCK) > 0 ? vh_tuning(VH_TUNE_REDUCE_BLOCK) : 128;
@@ -2047,248 +1598,5 @@ extern "C" int vh_transpose(const float* in, int ldi, int rows, int cols, float*
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (ldo + 31) / 32), dim3(256), 0, (hipStream_t)stream,
                        in, ldi, rows, cols, out, ldo);
     VH_CHECK_LAUNCH("vh_transpose");
-    return VH_OK;
-}
-
-// =============================================================================================
-// Persistent decode-chain kernel: everything of a decode step that lies between two attention launches —
-//   S1 out-projection + bias + residual          x_mid = x + attn Wo^T + bo            (modules.py:171,277)
-//   S2 LN2 (folded) + linear_1 + GELU            hid   = gelu(LN(x_mid) W1^T + b1)     (modules.py:221,278)
-//   S3 linear_2, K split into 256-wide slices    slab_s = hid[:, s] W2[:, s]^T
-//   S4 slab sum + bias + residual                x     = sum_s slab_s + b2 + x_mid     (modules.py:279)
-//   S5 LN1 (folded) + QKV of the NEXT layer with K/V appended in place (modules.py:146-157,271), or the head
-//      (valle_ar.py:158) after the last layer
-// — as ONE launch of one workgroup per CU, with NO barrier between the stages: a stage's output travels in the
-// flag-in-data form ((value, tag) pairs, one aligned 64-bit agent-scope access each) and its consumers spin on the
-// data itself, so the hand-over is one memory-side hop.
-//
-// Why this shape (measured): a dependent launch costs 4.6 us in the replayed decode graph whatever it
-// does; __threadfence() costs 24 us (every wave writes back and invalidates a whole per-XCD L2); a counter barrier
-// among the 256 workgroups with agent-scope accesses costs 3-5 us (publish, arrive, poll, read back: each a
-// memory-side round trip of about a microsecond) — the first version of this kernel, barriers between the stages,
-// took 37 us per layer against 24.6 us for one launch per stage.
-//
-// Progress: every workgroup runs its stage-1 items (which wait for nothing of this launch) before anything else, then
-// stage 2, ...; with one resident workgroup per CU every producer is running, so every wait ends.  All waits are
-// bounded (LL_SPIN_LIMIT): a timeout raises the error word and the workgroup carries on with what it has — the host
-// reads the word at the end of generate() and raises.  A tag is (decode position, layer, stage): unique per launch
-// and buffer, so data of an earlier launch is never mistaken for this one's.
-//
-// The stages are the SAME code as the stand-alone launches (skinny_body: same fragments, same summation order):
-// the chain reproduces the launch-per-stage step bit for bit (test).
-// =============================================================================================
-struct ChainArgs {
-    const float* attn; float* x; float* q;
-    float* xm_ll; float* hid_ll; float* slab_ll; float* x_ll;   // (value, tag) buffers: 2 floats per element
-    const float* wo; const float* bo;
-    const float* w1f; const float* w1c1; const float* w1c2;
-    const float* w2; const float* b2;
-    const float* wqf; const float* qc1; const float* qc2;    // next layer's folded QKV (nullptr after the last layer)
-    float* kc; float* vc; const int32_t* cache_len;
-    const float* proj; float* logits; int ldl, V;            // the head, used when wqf == nullptr
-    int B, d, dff, n_heads, S_max, layer;
-    float eps;
-    unsigned* sync;    // [1] error word, [2] != 0: leave wall-clock stamps at word 64 + 32 wg
-};
-
-#define CHAIN_THREADS 512
-
-// MT = ceil(B / 16); d_model = 512 (one K pass per stage: the LL input form loads its fragments once)
-template <int MT>
-__global__ __launch_bounds__(CHAIN_THREADS) void decode_chain_kernel(ChainArgs c) {
-    constexpr int PW = 4, NJ = 8;
-    unsigned* sync = c.sync;
-    const int wg = blockIdx.x, nwg = gridDim.x;
-    const LnFuse none{};
-    // (decode position, layer, stage): the position advances once per step, before the step's first launch
-    const uint32_t tag0 = ((uint32_t)(c.cache_len[0] + 1) * 64u + (uint32_t)c.layer) * 8u;
-    long long* stamps = sync[2] ? reinterpret_cast<long long*>(sync + 64) + (size_t)wg * 16 : nullptr;
-#define CHAIN_STAMP(k) do { if (stamps && threadIdx.x == 0) stamps[k] = wall_clock64(); } while (0)
-    CHAIN_STAMP(0);
-    if (stamps && threadIdx.x == 0) {                 // which XCD this workgroup runs on (HW_REG_XCC_ID, bits 3:0)
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        stamps[6] = xcc & 0xf;
-    }
-    // ---- S1: out-projection + bias + residual -> xm (LL, tag 1).  (d/16) column blocks x row groups of 8 (or 16) rows.
-    {
-        GemmArgs a{};
-        a.A = c.attn; a.lda = c.d; a.W = c.wo; a.bias = c.bo; a.res = c.x; a.ldr = c.d;
-        a.out = c.xm_ll; a.out_org = c.xm_ll; a.ll_out = c.xm_ll; a.tag_out = tag0 + 1; a.ldo = c.d;
-        a.M = c.B; a.N = c.d; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
-        const int nx = c.d / 16;
-        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
-        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
-        for (int it = wg; it < nx * nz; it += nwg) {
-            skinny_body<1, 8, EPI_PLAIN, PW, 0, 1, 0, 2>(a, none, VB{it % nx, 0, it / nx, 1, nz});
-            __syncthreads();
-        }
-    }
-    CHAIN_STAMP(1);
-    // ---- S2: folded LN2 + linear_1 + GELU: xm (tag 1) -> hid (LL, tag 2)
-    {
-        GemmArgs a{};
-        a.A = c.xm_ll; a.a_org = c.xm_ll; a.ll_in = c.xm_ll; a.tag_in = tag0 + 1; a.lda = c.d; a.W = c.w1f;
-        a.out = c.hid_ll; a.out_org = c.hid_ll; a.ll_out = c.hid_ll; a.tag_out = tag0 + 2; a.ldo = c.dff;
-        a.M = c.B; a.N = c.dff; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_GELU_ERF; a.err_word = sync + 1;
-        LnFuse ln{nullptr, nullptr, nullptr, nullptr, c.eps, c.w1c1, c.w1c2};
-        const int nx = c.dff / 16;
-        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
-        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
-        for (int it = wg; it < nx * nz; it += nwg) {
-            skinny_body<1, 8, EPI_PLAIN, PW, 2, NJ, 0, 3>(a, ln, VB{it % nx, 0, it / nx, 1, nz});
-            __syncthreads();
-        }
-    }
-    CHAIN_STAMP(2);
-    // ---- S3: linear_2 in K slices of 256: hid (tag 2) -> slabs [slice][B][d] (LL, tag 3)
-    const int slices = c.dff / 256;
-    {
-        GemmArgs a{};
-        a.A = c.hid_ll; a.a_org = c.hid_ll; a.ll_in = c.hid_ll; a.tag_in = tag0 + 2; a.lda = c.dff; a.W = c.w2;
-        a.out = c.slab_ll; a.out_org = c.slab_ll; a.ll_out = c.slab_ll; a.tag_out = tag0 + 3; a.ldo = c.d;
-        a.M = c.B; a.N = c.d; a.K = c.dff; a.k_len = 256; a.act = VH_ACT_NONE; a.err_word = sync + 1;
-        const int nx = c.d / 16;
-        for (int it = wg; it < nx * slices; it += nwg) {
-            skinny_body<MT, 8, EPI_PARTIAL, 2, 0, 1, 0, 3>(a, none, VB{it % nx, it / nx, 0, slices, 1});
-            __syncthreads();
-        }
-    }
-    CHAIN_STAMP(3);
-    // ---- S4: x = sum of the slabs (slice order: reproducible) + b2 + xm -> x (plain, the next launch's residual)
-    //          and x (LL, tag 4) for S5
-    {
-        const int groups = c.d / 4, items = c.B * groups;
-        const int64_t stride = (int64_t)c.B * c.d;
-        for (int idx = wg * CHAIN_THREADS + threadIdx.x; idx < items; idx += nwg * CHAIN_THREADS) {
-            const int m = idx / groups, n = (idx - m * groups) * 4;
-            const int64_t e = (int64_t)m * c.d + n;
-            int spins = __hip_atomic_load(sync + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? LL_SPIN_LIMIT : 0;
-            {   // cheap pre-poll: one pair of the last slice's slab
-                const uint64_t* q = reinterpret_cast<const uint64_t*>(c.slab_ll + 2 * (e + (slices - 1) * stride));
-                while ((uint32_t)(__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >> 32) != tag0 + 3 &&
-                       ++spins <= LL_SPIN_LIMIT)
-                    __builtin_amdgcn_s_sleep(8);
-                spins = spins > LL_SPIN_LIMIT ? LL_SPIN_LIMIT : 0;
-            }
-            // through the caches, (value, tag) words taken apart at once; a straggler: invalidate and read again
-            f32x4 acc, xmv;
-            bool ok;
-            auto take = [&](const float* ll, f32x4& val, uint32_t tag) {
-                const f32x4 lo = ld4(ll), hi = ld4(ll + 4);
-                val = f32x4{lo.x, lo.z, hi.x, hi.z};
-                ok = (int)ok & (int)(__float_as_uint(lo.y) == tag) & (int)(__float_as_uint(lo.w) == tag) &
-                     (int)(__float_as_uint(hi.y) == tag) & (int)(__float_as_uint(hi.w) == tag);
-            };
-#pragma unroll 1
-            for (;;) {
-                ok = true;
-                take(c.slab_ll + 2 * e, acc, tag0 + 3);
-#pragma unroll 1
-                for (int s0 = 1; s0 < slices; s0 += 4) {  // slice order, four slices in flight
-                    f32x4 part[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) take(c.slab_ll + 2 * (e + min(s0 + j, slices - 1) * stride), part[j], tag0 + 3);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (s0 + j < slices) acc += part[j];
-                }
-                take(c.xm_ll + 2 * e, xmv, tag0 + 1);
-                if (__builtin_expect(ok, 1)) break;
-                if (++spins > LL_SPIN_LIMIT) {
-                    atomicCAS(sync + 1, 0u, 0xC0000000u | ((tag0 + 3) & 0xfffffu) << 8 | (unsigned)(blockIdx.x & 0xff));
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(16);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            }
-            acc += ld4(c.b2 + n);
-            acc += xmv;
-            st4(c.x + e, acc);
-            ll_store4(c.x_ll + 2 * e, acc, tag0 + 4);
-        }
-    }
-    CHAIN_STAMP(4);
-    // ---- S5: x (tag 4) -> folded LN1 + QKV of the next layer (K/V appended at cache_len), or the head
-    if (c.wqf) {
-        GemmArgs a{};
-        a.A = c.x_ll; a.a_org = c.x_ll; a.ll_in = c.x_ll; a.tag_in = tag0 + 4; a.lda = c.d; a.W = c.wqf; a.out = c.q; a.ldo = c.d;
-        a.M = c.B; a.N = 3 * c.d; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
-        a.kc = c.kc; a.vc = c.vc; a.cache_len = c.cache_len; a.T = 1; a.S_max = c.S_max; a.d_model = c.d; a.n_heads = c.n_heads;
-        LnFuse ln{nullptr, nullptr, nullptr, nullptr, c.eps, c.qc1, c.qc2};
-        const int nx = 3 * c.d / 16;
-        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
-        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
-        for (int it = wg; it < nx * nz; it += nwg) {
-            skinny_body<1, 8, EPI_QKV, PW, 2, NJ, 0, 1>(a, ln, VB{it % nx, 0, it / nx, 1, nz});
-            __syncthreads();
-        }
-    } else {
-        GemmArgs a{};
-        a.A = c.x_ll; a.a_org = c.x_ll; a.ll_in = c.x_ll; a.tag_in = tag0 + 4; a.lda = c.d; a.W = c.proj; a.out = c.logits; a.ldo = c.ldl;
-        a.M = c.B; a.N = c.V; a.K = c.d; a.k_len = c.d; a.act = VH_ACT_NONE; a.err_word = sync + 1;
-        const int nx = (c.V + 15) / 16;
-        a.rg_rows = (nx * ((c.B + 7) / 8) <= nwg) ? 8 : 16;
-        const int nz = (c.B + a.rg_rows - 1) / a.rg_rows;
-        for (int it = wg; it < nx * nz; it += nwg) {
-            skinny_body<1, 8, EPI_PLAIN, PW, 0, 1, 0, 1>(a, none, VB{it % nx, 0, it / nx, 1, nz});
-            __syncthreads();
-        }
-    }
-    CHAIN_STAMP(5);
-}
-
-extern "C" size_t vh_decode_chain_ws_bytes(int B, int d_model, int dff) {
-    // (value, tag) buffers: x_mid (B, d), slabs (dff / 256, B, d), x (B, d), hidden (B, dff)
-    return 2 * ((size_t)(2 + dff / 256) * B * d_model + (size_t)B * dff) * sizeof(float);
-}
-
-extern "C" int vh_decode_chain(const float* attn, float* x, float* q, const float* wo, const float* bo,
-                               const float* w1f, const float* w1c1, const float* w1c2, const float* w2,
-                               const float* b2, const float* wqf, const float* qc1, const float* qc2, float* kcache,
-                               float* vcache, const int32_t* cache_len, const float* proj, float* logits, int ldl,
-                               int V, int B, int d_model, int dff, int n_heads, int S_max, int layer, float ln_eps,
-                               void* workspace, size_t workspace_bytes, uint32_t* sync, void* stream) {
-    VH_REQUIRE(attn && x && wo && bo && w1f && w1c1 && w1c2 && w2 && b2 && workspace && sync && cache_len, VH_EINVAL,
-               "vh_decode_chain: null pointer");
-    VH_REQUIRE((wqf != nullptr) != (proj != nullptr), VH_EINVAL,
-               "vh_decode_chain: exactly one of the next layer's QKV and the head");
-    VH_REQUIRE(!wqf || (qc1 && qc2 && q && kcache && vcache), VH_EINVAL, "vh_decode_chain: QKV stage pointers");
-    VH_REQUIRE(!proj || (logits && V > 0 && ldl >= V && ldl % 4 == 0), VH_EINVAL, "vh_decode_chain: head stage");
-    VH_REQUIRE(B > 0 && B <= 64 && d_model == 512 && d_model == n_heads * VH_HEAD_DIM && dff % 256 == 0 &&
-                   dff / 256 <= 16 && dff >= 256 && layer >= 0 && layer < 64,
-               VH_EUNSUPPORTED, "vh_decode_chain: B=%d d_model=%d dff=%d layer=%d (B <= 64, d_model = 512, dff a multiple "
-               "of 256 up to 4096, layer < 64)", B, d_model, dff, layer);
-    VH_REQUIRE(workspace_bytes >= vh_decode_chain_ws_bytes(B, d_model, dff) && vh_aligned16(workspace), VH_EINVAL,
-               "vh_decode_chain: workspace too small or unaligned");
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) {
-            n_cu = 0;
-            vh_set_error("vh_decode_chain: cannot read the CU count");
-            return VH_ELAUNCH;
-        }
-    }
-    ChainArgs c{};
-    float* ws = (float*)workspace;
-    const size_t bd = (size_t)B * d_model;
-    c.attn = attn; c.x = x; c.q = q;
-    c.xm_ll = ws; c.slab_ll = ws + 2 * bd; c.x_ll = c.slab_ll + 2 * (size_t)(dff / 256) * bd; c.hid_ll = c.x_ll + 2 * bd;
-    c.wo = wo; c.bo = bo; c.w1f = w1f; c.w1c1 = w1c1; c.w1c2 = w1c2; c.w2 = w2; c.b2 = b2;
-    c.wqf = wqf; c.qc1 = qc1; c.qc2 = qc2; c.kc = kcache; c.vc = vcache; c.cache_len = cache_len;
-    c.proj = proj; c.logits = logits; c.ldl = ldl; c.V = V;
-    c.B = B; c.d = d_model; c.dff = dff; c.n_heads = n_heads; c.S_max = S_max; c.layer = layer; c.eps = ln_eps; c.sync = sync;
-    // one workgroup per CU: all of them resident at once (consumers spin on their producers' data)
-    // (VH_TUNE_CHAIN_GRID: diagnostic — fewer workgroups, e.g. the 32 CUs of one XCD behind a CU-masked stream)
-    const int cap = vh_tuning(VH_TUNE_CHAIN_GRID) > 0 ? vh_tuning(VH_TUNE_CHAIN_GRID) : 256;
-    const dim3 grid(n_cu > cap ? cap : n_cu);
-    const int mt = (B + 15) / 16;
-    hipStream_t s = (hipStream_t)stream;
-    if (mt == 1) hipLaunchKernelGGL((decode_chain_kernel<1>), grid, dim3(CHAIN_THREADS), 0, s, c);
-    else if (mt == 2) hipLaunchKernelGGL((decode_chain_kernel<2>), grid, dim3(CHAIN_THREADS), 0, s, c);
-    else hipLaunchKernelGGL((decode_chain_kernel<4>), grid, dim3(CHAIN_THREADS), 0, s, c);
-    VH_CHECK_LAUNCH("vh_decode_chain");
     return VH_OK;
 }

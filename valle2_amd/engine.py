@@ -49,30 +49,10 @@ def _layer_params(layer):
             ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias)
 
 
-# Forms of the decode step's GEMM chain (A/B switches; every form is under the same parity tests):
 FOLD_LAYERNORM = os.environ.get('VALLE2_FOLD_LN', '1') != '0'   # LayerNorm folded into the QKV / linear_1
-                                                                 # weights (vh_ln_fold)
-PERSISTENT_CHAIN = os.environ.get('VALLE2_CHAIN', '0') == '1'   # the GEMM chain between two attention launches as ONE
-                                                                 # persistent launch, stages handing over through
-                                                                 # (value, tag) pairs (vh_decode_chain).  Off: measured
-                                                                 # 700 vs 617 us per step; bit-identical
-                                                                 # results, kept as an option; needs the folded weights,
-                                                                 # d_model = 512, dff % 256 == 0, dff <= 4096
-PIPELINED_ATTENTION = os.environ.get('VALLE2_PIPE', '0') == '1'  # decode attention on its own stream, launched a layer
-                                                                 # early: it requests its first keys while the previous
-                                                                 # layer's GEMM chain runs and takes q / k / v from
-                                                                 # (value, tag) pairs (vh_attn_decode_pipe); needs the
-                                                                 # folded weights; bit-identical results
-TWO_SLAB_RESIDUAL = os.environ.get('VALLE2_X2', '0') == '1'     # residual stream between layers as two fp32 slabs
-                                                                 # (linear_2's two K halves, added on load by the
-                                                                 # consumers: no split-K reduce launch).  Off:
-                                                                 # measured equal within noise (620 vs 617 us per
-                                                                 # step), DESIGN.md §3, kept as an option.
-ACC64_RESIDUAL = os.environ.get('VALLE2_ACC64', '0') == '1'     # residual stream in fp64 accumulator form
-                                                                 # (vh_linear_acc64: linear_2's K slices add
-                                                                 # onto it with exact atomics, no reduce launch).
-                                                                 # Off: measured 1.7 us per layer SLOWER at
-                                                                 # 12L/512d, kept as an option.
+                                                                 # weights (vh_ln_fold); without it the decode step
+                                                                 # normalises in the operand load and the FeedForward
+                                                                 # runs as linear_1 + split-K linear_2 + reduce
 
 
 _WEIGHTS_EPOCH = 0
@@ -224,32 +204,16 @@ class ArDecoder:
         self.logits = torch.zeros(batch, self.ldl, **f32)
         self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
         ws_bytes = _lib.lib().vh_linear_ws_bytes(batch, d, dff)
-        self.gemm_ws = torch.zeros(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None   # counters start at zero
+        self.gemm_ws = torch.empty(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
         self.sum_logprobs = torch.zeros(batch, **f32)
         self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
         self._folded = folded_layer_norms(model.transformer)   # kept alive: the table holds raw pointers
-        self.acc64 = bool(ACC64_RESIDUAL and self._folded is not None and d % 128 == 0 and dff % 128 == 0)
-        self.x64 = torch.zeros(batch, d, device=dev, dtype=torch.float64) if self.acc64 else None
-        self.xmid = torch.empty(batch, d, **f32) if self.acc64 else None
-        self.chain = bool(PERSISTENT_CHAIN and self._folded is not None and d == 512 and dff % 256 == 0
-                          and 256 <= dff <= 4096 and cfg.num_layers <= 64)
-        chain_bytes = _lib.lib().vh_decode_chain_ws_bytes(batch, d, dff) if self.chain else 0
-        self.chain_ws = torch.zeros(chain_bytes // 4, **f32) if self.chain else None     # tags start at 0 = never valid
-        self.chain_sync = torch.zeros(64 + 32 * 256, device=dev, dtype=torch.int32) if self.chain else None
-        if self.chain:
-            self.acc64 = False
-            self.x64 = self.xmid = None
-        self.x2 = bool(TWO_SLAB_RESIDUAL and not self.acc64 and not self.chain and self._folded is not None
-                       and dff % 2048 == 0 and d <= 1024 and d % 128 == 0)
-        self.xs = torch.zeros(2, batch, d, **f32) if self.x2 else None
-        self.pipe = bool(PIPELINED_ATTENTION and self._folded is not None and not (self.acc64 or self.chain or self.x2)
-                         and 2 <= cfg.num_layers <= 64 and d == 512)
-        self.qkv_ll = torch.zeros(3, batch, d, 2, **f32) if self.pipe else None          # tag 0 = never valid
-        self.attn_ll = torch.zeros(batch, d, 2, **f32) if self.pipe else None
-        self.pipe_err = torch.zeros(16 + 512, device=dev, dtype=torch.int32) if self.pipe else None
+        # FeedForward of a layer as one launch split over dim_feedforward + the slab reduce (vh_ffn_decode)
+        ffn_bytes = _lib.lib().vh_ffn_decode_ws_bytes(batch, d, dff) if self._folded is not None else 0
+        self.ffn_ws = torch.empty(ffn_bytes // 4, **f32) if ffn_bytes else None
         self._table = layer_table(model.transformer, cache, self._folded)
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
@@ -263,9 +227,7 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
-            sum_logprobs=ptr(self.sum_logprobs), x64=ptr(self.x64), xmid=ptr(self.xmid), xs=ptr(self.xs),
-            chain_ws=ptr(self.chain_ws), chain_ws_bytes=chain_bytes, chain_sync=ptr(self.chain_sync),
-            qkv_ll=ptr(self.qkv_ll), attn_ll=ptr(self.attn_ll), pipe_err=ptr(self.pipe_err))
+            sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes)
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:
@@ -273,21 +235,6 @@ class ArDecoder:
             raise _lib.VhError(f'vh_ar_decoder_create: {msg.decode() if msg else "failed"}')
         self._captured = False
         self.use_graph = use_graph
-
-    @property
-    def x_in(self):
-        """Where a step expects the current token's embedding (fp64 rows in accumulator form)."""
-        return self.x64 if self.acc64 else self.x
-
-    def check_chain(self):
-        """After a synchronisation: raise if a grid barrier of the persistent chain timed out (its workgroups were
-        not all resident, or a previous launch was cut short) — the decoded tokens are then not to be trusted."""
-        if self.chain and int(self.chain_sync[1].item()) != 0:
-            raise _lib.VhError('vh_decode_chain: a wait on a stage hand-over timed out (the launch needs one resident workgroup per '
-                               'CU); set VALLE2_CHAIN=0 to decode with one launch per stage')
-        if self.pipe and int(self.pipe_err[0].item()) != 0:
-            raise _lib.VhError(f'vh_attn_decode_pipe: the wait for a query timed out (word {int(self.pipe_err[0].item()) & 0xffffffff:#x}); '
-                               'set VALLE2_PIPE=0 to decode with attention in stream order')
 
     def close(self):
         if getattr(self, '_h', None):
@@ -302,12 +249,12 @@ class ArDecoder:
         kernels.linear(hidden_last, m[0], out=self.logits[:, : self.V])
         if self.sampling[0] == 1:
             kernels.greedy_step(self.logits, self.V, self._desc.eos, self.codes, self.eos_count, m[1], m[2],
-                                self.audio_pos, self.cache_len, self.x_in, pos_base=self.pos_base)
+                                self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
         else:
             top_k, top_p, temp, seed = self.sampling
             kernels.sample_step(self.logits, self.V, self._desc.eos, top_k, top_p, temp, seed, self.codes,
                                 self.eos_count, self.sum_logprobs, m[1], m[2], self.audio_pos,
-                                self.cache_len, self.x_in, pos_base=self.pos_base)
+                                self.cache_len, self.x, pos_base=self.pos_base)
 
     def run(self, n_steps):
         """Enqueue n_steps decode steps on the current stream (graph replay when enabled)."""

@@ -133,7 +133,7 @@ def linear_ws(a, w, bias=None, residual=None, out=None, act=ACT_NONE, workspace=
         raise _lib.VhError('linear_ws: residual shape')
     need = _lib.lib().vh_linear_ws_bytes(M, N, K)
     if workspace is None and need:
-        workspace = torch.zeros(need // 4, device=a.device, dtype=torch.float32)   # counters start at zero
+        workspace = torch.empty(need // 4, device=a.device, dtype=torch.float32)
     if need and workspace.numel() * 4 < need:
         raise _lib.VhError(f'linear_ws: workspace of {workspace.numel() * 4} B < {need} B')
     check(_lib.lib().vh_linear_ws(
@@ -190,96 +190,45 @@ def linear_folded(a, folded, residual=None, out=None, act=ACT_NONE, eps=1e-5):
 
 
 def linear_qkv_folded(a, folded, q_out, kcache, vcache, B, T, n_heads, cache_len=None, eps=1e-5):
-    """`a`: (M, d) float32 / float64 rows, or a (2, M, d) float32 tensor = the two-slab form of the rows."""
     wf, c1, c2 = folded
-    form, stride = (1 if a.dtype == torch.float64 else 0), 0
-    if a.dim() == 3:
-        if a.shape[0] != 2 or not a.is_contiguous() or a.dtype != torch.float32:
-            raise _lib.VhError('linear_qkv_folded: the two-slab form is a contiguous (2, M, d) float32 tensor')
-        form, stride, a = 2, a.stride(0), a[0]
     M, d = a.shape
     S_max = kcache.shape[2]
     if M != B * T or tuple(wf.shape) != (3 * d, d) or tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM):
         raise _lib.VhError(f'linear_qkv_folded: shapes a={tuple(a.shape)} w={tuple(wf.shape)}')
     check(_lib.lib().vh_linear_qkv_folded(
-        _f32_or_f64(a, 'a').data_ptr(), form, a.stride(0), ptr(wf), ptr(c1), ptr(c2),
+        _dev_f32(a, 'a'), a.stride(0), ptr(wf), ptr(c1), ptr(c2),
         q_out.data_ptr(), q_out.stride(0), ptr(kcache), ptr(vcache), ptr(cache_len), B, T, d, n_heads, S_max,
-        eps, stride, stream()), 'vh_linear_qkv_folded')
+        eps, stream()), 'vh_linear_qkv_folded')
     return q_out
 
 
-def linear_to_x2(a, w, slabs, bias=None, residual=None):
-    """slabs (2, M, N) <- the two K halves of a @ w.T; slab 0 also carries bias + residual (decode rows)."""
-    M, K = a.shape
-    N = w.shape[0]
-    if tuple(slabs.shape) != (2, M, N) or not slabs.is_contiguous() or w.shape[1] != K or not w.is_contiguous():
-        raise _lib.VhError(f'linear_to_x2: a {tuple(a.shape)} w {tuple(w.shape)} slabs {tuple(slabs.shape)}')
-    if residual is not None and (tuple(residual.shape) != (M, N) or residual.stride(1) != 1):
-        raise _lib.VhError('linear_to_x2: residual shape')
-    check(_lib.lib().vh_linear_to_x2(_dev_f32(a, 'a'), a.stride(0), ptr(_f32(w, 'w')), ptr(bias),
-                                     _dev_f32(residual, 'residual') if residual is not None else None,
-                                     residual.stride(0) if residual is not None else 0, _dev_f32(slabs, 'slabs'), N,
-                                     slabs.stride(0), M, N, K, stream()), 'vh_linear_to_x2')
-    return slabs
+def ffn_decode_ws(M, d, dff, device):
+    n = _lib.lib().vh_ffn_decode_ws_bytes(M, d, dff)
+    return torch.empty(max(n, 16) // 4, device=device, dtype=torch.float32) if n else None
 
 
-def linear_x2(a, w, bias=None, residual=None, out=None):
-    """out = a @ w.T + bias + residual where exactly one of `a` / `residual` is a (2, M, ·) two-slab tensor."""
-    a_two, r_two = a.dim() == 3, residual is not None and residual.dim() == 3
-    if a_two == r_two:
-        raise _lib.VhError('linear_x2: exactly one of a / residual must be in the two-slab form')
-    two = a if a_two else residual
-    if two.shape[0] != 2 or not two.is_contiguous():
-        raise _lib.VhError('linear_x2: the two-slab operand must be a contiguous (2, M, ·) tensor')
-    a2 = a[0] if a_two else a
-    M, K = a2.shape
-    N = w.shape[0]
-    if w.shape[1] != K or not w.is_contiguous():
-        raise _lib.VhError('linear_x2: weight shape')
+def ffn_decode(x, folded, w2, b2=None, out=None, workspace=None, eps=1e-5):
+    """out = x + b2 + GELU(LN2(x) @ W1.T + b1) @ w2.T for M <= 64 decode rows (vh_ffn_decode); `folded` =
+    ln_fold(W1, ln2_gamma, ln2_beta, b1).  out may be x itself."""
+    wf, c1, c2 = folded
+    M, d = x.shape
+    dff = wf.shape[0]
+    if tuple(wf.shape) != (dff, d) or tuple(w2.shape) != (d, dff) or not w2.is_contiguous() or not wf.is_contiguous():
+        raise _lib.VhError(f'ffn_decode: x {tuple(x.shape)} w1f {tuple(wf.shape)} w2 {tuple(w2.shape)}')
+    if c1.numel() != dff or c2.numel() != dff or (b2 is not None and b2.numel() != d):
+        raise _lib.VhError('ffn_decode: c1 / c2 / b2 sizes')
     if out is None:
-        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
-    r2 = None if residual is None else (residual[0] if r_two else residual)
-    if r2 is not None and tuple(r2.shape) != (M, N):
-        raise _lib.VhError('linear_x2: residual shape')
-    check(_lib.lib().vh_linear_x2(_dev_f32(a2, 'a'), int(a_two), a2.stride(0), ptr(_f32(w, 'w')), ptr(bias),
-                                  _dev_f32(r2, 'residual') if r2 is not None else None, int(r_two),
-                                  r2.stride(0) if r2 is not None else 0, two.stride(0), _dev_f32(out, 'out'),
-                                  out.stride(0), M, N, K, stream()), 'vh_linear_x2')
-    return out
-
-
-def _f32_or_f64(t, name):
-    if t.dtype not in (torch.float32, torch.float64) or not t.is_cuda or t.stride(-1) != 1:
-        raise _lib.VhError(f'{name}: expected a row-major fp32 / fp64 device tensor, got {t.dtype} on {t.device}')
-    return t
-
-
-def linear_acc64(a, w, acc, bias=None, residual=None):
-    """acc (M,N) float64 += a @ w.T (+ bias + residual): split-K with exact fp64 atomics (reproducible)."""
-    M, K = a.shape
-    N = w.shape[0]
-    if acc.dtype != torch.float64 or tuple(acc.shape) != (M, N) or acc.stride(1) != 1:
-        raise _lib.VhError(f'linear_acc64: acc must be float64 ({M},{N}), got {acc.dtype} {tuple(acc.shape)}')
-    check(_lib.lib().vh_linear_acc64(
-        _f32(a, 'a').data_ptr(), a.stride(0), ptr(w), ptr(bias), ptr(residual),
-        residual.stride(0) if residual is not None else 0, acc.data_ptr(), acc.stride(0), M, N, K,
-        stream()), 'vh_linear_acc64')
-    return acc
-
-
-def linear_x64(a, w, bias=None, residual64=None, out=None):
-    """out = a @ w.T + bias [+ residual64, cleared as read].  Exactly one of `a` (float64 rows) and
-    `residual64` is in the fp64 accumulator form."""
-    M, K = a.shape
-    N = w.shape[0]
-    if out is None:
-        out = torch.empty(M, (N + 3) // 4 * 4, device=a.device, dtype=torch.float32)[:, :N]
-    if residual64 is not None and (residual64.dtype != torch.float64 or residual64.stride(1) != 1):
-        raise _lib.VhError('linear_x64: residual64 must be a row-major float64 tensor')
-    check(_lib.lib().vh_linear_x64(
-        _f32_or_f64(a, 'a').data_ptr(), int(a.dtype == torch.float64), a.stride(0), ptr(w), ptr(bias),
-        ptr(residual64), residual64.stride(0) if residual64 is not None else 0, out.data_ptr(),
-        out.stride(0), M, N, K, stream()), 'vh_linear_x64')
+        out = torch.empty(M, d, device=x.device, dtype=torch.float32)
+    if tuple(out.shape) != (M, d) or out.stride(1) != 1 or x.stride(1) != 1:
+        raise _lib.VhError('ffn_decode: x / out must be row-major (M, d)')
+    if workspace is None:
+        workspace = ffn_decode_ws(M, d, dff, x.device)
+    if workspace is None:
+        raise _lib.VhError(f'ffn_decode: unsupported shape M={M} d={d} dff={dff}')
+    check(_lib.lib().vh_ffn_decode(
+        _dev_f32(x, 'x'), x.stride(0), ptr(_f32(wf, 'w1f')), ptr(c1), ptr(c2), ptr(_f32(w2, 'w2')), ptr(b2),
+        _dev_f32(out, 'out'), out.stride(0), M, d, dff, eps, ptr(workspace), workspace.numel() * 4, stream()),
+        'vh_ffn_decode')
     return out
 
 
@@ -345,21 +294,13 @@ def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=
     return out
 
 
-def _x_next_ptrs(x_next):
-    """(fp32 pointer, fp64 pointer) for the next-embedding output: a float64 tensor is the fp64
-    accumulator form of the residual stream (linear_acc64)."""
-    if not x_next.is_contiguous():
-        raise _lib.VhError('x_next must be contiguous')
-    return (None, ptr(x_next)) if x_next.dtype == torch.float64 else (ptr(x_next), None)
-
-
 def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next,
                 pos_base=None):
     B = logits.shape[0]
     d = x_next.shape[1]
     check(_lib.lib().vh_greedy_step(
         logits.data_ptr(), logits.stride(0), V, eos, ptr(codes), codes.stride(0), ptr(eos_count),
-        ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next), B, d,
+        ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(_f32(x_next, 'x_next')), B, d,
         stream()), 'vh_greedy_step')
 
 
@@ -370,7 +311,7 @@ def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_coun
     check(_lib.lib().vh_sample_step(
         logits.data_ptr(), logits.stride(0), V, eos, int(top_k), float(top_p), float(temperature),
         int(seed) & (2 ** 64 - 1), ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base),
-        ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), *_x_next_ptrs(x_next),
+        ptr(sum_logprobs), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len), ptr(_f32(x_next, 'x_next')),
         B, d, stream()), 'vh_sample_step')
 
 

@@ -124,9 +124,9 @@ class ValleAR(_Base):
 
     def training_step(self, batch, **kwargs):
         """valle_ar.py:43-90: mean cross entropy over ALL (B, Ty) positions, pads included.  With
-        grad mode on the loss carries a full autograd graph (HIP forward kernels; backward = HIP
-        row kernels + library GEMMs, valle2_amd/autograd.py); under no_grad it takes the fused
-        inference kernels."""
+        grad mode on the loss carries a full autograd graph (hand-written HIP kernels forward and
+        backward: tile GEMMs, TN weight-gradient GEMM, flash attention backward, row kernels —
+        valle2_amd/autograd.py); under no_grad it takes the fused inference kernels."""
         from . import autograd as A
         if torch.is_grad_enabled():
             logits = self._logits_with_graph(batch)
@@ -269,9 +269,8 @@ class ValleAR(_Base):
             n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             marks[2].synchronize()
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
-            dec.check_chain()
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'two_slab': dec.x2, 'chain': dec.chain, 'pipe': dec.pipe,
+                                        'ffn_fused': dec.ffn_ws is not None,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
