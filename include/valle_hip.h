@@ -70,7 +70,7 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
                                        launches (vh_linear_folded + vh_linear_ws) */
        VH_TUNE_GRAPH_STEPS = 6,     /* decode graph: 0 (default) = replay in graphs of 8 consecutive steps (+ single-step graphs
                                        for the remainder); 1 = one graph launch per step */
-       VH_TUNE_FFN_SLICE = 7,       /* vh_ffn_decode: hidden columns per workgroup, 0 (default) = chosen from the shape, else 16 / 32 / 64 */
+       VH_TUNE_FFN_SLICE = 7,       /* vh_ffn_decode: hidden columns per workgroup, 0 (default) = chosen from the shape, else 16 / 32 */
        VH_TUNE_FFN_ROWS = 8,        /* vh_ffn_decode: rows per workgroup, 0 (default) = chosen from the shape, else 8 / 16 */
        VH_TUNE_COUNT = 9 };
 int vh_set_tuning(int knob, int value);

@@ -28,8 +28,7 @@ def main(rounds=8):
     forms = {'default': {},
              'ffn three launches': {5: 1},
              'ffn fused 32 x 16 rows': {7: 32, 8: 16},
-             'ffn fused 16 x 16 rows': {7: 16, 8: 16},
-             'ffn fused 64 x 8 rows': {7: 64, 8: 8}}
+             'ffn fused 16 x 16 rows': {7: 16, 8: 16}}
     if len(sys.argv) > 1:
         forms = {k: v for k, v in forms.items() if k == 'default' or any(a in k for a in sys.argv[1:])}
     res = {k: [] for k in forms}

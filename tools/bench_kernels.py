@@ -135,9 +135,9 @@ def bench_gemm():
         'ffn fused (default plan)': ffn,
         'ffn fused slice 32 x 8 rows': tuned2(32, 8, ffn),
         'ffn fused slice 32 x 16 rows': tuned2(32, 16, ffn),
+
         'ffn fused slice 16 x 16 rows': tuned2(16, 16, ffn),
         'ffn fused slice 16 x 8 rows': tuned2(16, 8, ffn),
-        'ffn fused slice 64 x 8 rows': tuned2(64, 8, ffn),
         'ffn three launches (ffn1 fold + ffn2 split-K + reduce)': ffn_three,
         'qkv fold': lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
         'qkv fold, no row groups': tuned(2, 2, lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl)),

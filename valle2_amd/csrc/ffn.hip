@@ -38,61 +38,42 @@ struct FfnArgs {
 template <int D, int SW>
 __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const float* hw1, const float* hw2, int h_ldx,
                                                          int hM, int h_dff, FfnArgs a) {
-    constexpr int NW = 8, PW = D / 128, NJ = D / 64, CB1 = SW / 16, CB2 = D / 128, KC2 = SW / 16, HLD = SW + 4;
-    static_assert(D % 128 == 0 && SW % 16 == 0 && CB1 <= NW, "shape");
+    constexpr int NW = 8, PW = D / 128, CB1 = SW / 16, CB2 = D / 128, KC2 = SW / 16, HLD = SW + 4;
+    static_assert(D % 128 == 0 && SW % 16 == 0 && CB1 <= 2, "shape");
     __shared__ __attribute__((aligned(16))) float red[NW][CB1][64][4];
     __shared__ __attribute__((aligned(16))) float hid[16][HLD];
-    __shared__ float s_mean[16], s_rstd[16];
+    __shared__ __attribute__((aligned(16))) float pst[16][2 * NW];   // per row: (sum, sum of squares) of each wave's K range
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
-    // Workgroups that share a slice (its W1f rows and W2 columns) differ in the row group only: they are given
-    // block ids that are equal mod 8, i.e. the same XCD (round-robin dispatch), so the slice's 2 x SW x D x 4
-    // bytes of weights are fetched into ONE L2.
-    const int bid = blockIdx.x;
-    int slice, rg;
-    if ((a.n_slices & 7) == 0) {
-        const int xcd = bid & 7, j = bid >> 3;
-        slice = (j / a.n_rg) * 8 + xcd;
-        rg = j % a.n_rg;
-    } else {
-        slice = bid / a.n_rg;
-        rg = bid % a.n_rg;
-    }
+    // grid = (slices, row groups).  Workgroups that share a slice (its W1f rows and W2 columns) differ in blockIdx.y
+    // only: their linear ids differ by multiples of n_slices, so with n_slices % 8 == 0 they run on the same XCD
+    // (round-robin dispatch) and the slice's 2 x SW x D x 4 bytes of weights are fetched into ONE L2.
+    const int slice = blockIdx.x, rg = blockIdx.y;
     const int row0 = rg * a.rg_rows;
     const int rows = min(hM - row0, a.rg_rows);                 // 1..16 valid rows in this group
     const float* X = hx + (int64_t)row0 * h_ldx;
     const int n1 = slice * SW;                                  // first hidden column of the slice
 
-    // ---- every load this workgroup will ever need, in the order their data is used
-    // statistics: DPP row g of wave w holds activation row 4w + g (clamped: rows beyond the group repeat its last row)
-    const bool stat_wave = 4 * w < a.rg_rows;                   // wave-uniform
-    const int srow = 4 * w + g;
-    f32x4 v[NJ];
-    if (stat_wave) {
-        const float* xr = X + (int64_t)min(srow, rows - 1) * h_ldx + 4 * i;
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) v[jj] = ld4(xr + 64 * jj);
-    }
-    // phase 1: W1f rows n1 + 16 cb + i (A operand), x rows i (B operand), k = w * 16 PW + 16 c + 4 g + {0..3}
+    // ---- every load this workgroup will ever need, in the order their data is used.  STRAIGHT-LINE code: a load or a
+    // reduction under a (wave-uniform) branch lets the compiler merge the branch bodies and wait for the first loads
+    // before it has issued the rest — three dependent round trips instead of one (seen in the first version's ISA).
+    // phase 1: x rows i (B operand), W1f rows n1 + 16 cb + i (A operand), k = w * 16 PW + 16 c + 4 g + {0..3}
     const int koff = w * (PW * 16) + 4 * g;
+    const float* xrow = X + (int64_t)min(i, rows - 1) * h_ldx;  // rows beyond the group repeat its last row
+    const float shift = xrow[0];                                // statistics are taken about the row's first element
     f32x4 wf1[CB1][PW], xf[PW];
-    {
-        const float* xp = X + (int64_t)min(i, rows - 1) * h_ldx + koff;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) xf[c] = ld4(xp + 16 * c);
+    for (int c = 0; c < PW; ++c) xf[c] = ld4(xrow + koff + 16 * c);
 #pragma unroll
-        for (int cb = 0; cb < CB1; ++cb) {
-            const float* wp = hw1 + (int64_t)(n1 + 16 * cb + i) * D + koff;
+    for (int cb = 0; cb < CB1; ++cb) {
+        const float* wp = hw1 + (int64_t)(n1 + 16 * cb + i) * D + koff;
 #pragma unroll
-            for (int c = 0; c < PW; ++c) wf1[cb][c] = ld4(wp + 16 * c);
-        }
+        for (int c = 0; c < PW; ++c) wf1[cb][c] = ld4(wp + 16 * c);
     }
-    // phase-1 epilogue operands of the finalising waves (wave cb finalises hidden columns n1 + 16 cb ..)
-    f32x4 e_c1 = {0.f, 0.f, 0.f, 0.f}, e_c2 = {0.f, 0.f, 0.f, 0.f};
-    if (w < CB1) {
-        e_c1 = ld4(a.c1 + n1 + 16 * w + 4 * g);
-        e_c2 = ld4(a.c2 + n1 + 16 * w + 4 * g);
-    }
+    // phase-1 epilogue operands: wave w finalises component (w >> 1) & 3 of hidden column block w % CB1 … see below
+    const int fcb = w % CB1, fcomp = (w / CB1) & 3;
+    const float e_c1 = a.c1[n1 + 16 * fcb + 4 * g + fcomp];
+    const float e_c2 = a.c2[n1 + 16 * fcb + 4 * g + fcomp];
     // phase 2: W2 rows (= output columns) 16 (w CB2 + cb) + i, k = n1 + 16 c + 4 g + {0..3}: one 128-B line per row at SW = 32
     f32x4 wf2[CB2][KC2];
 #pragma unroll
@@ -103,20 +84,22 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- row statistics (two-pass mean / centred variance, as gemm_skinny_fast)
-    if (stat_wave) {
-        float sum = 0.f;
+    // ---- row statistics from the operand fragments (no second read of the rows): this lane holds 4 PW elements of
+    // row i; sums of (x - shift) and (x - shift)^2, folded over the wave's four k groups (lanes i, i+16, i+32, i+48),
+    // one (sum, sum of squares) pair per wave and row to LDS; the finalising lanes add the 8 pairs in wave order.
+    // The shift (an element of the row) keeps the one-pass variance free of cancellation: |shift - mean| is a few
+    // standard deviations at most, so the subtraction below loses a few bits of 24, not most of them.
+    {
+        float sa = 0.f, sb = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) sum += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
-        const float mu = row16_sum(sum) / (float)D;
-        float ss = 0.f;
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj) {
-            const f32x4 t = v[jj] - mu;
-            ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+        for (int c = 0; c < PW; ++c) {
+            const f32x4 t = xf[c] - shift;
+            sa += (t.x + t.y) + (t.z + t.w);
+            sb += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
         }
-        const float var = row16_sum(ss) / (float)D;
-        if (i == 0 && srow < 16) { s_mean[srow] = mu; s_rstd[srow] = rsqrtf(var + a.eps); }
+        sa += __shfl_xor(sa, 16, 64); sb += __shfl_xor(sb, 16, 64);
+        sa += __shfl_xor(sa, 32, 64); sb += __shfl_xor(sb, 32, 64);
+        if (g == 0) { pst[i][2 * w] = sa; pst[i][2 * w + 1] = sb; }
     }
 
     // ---- phase 1: this wave's K range of x · W1fᵀ for the SW hidden columns
@@ -133,15 +116,24 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
 #pragma unroll
     for (int cb = 0; cb < CB1; ++cb) st4(&red[w][cb][lane][0], acc1[cb]);
     __syncthreads();
-    if (w < CB1) {
-        // lane: activation row m = i, hidden columns n1 + 16 w + 4 g + {0..3}; waves added in wave order
-        f32x4 s = ld4(&red[0][w][lane][0]);
+    // Finalise, spread over the waves so that each lane evaluates ONE GELU (the code every launch has to fetch cold is
+    // what these kernels wait for): wave w takes component fcomp of column block fcb — lane (i, g): activation row
+    // i, hidden column n1 + 16 fcb + 4 g + fcomp — partial sums added in wave order.  (CB1 * 4 <= 8 waves take part.)
+    if (w < 4 * CB1) {
+        float s = red[0][fcb][lane][fcomp];
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) s += ld4(&red[ww][w][lane][0]);
-        const float mu = s_mean[i], rs = s_rstd[i];
-        s = (s - mu * e_c1) * rs + e_c2;
-        const vh_f32x2 g0 = gelu_erf2(vh_f32x2{s.x, s.y}), g1 = gelu_erf2(vh_f32x2{s.z, s.w});
-        st4(&hid[i][16 * w + 4 * g], f32x4{g0.x, g0.y, g1.x, g1.y});
+        for (int ww = 1; ww < NW; ++ww) s += red[ww][fcb][lane][fcomp];
+        f32x4 p[NW / 2];
+#pragma unroll
+        for (int q = 0; q < NW / 2; ++q) p[q] = ld4(&pst[i][4 * q]);
+        float sa = p[0].x, sb = p[0].y;
+        sa += p[0].z; sb += p[0].w;
+#pragma unroll
+        for (int q = 1; q < NW / 2; ++q) { sa += p[q].x; sb += p[q].y; sa += p[q].z; sb += p[q].w; }
+        const float dm = sa * (1.0f / D);                       // mean - shift
+        const float var = fmaxf(sb * (1.0f / D) - dm * dm, 0.f);
+        const float mu = shift + dm, rs = rsqrtf(var + a.eps);
+        hid[i][16 * fcb + 4 * g + fcomp] = gelu_erf((s - mu * e_c1) * rs + e_c2);
     }
     __syncthreads();
 
@@ -159,10 +151,12 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
 #pragma unroll
             for (int cb = 0; cb < CB2; ++cb)
                 acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[cb][c][jj], hf[c][jj], acc2[cb], 0, 0, 0);
+    // non-temporal stores: the slabs are read once, by another launch, from whatever XCD — written through they do
+    // not wait in this XCD's L2 for the write-back at the end of the kernel (9.35 -> 8.66 us per launch)
     if (i < rows) {
         float* dst = a.slabs + ((int64_t)slice * hM + row0 + i) * D + 16 * (w * CB2) + 4 * g;
 #pragma unroll
-        for (int cb = 0; cb < CB2; ++cb) st4(dst + 16 * cb, acc2[cb]);
+        for (int cb = 0; cb < CB2; ++cb) __builtin_nontemporal_store(acc2[cb], reinterpret_cast<f32x4*>(dst + 16 * cb));
     }
 }
 
@@ -209,7 +203,7 @@ static int ffn_plan(int M, int d_model, int dff, int* rg_rows) {
         return 0;
     const int rg8 = (M + 7) / 8, rg16 = (M + 15) / 16;
     int sw = vh_tuning(VH_TUNE_FFN_SLICE);
-    if (sw != 16 && sw != 32 && sw != 64) {
+    if (sw != 16 && sw != 32) {
         // as many workgroups as the chip has CUs, as few slabs as that allows
         sw = (dff % 32 == 0 && (dff / 32) * rg8 >= 192) ? 32 : 16;
     }
@@ -246,14 +240,13 @@ extern "C" int vh_ffn_decode(const float* x, int ldx, const float* w1f, const fl
                "vh_ffn_decode: workspace of %zu B < %zu B (vh_ffn_decode_ws_bytes)", workspace_bytes,
                (size_t)n_slices * M * d_model * sizeof(float));
     FfnArgs a{c1, c2, (float*)workspace, n_slices, (M + rg_rows - 1) / rg_rows, rg_rows, ln_eps};
-    const dim3 grid(n_slices * a.n_rg);
+    const dim3 grid(n_slices, a.n_rg);
     hipStream_t s = (hipStream_t)stream;
 #define FFN(DD, SS) hipLaunchKernelGGL((ffn_decode_kernel<DD, SS>), grid, dim3(512), 0, s, x, w1f, w2, ldx, M, dff, a)
 #define FFN_D(DD)                              \
     do {                                       \
         if (sw == 16) FFN(DD, 16);             \
-        else if (sw == 32) FFN(DD, 32);        \
-        else FFN(DD, 64);                      \
+        else FFN(DD, 32);                      \
     } while (0)
     if (d_model == 128) FFN_D(128);
     else if (d_model == 256) FFN_D(256);
