@@ -22,14 +22,23 @@ bound), `prefill` (event-timed prompt pass against the fp32 MFMA peak), `decode_
 decode step against the HBM peak, all algorithmic bytes of the step), `train` (configs[3] forward +
 backward + gradient all-reduce + clip/AdamW step time, AR and NAR, on every rank: the RCCL leg),
 `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only),
-`nar` (one NAR stage forward of configs[2], secondary metric).  The optional legs run under a
-deadline: if one stalls, the line is printed with what was measured and the process exits.
+`nar` (one NAR stage forward of configs[2], secondary metric), `beams` (the reference's own signature:
+`generate()` of ONE utterance with num_beams=32, timed beside the 32-distinct-utterances headline),
+`config5` (configs[4]'s AR leg: 24L/1024d, 8 rows, decode at context ~2.7 k against the HBM peak).
+`roofline.traffic` is measured in this run: after the timed region a FRESH child process runs one
+generate under `rocprofv3 --pmc FETCH_SIZE` (and one under `--pmc WRITE_SIZE`) and the decode-attention
+kernel's counters are read from its CSV (the committed constant under profiles/ is the fallback).
+The optional legs run under a deadline: if one stalls, the line is printed with what was measured and
+the process exits.
 """
 from __future__ import annotations
 
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
 import socket
 import subprocess
 import sys
@@ -59,7 +68,11 @@ def parse():
     ap.add_argument('--no-nar', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-train', action='store_true')
-    ap.add_argument('--extras-deadline', type=float, default=420.0,
+    ap.add_argument('--no-beams', action='store_true')
+    ap.add_argument('--no-config5', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true', help='do not start the rocprofv3 --pmc child processes')
+    ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)   # one generate, nothing else
+    ap.add_argument('--extras-deadline', type=float, default=600.0,
                     help='seconds the optional legs (roofline, nar, train, cpu_baseline) may take in total')
     ap.add_argument('--small', action='store_true', help='tiny shapes for a functional check')
     return ap.parse_args()
@@ -84,10 +97,12 @@ def host_cores():
                 n = min(n, max(1, int(int(quota) / int(period))))
         except (OSError, ValueError):
             pass
-    # a GPU box gives each GPU a 16-core share of the host (driver note); never oversubscribe it
+    # Where neither a cgroup quota nor an affinity mask says how many cores are this process's (os.cpu_count() = the
+    # whole host), cap at the share a GPU box gives one GPU — VALLE2_CORES_PER_GPU, 16 on this pool (driver note) —
+    # oversubscribing torch's pool stalled the baseline for minutes
     try:
         import torch
-        n = min(n, 16 * max(1, torch.cuda.device_count()))
+        n = min(n, int(os.environ.get('VALLE2_CORES_PER_GPU', '16')) * max(1, torch.cuda.device_count()))
     except Exception:
         pass
     return n
@@ -137,6 +152,116 @@ def cpu_baseline(cfg_kw, sd, utt, rows, new, gpu_tokens=None):
                       f'({t_step * 1e3:.1f} ms/step at S~{TEXT + FRAMES + 1}), extrapolated to {new} tokens'}
 
 
+def measure_attn_traffic(rows, new):
+    """HBM bytes per decode-attention launch from PMC counters, measured NOW: a fresh child process per counter
+    (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-child`, one configs[1] generate, nothing
+    else; separate passes, no tracing domain beside --kernel-trace) — never this process re-executed.  Units and the
+    gfx950 correction as MI355X_MICROARCH.md section HBM prescribes: both counters are in KB; FETCH_SIZE counts a wide
+    coalesced read at 1/2 (128-B requests tallied at 64 B) -> doubled; WRITE_SIZE is exact.  Returns a dict or None."""
+    rocprof = shutil.which('rocprofv3') or '/opt/rocm/bin/rocprofv3'
+    if not Path(rocprof).exists() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
+        return None                                       # no profiler here, or this run is itself being profiled
+    out = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        tmp = tempfile.mkdtemp(prefix='vh_pmc_')
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
+                                                                'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
+        env['TMPDIR'] = tmp
+        cmd = [rocprof, '--kernel-trace', '--pmc', counter, '-d', tmp, '-o', 'pmc', '--output-format', 'csv', '--',
+               sys.executable, str(Path(__file__).resolve()), '--traffic-child']
+        log(f'traffic: {" ".join(cmd[:6])} ... (child process)')
+        try:
+            subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
+                           check=True)
+            vals = []
+            for path in glob.glob(f'{tmp}/**/*counter_collection.csv', recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if 'attn_decode_ring_kernel' in r['Kernel_Name'] and r['Counter_Name'] == counter:
+                        vals.append(float(r['Counter_Value']))
+            if len(vals) != (new - 1) * AR['num_layers']:
+                log(f'traffic: {len(vals)} {counter} rows for the decode-attention kernel, expected '
+                    f'{(new - 1) * AR["num_layers"]}')
+                return None
+            out[counter] = sum(vals) / len(vals)
+        except Exception as e:                              # noqa: BLE001 — the committed constant is the fallback
+            log(f'traffic: child failed ({type(e).__name__}: {e})')
+            return None
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return {'bytes_per_launch': 2.0 * out['FETCH_SIZE'] * 1024 + out['WRITE_SIZE'] * 1024,
+            'fetch_size_kb': out['FETCH_SIZE'], 'write_size_kb': out['WRITE_SIZE'],
+            'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two fresh child processes of this run, '
+                      'mean over every decode-attention launch of one generate; bytes = 2 x FETCH_SIZE KB (gfx950 tallies '
+                      'a 128-B request at 64 B) + WRITE_SIZE KB'}
+
+
+def training_flop(cfg, model_name, batch, padded=False):
+    """Algorithmic FLOP of one training step = 3 x forward (forward + 2 x backward) over the REAL
+    (unpadded) positions of the batch: GEMMs 2 P_L per position and layer, attention 4 d per visible (query, key) pair
+    and layer (prefix-LM for AR: text block + causal audio; full for NAR), the head over the predicted positions.
+    padded=True: the same rule over the batch as the reference's semantics make it run — every row at the batch's
+    maximum lengths (its loss averages over the pad positions too, valle_ar.py:86, so their logits are computed)."""
+    d, dff, L = cfg.d_model, cfg.dim_feedforward, cfg.num_layers
+    p_l = 4 * d * d + 2 * d * dff
+    fwd = 0.0
+    for b in range(batch['tokens'].shape[0]):
+        x, y = int(batch['tokens_lens'][b]), int(batch['codes_lens'][b])
+        if padded:
+            x, y = int(batch['tokens_lens'].max()), int(batch['codes_lens'].max())
+        if model_name == 'ValleAR':
+            pairs = x * x + y * x + y * (y + 1) // 2
+            head = 2.0 * d * (cfg.num_audio_tokens + 1) * y
+        else:
+            pairs = (x + y) * (x + y)
+            head = 2.0 * d * cfg.num_audio_tokens * max(0, y - min(y // 3, 3 * cfg.quantization_factor))
+        fwd += 2.0 * L * p_l * (x + y) + 4.0 * d * pairs * L + head
+    return 3.0 * fwd
+
+
+def config5_leg(dev):
+    """BASELINE.json configs[4], AR leg: 24L/1024d/h16/dff4096, 8 rows (num_beams), 400 text + 2250-frame context —
+    the END of a 30 s utterance, where the KV stream is longest — 256 greedy tokens; the decode steps against the HBM
+    peak with SURVEY 8d's algorithmic bytes (weights + head once per step, every K/V element once per step)."""
+    import torch
+
+    from valle2_amd import ConfigValle, get_model_class, synth
+    log('config5: 24L/1024d AR decode at context ~2.7 k')
+    rows, text, frames, new = 8, 400, 2250, 256
+    cfg = ConfigValle(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0, norm='LayerNorm',
+                      num_beams=rows, top_k=1, max_audio_len=new)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=0, rich=False), cfg)
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    utts = [synth.synth_utterance(cfg, text // 2, text // 2, frames, seed=7 + u) for u in range(rows)]
+    texts = [torch.cat([u[0], u[2]]).to(dev) for u in utts]
+    firsts = [u[1][:, 0].to(dev) for u in utts]
+    m.generate_batch(texts, firsts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 2
+    for _ in range(reps):
+        out = m.generate_batch(texts, firsts)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert out.shape[1] == frames + 1 + new
+    st = m.last_generate_stats
+    d, L = cfg.d_model, cfg.num_layers
+    l_pl = 4 * d * d + 2 * d * cfg.dim_feedforward
+    elems = [L * l_pl + (cfg.num_audio_tokens + 1) * d + 2 * L * rows * (st['s0'] + t) * d + 2 * L * rows * d
+             for t in range(1, new)]
+    dec_bytes = 4.0 * sum(elems)
+    gbs = dec_bytes / (st['decode_ms'] * 1e-3) / 1e9
+    del m
+    torch.cuda.empty_cache()
+    return {'workload': 'configs[4] AR leg: 24L/1024d/h16/dff4096 greedy generate_batch, 8 rows, 400 text + BOS + 2250 '
+                        'codec tokens -> 256 new tokens (context 2651..2907), fp32',
+            'value': rows * new / dt, 'unit': 'tokens/s', 'ms_per_generate': dt * 1e3, 'prefill_ms': st['prefill_ms'],
+            'decode_ms_per_step': st['decode_ms'] / (new - 1), 'algorithmic_bytes_total': dec_bytes,
+            'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
+            'n_split': st['n_split']}
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` without a launcher: start N ranks of this script, one per GPU.  Runs before
     anything in this process has touched the GPU (torch is not even imported here); the parent only
@@ -172,7 +297,11 @@ def train_leg(dev, world, rank, small):
 
     from valle2_amd import ConfigValle, dp, get_model_class, synth
     out = {'config': 'configs[3]: 12L/512d fwd+bwd, per-GPU batch 16, tokens 40..120, codes 225..900, fp32 grads, '
-                     f'DP x{world}' + (' (RCCL flat-bucket all-reduce overlapped with backward)' if world > 1 else '')}
+                     f'DP x{world}' + (' (RCCL flat-bucket all-reduce overlapped with backward)' if world > 1 else ''),
+           'bound': 'mfma', 'peak_tflops': MFMA_F32_PEAK_TF,
+           'flop_rule': '3 x forward (fwd + 2 x bwd) over the real, unpadded positions of this rank: GEMMs 2 P_L per '
+                        'position and layer + attention 4 d per visible pair and layer + head (SURVEY 8d); *_frac = this '
+                        "rank's TFLOP/s / 157.3"}
     kw = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, batch_size=16)
     if small:
         kw.update(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, batch_size=4)
@@ -183,7 +312,7 @@ def train_leg(dev, world, rank, small):
         opt = model.configure_optimizers()['optimizer']
         reducer = dp.GradReducer(opt.flat_grad, opt.slots)
         warm, timed = 3, 5
-        rows = 0
+        rows, flop, flop_pad = 0, 0.0, 0.0
         for i in range(warm + timed):
             if name == 'ValleAR':
                 batch = synth.synth_ar_batch(cfg, cfg.batch_size, seed=100 + i + 1000 * rank)
@@ -202,12 +331,19 @@ def train_leg(dev, world, rank, small):
             opt.step(grad_scale=1.0 / world, max_norm=cfg.gradient_clip_val, zero_grad=True)
             if i >= warm:
                 rows += batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])
+                flop += training_flop(cfg, name, batch)
+                flop_pad += training_flop(cfg, name, batch, padded=True)
         torch.cuda.synchronize()
         dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
         key = 'ar' if name == 'ValleAR' else 'nar'
         out[f'{key}_ms_per_step'] = dt / timed * 1e3
         out[f'{key}_positions_per_s'] = world * rows / dt          # rank 0's rows x world (shapes are seeded per rank)
         out[f'{key}_allreduce_bytes'] = 4 * opt.numel if world > 1 else 0
+        # this rank's algorithmic FLOP per step (real positions, 3 x forward) against the fp32 MFMA peak of ONE GPU
+        out[f'{key}_flop_per_step'] = flop / timed
+        out[f'{key}_tflops'] = flop / dt / 1e12
+        out[f'{key}_frac'] = flop / dt / 1e12 / MFMA_F32_PEAK_TF
+        out[f'{key}_frac_padded_positions'] = flop_pad / dt / 1e12 / MFMA_F32_PEAK_TF   # the work the step really runs
         out[f'{key}_loss'] = float(loss.detach())
         reducer.remove()
         del model, opt, reducer
@@ -278,6 +414,10 @@ def main():
             dist.barrier(group=host_pg)
         torch.cuda.synchronize()
 
+    if args.traffic_child:                 # under rocprofv3 --pmc, started by measure_attn_traffic(): one generate
+        step()
+        torch.cuda.synchronize()
+        return
     log(f'rank {rank}/{world}: model ready, warmup {args.warmup}')
     for _ in range(args.warmup):
         step()
@@ -379,8 +519,16 @@ def main():
                     'marker_bracket_us = two marker events recorded around the same launch (event + dispatch overhead '
                     'included; not used), marker_floor_us = that bracket with nothing inside; traffic = PMC FETCH_SIZE/WRITE_SIZE from separate '
                     'rocprofv3 --pmc passes of this workload, committed under profiles/ (null when absent)'}
+        measured = None if (args.small or args.no_traffic) else measure_attn_traffic(rows, new)
         pmc = REPO / 'profiles' / 'attn_decode_traffic.json'
-        if pmc.exists() and not args.small:
+        if measured:
+            result['roofline']['traffic'] = measured['bytes_per_launch']
+            result['roofline']['traffic_source'] = measured['source']
+            result['roofline']['traffic_fetch_size_kb'] = measured['fetch_size_kb']
+            result['roofline']['traffic_write_size_kb'] = measured['write_size_kb']
+            result['roofline']['traffic_over_algorithmic'] = measured['bytes_per_launch'] / bytes_per_launch
+            result['roofline']['traffic_measured_in_this_run'] = True
+        elif pmc.exists() and not args.small:
             t = json.loads(pmc.read_text())
             if t.get('rows') == rows and t.get('new_tokens') == new:
                 result['roofline']['traffic'] = t['bytes_per_launch']
@@ -392,6 +540,30 @@ def main():
                       + 2 * cfg.num_layers * rows * (st['s0'] + t) * cfg.d_model
                       + 2 * cfg.num_layers * rows * cfg.d_model for t in range(1, new)]
         result['roofline']['decode_algorithmic_bytes_total'] = 4.0 * sum(step_elems)
+
+    if rank == 0 and not args.no_beams:
+        # the reference's own signature (valle_ar.py:136-138): ONE utterance, num_beams = 32 replicated rows, greedy;
+        # rows are never deduplicated, so this costs what the 32-distinct-utterances headline costs
+        log('beams: generate() of one utterance with num_beams=32')
+        utt0 = [u.to(dev) for u in utts[0]]              # inputs resident in HBM, as for the headline
+        model.generate(*utt0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            toks = model.generate(*utt0)
+        torch.cuda.synchronize()
+        dtb = (time.perf_counter() - t0) / reps
+        st_b = model.last_generate_stats
+        result['beams'] = {'metric': 'acoustic tokens/sec, generate(prompt_tokens, prompt_codes, target_tokens) with '
+                                     f'num_beams={rows} (identical rows, not deduplicated)',
+                           'value': rows * new / dtb, 'unit': 'tokens/s', 'ms_per_generate': dtb * 1e3,
+                           'tokens_returned': int(toks.numel()), 'decode_ms': st_b['decode_ms'],
+                           'prefill_ms': st_b['prefill_ms'],
+                           'vs_distinct_rows': (rows * new / dtb) / (value / world)}
+
+    if rank == 0 and not args.no_config5 and not args.small:
+        result['config5'] = config5_leg(dev)
 
     if rank == 0 and world == 1 and not args.no_nar and not args.small:
         log('nar: one stage forward of configs[2]')

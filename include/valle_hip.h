@@ -357,9 +357,10 @@ int vh_categorical_rows(const float* logits, int ld, int V, int rows, float temp
  * stages' heads and embeddings receive nothing, valle_nar.py:76).  block_slot (n / 64 int32, device) maps
  * each 64-float block to its parameter slot, slot_step (device) holds the slot's own step count for this
  * update, 0 = skip the slot entirely (no decay, no moments, no move).  Needs n % 64 == 0.
- * guard (optional, one int32 on the device): nonzero when the update launch starts = nothing is touched (the error
- * flag of the range-checking kernels: a step that saw a bad id never reaches the parameters, and the host can read
- * the flag a step later instead of synchronising every step). */
+ * guard (optional, one int32 on the device): nonzero when the update launch starts = parameters and moments are not
+ * touched (the error flag of the range-checking kernels: a step that saw a bad id never reaches the parameters, and
+ * the host can read the flag a step later instead of synchronising every step); the gradient is still cleared when
+ * zero_grad != 0, so the buffer the next backward accumulates into is zero either way. */
 size_t vh_adamw_ws_bytes(void);
 int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,

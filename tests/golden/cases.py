@@ -29,7 +29,7 @@ AR_TINY = dict(TINY, norm='LayerNorm', num_beams=4, top_k=1, max_audio_len=64)
 AR_MID = dict(MID, norm='LayerNorm', num_beams=2, top_k=1, max_audio_len=48)
 NAR_TINY = dict(TINY, norm='AdaptiveLayerNorm')
 # full BASELINE.json sizes (round 2): configs[1] generate, configs[3] training batch, configs[4] NAR stage
-AR_FULL = dict(MID, norm='LayerNorm', num_beams=32, top_k=1, max_audio_len=128)
+AR_FULL = dict(MID, norm='LayerNorm', num_beams=32, top_k=1, max_audio_len=512)
 AR_TRAIN_FULL = dict(MID, norm='LayerNorm')
 BIG = dict(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0)
 NAR_BIG = dict(BIG, norm='AdaptiveLayerNorm')

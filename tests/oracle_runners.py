@@ -132,7 +132,7 @@ def sampling_filter():
     return out
 
 
-ORACLE_FULL_STEPS = 20      # the oracle re-runs the first steps of the 128-step full-size golden (CPU time)
+ORACLE_FULL_STEPS = 20      # the oracle re-runs the first steps of the 512-step full-size golden (CPU time)
 
 
 def ar_generate_full():

@@ -1,5 +1,5 @@
-"""world_size-2 `gloo` tests (CPU) of the N>1 path: utterance sharding, the benchmark's
-max-over-ranks reduction and the bucketed gradient mean used by the training path."""
+"""`gloo` tests (CPU, world sizes 2, 4 and 8) of the N>1 path: utterance sharding, the benchmark's
+max-over-ranks reduction and the bucketed gradient mean / overlapped reducer used by the training path."""
 import os
 import socket
 
@@ -83,7 +83,7 @@ def _branch_worker(rank, world, port, out):
     from valle2_amd.optim import flat_layout
     torch.manual_seed(0)
     trunk = torch.nn.Linear(6, 8)
-    heads = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])   # equal sizes: a swap would go unnoticed
+    heads = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(world + 1)])   # equal sizes: a swap would go unnoticed
     params = list(trunk.parameters()) + list(heads.parameters())
     slots, total = flat_layout(params)
     flat = torch.zeros(total)
@@ -94,12 +94,12 @@ def _branch_worker(rank, world, port, out):
     launch = red._launch
     red._launch = lambda b: (order.append(b), launch(b))[1]
     x = torch.randn(4, 6, generator=torch.Generator().manual_seed(7))
-    heads[rank](trunk(x)).square().sum().backward()         # rank 0 trains head 0, rank 1 head 1; head 2 nobody
+    heads[rank](trunk(x)).square().sum().backward()         # rank r trains head r; the last head nobody
     red.finish()
     ref = {}
     torch.manual_seed(0)
     trunk2 = torch.nn.Linear(6, 8)
-    heads2 = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(3)])
+    heads2 = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(world + 1)])
     for r in range(world):
         for p in list(trunk2.parameters()) + list(heads2.parameters()):
             p.grad = None
@@ -112,39 +112,39 @@ def _branch_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_grad_reducer_launches_buckets_in_index_order_when_ranks_train_different_parameters():
-    world, port = 2, _free_port()
+def _spawn(target, world):
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_branch_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
-    for rank, order, n_buckets, ok in res:
-        assert order == list(range(n_buckets)) and n_buckets == 8, (rank, order)
+    return res
+
+
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_grad_reducer_launches_buckets_in_index_order_when_ranks_train_different_parameters(world):
+    """One bucket per parameter, every rank training a different head (world sizes up to the 8 of a node): the
+    collectives must leave in bucket order on every rank and every reduced slice must be the sum over ranks."""
+    for rank, order, n_buckets, ok in _spawn(_branch_worker, world):
+        assert order == list(range(n_buckets)) and n_buckets == 2 + 2 * (world + 1), (rank, order)
         assert ok, f'rank {rank}: reduced gradients are not the sum over ranks'
 
 
-def test_grad_reducer_overlapped_buckets_two_ranks():
-    world, port = 2, _free_port()
-    ctx = mp.get_context('spawn')
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (_, nb0, inb0, l0, r0, v0), (_, nb1, inb1, l1, r1, v1) = res
-    assert nb0 == nb1 and nb0 >= 2 and v0 and v1
-    assert inb0 >= 1 and inb1 >= 1                      # at least one bucket left during backward
-    for a, b, ra, rb in zip(l0, l1, r0, r1):
-        total = torch.tensor(a) + torch.tensor(b)        # SUM over ranks (the mean is the optimizer's grad_scale)
-        assert torch.allclose(torch.tensor(ra), total, atol=1e-6) and torch.allclose(torch.tensor(rb), total, atol=1e-6)
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_grad_reducer_overlapped_buckets(world):
+    res = _spawn(_reducer_worker, world)
+    assert len({r[1] for r in res}) == 1 and res[0][1] >= 2 and all(r[5] for r in res)
+    assert all(r[2] >= 1 for r in res)                   # at least one bucket left during backward on every rank
+    n_params = len(res[0][3])
+    for i in range(n_params):
+        total = sum(torch.tensor(r[3][i]) for r in res)  # SUM over ranks (the mean is the optimizer's grad_scale)
+        for r in res:
+            assert torch.allclose(torch.tensor(r[4][i]), total, atol=1e-5), (r[0], i)
 
 
 def test_two_rank_gloo():

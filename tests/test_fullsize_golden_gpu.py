@@ -34,18 +34,25 @@ def build(name, kw, sd):
 
 
 def test_config1_full_size_greedy_tokens_match_the_reference():
+    """configs[1] exactly as the bench runs it — 32 beams, 256 text + BOS + 767 codec tokens, ALL 512 greedy steps
+    (contexts 1024..1536) — against the real reference (tests/golden/gen_golden.py, 3 min of reference CPU time):
+    every token equal wherever the reference's top-1/top-2 margin exceeds 1e-4 (one of the 512 steps is closer than
+    that, 5.7e-5: a divergence there would be a rounding-level tie, and the run is compared up to it)."""
     from tests.test_models_gpu import tokens_match
     gold = load_golden('ar_generate_full')
     kw, sd, utt = C.ar_generate_inputs('full')
-    assert kw['num_beams'] == 32 and utt[1].shape[0] == 767 and int(gold['steps']) == 128
+    assert kw['num_beams'] == 32 and utt[1].shape[0] == 767 and int(gold['steps']) == 512 == kw['max_audio_len']
     m = build('ValleAR', kw, sd)
     out = m.generate(*[u.to(DEV) for u in utt])
-    assert m.last_generate_stats['s0'] == 1024
+    assert m.last_generate_stats['s0'] == 1024 and m.last_generate_stats['steps_run'] == 512
     tokens_match(out, gold['tokens'], gold['margin'])
-    assert float(gold['margin'].min()) > 1e-4 and torch.equal(out.cpu(), gold['tokens'])
-    # every beam row decoded the same tokens (identical rows are not deduplicated, and agree)
+    sure = int((gold['margin'] > 1e-4).sum())
+    assert sure >= 510, sure
+    # on this build every one of the 512 tokens equals the reference's, the 5.7e-5 step included
+    assert torch.equal(out.cpu(), gold['tokens'])
+    # every beam row decoded the same tokens (identical rows are not deduplicated, and agree), eager stepping
     text = torch.cat([utt[0], utt[2]]).to(DEV)
-    rows = m.generate_batch([text] * 32, [utt[1][:, 0].to(DEV)] * 32, max_new=128, use_graph=False)
+    rows = m.generate_batch([text] * 32, [utt[1][:, 0].to(DEV)] * 32, max_new=512, use_graph=False)
     assert torch.equal(rows[:, 768:].cpu(), gold['tokens'][None].expand(32, -1))
 
 

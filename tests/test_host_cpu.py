@@ -207,14 +207,16 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     import sys
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     env['VALLE2_BENCH_SPAWN_PROBE'] = '1'
-    out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '3', '--steps', '2'], env=env,
-                         capture_output=True, text=True, timeout=120)
-    assert out.returncode == 0, out.stderr
-    ranks = sorted((json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')),
-                   key=lambda r: r['rank'])
-    assert [r['rank'] for r in ranks] == [0, 1, 2] and [r['local'] for r in ranks] == [0, 1, 2]
-    assert all(r['world'] == 3 and r['addr'] == '127.0.0.1' for r in ranks)
-    assert len({r['port'] for r in ranks}) == 1 and all(r['argv'] == ['--gpus', '3', '--steps', '2'] for r in ranks)
+    for n in (3, 8):                                   # 8 = the whole node the driver runs the scaling bench on
+        out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', str(n), '--steps', '2'], env=env,
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        ranks = sorted((json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')),
+                       key=lambda r: r['rank'])
+        assert [r['rank'] for r in ranks] == list(range(n)) and [r['local'] for r in ranks] == list(range(n))
+        assert all(r['world'] == n and r['addr'] == '127.0.0.1' for r in ranks)
+        assert len({r['port'] for r in ranks}) == 1
+        assert all(r['argv'] == ['--gpus', str(n), '--steps', '2'] for r in ranks)
     # under a launcher: one process, the launcher's rank
     env.update(WORLD_SIZE='8', RANK='5', LOCAL_RANK='5')
     out = subprocess.run([sys.executable, str(REPO / 'bench.py'), '--gpus', '8'], env=env, capture_output=True,
@@ -226,3 +228,15 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     out = subprocess.run([sys.executable, str(REPO / 'bench.py')], env=env, capture_output=True, text=True, timeout=120)
     lines = [json.loads(line) for line in out.stdout.splitlines() if line.startswith('{')]
     assert len(lines) == 1 and lines[0]['world'] == 1 and lines[0]['rank'] == 0
+
+
+def test_raise_device_errors_reads_every_flag(monkeypatch):
+    """With device=None every device's flag is read and cleared, not only the first (round-3 advisor finding)."""
+    import torch
+    from valle2_amd import _lib
+    flags = {0: torch.zeros(1, dtype=torch.int32), 1: torch.tensor([_lib.DEVERR_TARGET], dtype=torch.int32)}
+    monkeypatch.setattr(_lib, '_err_flags', flags)
+    with pytest.raises(IndexError, match='target'):
+        _lib.raise_device_errors()
+    assert int(flags[1]) == 0
+    _lib.raise_device_errors()                       # nothing pending any more

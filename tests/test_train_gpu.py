@@ -405,3 +405,111 @@ def test_flat_adamw_skips_parameters_without_gradient_like_torch():
     (mine[0] * 2.0).sum().backward()
     opt.step()
     assert not torch.equal(mine[0], before[0]) and all(torch.equal(mine[i], before[i]) for i in (1, 2, 3))
+
+
+# ---- round-3 advisor findings --------------------------------------------------------------------------------
+def _tiny_ar(seed=3):
+    from valle2_amd import get_model_class, synth
+    cfg = C.cfg_of(dict(C.AR_TINY))
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(synth.make_state_dict(cfg, 'ValleAR', seed=seed, rich=True))
+    return cfg, m.to(DEV).train()
+
+
+def test_poisoned_batch_leaves_host_and_device_state_consistent():
+    """A step whose kernels saw a bad id is guarded off on the device.  The host must agree: step counters rolled back,
+    gradient bookkeeping reset (the guarded launch still clears the flat gradient), so that a caller who catches the
+    IndexError and skips the batch carries on from exactly the state before the bad batch — nothing stale in the flat
+    gradient for the next backward's accumulate-type kernels, bias corrections not a step ahead."""
+    from valle2_amd import synth
+    cfg, a = _tiny_ar()
+    good = [synth.synth_ar_batch(cfg, 2, tok_range=(5, 9), code_range=(13, 20), seed=s) for s in (1, 2)]
+    good = [{k: (v.to(DEV) if not k.endswith('_lens') else v) for k, v in g.items()} for g in good]
+    bad = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in good[1].items()}
+    bad['target'][0, 2] = -100
+    opt = a.configure_optimizers()['optimizer']
+
+    def one_step(batch):
+        with torch.enable_grad():
+            a.training_step(batch).backward()
+        opt.step(max_norm=1.0, zero_grad=True)
+        opt.check_errors()                                  # synchronises: this step's flag
+    one_step(good[0])
+    snap = [t.clone() for t in (opt.flat_param, opt.exp_avg, opt.exp_avg_sq)]
+    counters = (opt.steps, list(opt.slot_steps))
+    with pytest.raises(IndexError, match='target'):
+        one_step(bad)
+    assert (opt.steps, opt.slot_steps) == counters, 'host step counters ran ahead of the device'
+    for now, was in zip((opt.flat_param, opt.exp_avg, opt.exp_avg_sq), snap):
+        assert torch.equal(now, was), 'the guarded step touched parameters or moments'
+    assert float(opt.flat_grad.abs().sum()) == 0.0, 'stale gradient of the skipped step left in the flat buffer'
+    assert all(opt._clean) and not any(opt._claimed) and not any(opt._touched)
+    assert all(p.grad is None for p, _, _ in opt.slots)
+    # the next step runs as step 2 on a clean buffer: the gradient it sees is this batch's alone
+    torch.manual_seed(77)                                   # (the position dropout draws from torch's generator)
+    with torch.enable_grad():
+        a.training_step(good[1]).backward()
+    opt.gather_grads()
+    g_after_skip = opt.flat_grad.clone()
+    opt.step(max_norm=1.0, zero_grad=True)
+    opt.check_errors()
+    assert opt.steps == 2 and not torch.equal(opt.flat_param, snap[0])
+    # the same batch on the same parameters from a freshly zeroed buffer gives the same gradient (to the rounding noise of
+    # the atomics in the column-sum / scatter kernels): nothing of the poisoned batch was mixed in
+    opt.flat_param.copy_(snap[0])
+    opt.zero_grad()
+    torch.manual_seed(77)
+    with torch.enable_grad():
+        a.training_step(good[1]).backward()
+    opt.gather_grads()
+    torch.testing.assert_close(g_after_skip, opt.flat_grad, atol=1e-5, rtol=1e-4)
+
+
+def test_a_second_flat_adamw_detaches_the_first():
+    """configure_optimizers() twice (a resume): the old optimizer's hooks must not keep it — four flat buffers — alive,
+    nor keep marking its slots; its registry entries go with it."""
+    import gc
+    import weakref
+    from valle2_amd import optim, synth
+    cfg, m = _tiny_ar()
+    first = m.configure_optimizers()['optimizer']
+    ref = weakref.ref(first)
+    n_slots = len(optim.GRAD_SLOTS)
+    second = m.configure_optimizers()['optimizer']
+    assert first._hooks == [] and len(optim.GRAD_SLOTS) == n_slots        # re-keyed to the new flat buffer
+    del first
+    gc.collect()
+    assert ref() is None, 'the first optimizer is still referenced (hook closures?)'
+    batch = synth.synth_ar_batch(cfg, 2, tok_range=(5, 9), code_range=(13, 20), seed=1)
+    before = second.flat_param.clone()
+    with torch.enable_grad():
+        m.training_step(batch).backward()
+    second.step()
+    second.check_errors()
+    assert not torch.equal(second.flat_param, before)
+    assert all(p.data_ptr() == second.flat_param[off:off + n].data_ptr() for p, off, n in second.slots)
+
+
+@pytest.mark.parametrize('n_batches,accum,max_steps,expect_steps', [(3, 2, 4, 4), (1, 4, 3, 3), (5, 2, 3, 3)])
+def test_train_accumulation_windows_end_with_the_epoch(n_batches, accum, max_steps, expect_steps):
+    """A re-iterable dataset whose length is not a multiple of grad_accum (or shorter than it): every epoch ends with
+    an optimizer step on the incomplete window (Lightning's behaviour), leftovers never leak into the next epoch, and
+    the loop terminates."""
+    from valle2_amd import synth
+    from valle2_amd.config import ConfigValle
+    from valle2_amd.train_model import train
+    cfg = ConfigValle(d_model=128, n_heads=2, dim_feedforward=256, num_layers=2, dropout=0.0, norm='LayerNorm',
+                      lr=1e-3, max_steps=max_steps, grad_accum=accum, batch_size=2, log_every_n_steps=1000, seed=5)
+    data = [synth.synth_ar_batch(cfg, 2, tok_range=(4, 8), code_range=(10, 20), seed=s) for s in range(n_batches)]
+    seen = []
+
+    class Data:                                   # re-iterable, counts what the loop consumed
+        def __iter__(self):
+            for i, b in enumerate(data):
+                seen.append(i)
+                yield b
+    model, losses = train(cfg, 'ValleAR', batches=Data())
+    windows_per_epoch = -(-n_batches // accum)
+    full_epochs, rest = divmod(expect_steps, windows_per_epoch)
+    want = full_epochs * n_batches + (min(n_batches, rest * accum) if rest else 0)
+    assert len(losses) == len(seen) == want, (len(losses), want)

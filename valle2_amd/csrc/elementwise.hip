@@ -507,7 +507,8 @@ __global__ __launch_bounds__(256) void categorical_rows_kernel(
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) cand = min(cand, __shfl_xor(cand, o));
         if (lane == 0) {
-            tokens[(int64_t)row * tokens_stride] = cand;
+            // a row of NaN / -inf only has no maximum: emit the last valid id, never V (outside every table)
+            tokens[(int64_t)row * tokens_stride] = min(cand, V - 1);
             if (logprob) logprob[row] = 0.f;
         }
         return;

@@ -388,9 +388,17 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
                                                          const int32_t* __restrict__ block_slot,
                                                          const int32_t* __restrict__ slot_step,
                                                          const int32_t* __restrict__ guard) {
-    // a device-side error flag raised earlier in this step (an id outside its table, ...): leave everything as it is —
-    // the host reads the flag later, without a synchronisation per step, and raises
-    if (guard && *guard) return;
+    // a device-side error flag raised earlier in this step (an id outside its table, ...): parameters and moments stay
+    // as they are — the host reads the flag later, without a synchronisation per step, and raises — but the gradient
+    // is still cleared when the caller asked for that: the host releases its gradient views after this launch either
+    // way, and the next backward's accumulate-type kernels (bias column sums, LayerNorm weight gradients, embedding
+    // scatter) rely on a zero buffer
+    if (guard && *guard) {
+        if (zero_grad)
+            for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
+                st4(g + 4 * i, f32x4{0.f, 0.f, 0.f, 0.f});
+        return;
+    }
     // total gradient norm: 1024 partials, 4 per thread, fixed order
     __shared__ double s[4];
     double acc = 0.0;

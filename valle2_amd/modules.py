@@ -113,6 +113,11 @@ def _on_device(forward):
         out = forward(target, *args, **kwargs)
         if target is not self and hasattr(target, 'last_generate_stats'):
             self.last_generate_stats = target.last_generate_stats
+        if home.type != 'cuda':
+            # the results travel to the host, which synchronises anyway: an id that was outside its table on the device
+            # (read as row 0 by the gather kernels) becomes the IndexError nn.Embedding raises, here and not at some
+            # later, unrelated call
+            _lib.raise_device_errors(dev)
         return _move(out, home, home.type == 'cuda')
     return wrapper
 

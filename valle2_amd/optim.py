@@ -92,7 +92,20 @@ class FlatAdamW(torch.optim.Optimizer):
         self._touched = [False] * len(self.slots)
         self._block_slot = None
         self._slot_step_dev = torch.zeros(len(self.slots), device=dev, dtype=torch.int32)
-        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touch(i))
+        # parameters that already live in another FlatAdamW's flat buffer (configure_optimizers called twice, a
+        # resume): detach the old optimizer first — its hooks and registry entries would otherwise stay live
+        for p in params:
+            ent = GRAD_SLOTS.get(p.data_ptr())
+            old = ent[0]() if ent is not None else None
+            if old is not None and old is not self:
+                old.close()
+        me = weakref.ref(self)                 # the hooks must not keep the optimizer (and its buffers) alive
+
+        def touch(_p, i):
+            opt = me()
+            if opt is not None:
+                opt._touched[i] = True
+        self._hooks = [p.register_post_accumulate_grad_hook(lambda _p, i=i: touch(_p, i))
                        for i, (p, _, _) in enumerate(self.slots)]
         with torch.no_grad():
             for p, off, n in self.slots:
@@ -101,34 +114,57 @@ class FlatAdamW(torch.optim.Optimizer):
                 p.data = view                      # the module now computes on the flat buffer
         for i, (p, _, _) in enumerate(self.slots):
             GRAD_SLOTS[p.data_ptr()] = (weakref.ref(self), i)
-        self._flag_host = self._flag_event = None  # asynchronous copy of the device error flag (check_errors)
+        # asynchronous copies of the device error flag, one per step still unverified: (event, pinned copy, host
+        # counters before that step) — see check_errors
+        self._flag_log = []
+        self._flag_pool = []
         self._claimed = [False] * len(self.slots)  # slice handed to backward as an output this step (grad_out)
         self._clean = [True] * len(self.slots)     # slice known to be all zero
         self._release_grads()
 
-    def _touch(self, i):
-        self._touched[i] = True
-
     def check_errors(self, wait=True):
-        """Raise the IndexError of a step whose kernels saw an out-of-range id (that step's update was not applied, nor
-        any later one).  wait=False: only look at a flag copy that has already arrived... the copy of the previous
-        step has, by the time the next step's backward is over; wait=True (end of training, tests): synchronise."""
-        if self._flag_event is None:
-            return
-        if wait or self._flag_event.query():
-            self._flag_event.synchronize()
-            self._flag_event = None
-            code = int(self._flag_host[0])
+        """Raise the IndexError of a step whose kernels saw an out-of-range id.  That step's update was not applied on
+        the device (the update launch checks the flag itself), nor any later one — the flag is sticky until it is read
+        here — so the host's step counters are rolled back to what they were before the flagged step, and the gradient
+        bookkeeping is reset (the guarded launch cleared the flat gradient if asked to; it is cleared here otherwise):
+        a caller that catches the error and skips the batch continues from a consistent state.
+        wait=False: only look at flag copies that have already arrived — the copy of the previous step has, by the
+        time the next step's backward is over; wait=True (end of training, tests): synchronise."""
+        while self._flag_log:
+            event, host, snap = self._flag_log[0]
+            if not (wait or event.query()):
+                return
+            event.synchronize()
+            code = int(host[0])
+            self._flag_log.pop(0)
+            self._flag_pool.append(host)
             if code:
+                self.steps, self.slot_steps = snap
+                for _, h, _ in self._flag_log:             # later steps were skipped on the device as well
+                    self._flag_pool.append(h)
+                self._flag_log = []
+                self.flat_grad.zero_()
+                self._clean = [True] * len(self.slots)
+                self._touched = [False] * len(self.slots)
+                self._release_grads()
                 _lib.raise_device_errors(self.flat_param.device, code=code)
+
+    def close(self):
+        """Detach from the parameters: remove the autograd hooks (their closures keep this optimizer — four flat
+        buffers of the model's size — alive as long as the parameters live) and this optimizer's entries of the
+        gradient-slot registry.  Called automatically when another FlatAdamW is built over the same parameters."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p, _, _ in self.slots:
+            ent = GRAD_SLOTS.get(p.data_ptr())
+            if ent is not None and ent[0]() in (self, None):
+                del GRAD_SLOTS[p.data_ptr()]
 
     def __del__(self):
         # drop this optimizer's entries from the address registry (an address can be reused by another tensor)
         try:
-            for p, _, _ in self.slots:
-                ent = GRAD_SLOTS.get(p.data_ptr())
-                if ent is not None and ent[0]() in (self, None):
-                    del GRAD_SLOTS[p.data_ptr()]
+            self.close()
         except Exception:
             pass
 
@@ -146,9 +182,14 @@ class FlatAdamW(torch.optim.Optimizer):
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        t = torch.tensor(self._touched, dtype=torch.int32, device=self.flat_param.device)
+        # the device error flag travels with the flags: a rank whose kernels saw a bad id skips its update (the launch
+        # is guarded by the flag) — every rank must skip it then, and raise together, or the replicas diverge and the
+        # faulty rank leaves the others hanging in the next collective
+        flag = _lib.err_flag(self.flat_param.device)
+        t = torch.cat([torch.tensor(self._touched, dtype=torch.int32, device=self.flat_param.device), flag])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        self._touched = [bool(v) for v in t.tolist()]
+        flag.copy_(t[-1:])
+        self._touched = [bool(v) for v in t[:-1].tolist()]
 
     # ---- gradient views -------------------------------------------------------------------------
     def grad_view(self, slot):
@@ -209,6 +250,7 @@ class FlatAdamW(torch.optim.Optimizer):
         lib = _lib.lib()
         if self._ws is None:
             self._ws = torch.empty(lib.vh_adamw_ws_bytes() // 8, device=self.flat_param.device, dtype=torch.float64)
+        snap = (self.steps, list(self.slot_steps))  # restored by check_errors if this step turns out to be guarded off
         self.steps += 1
         # per-slot step counts: a slot without a gradient this step is skipped (no decay, no moments) and its
         # count stands still; when every slot has always been updated the kernel takes the uniform fast path
@@ -227,11 +269,11 @@ class FlatAdamW(torch.optim.Optimizer):
             float(g['weight_decay']), self.steps, float(grad_scale), float(max_norm), int(zero_grad),
             ptr(self._ws), ptr(self.grad_norm), ptr(block_slot), ptr(slot_step), ptr(flag),
             torch.cuda.current_stream().cuda_stream), 'vh_adamw_flat')
-        if self._flag_host is None:
-            self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory()
-        self._flag_host.copy_(flag, non_blocking=True)
-        self._flag_event = torch.cuda.Event()
-        self._flag_event.record()
+        host = self._flag_pool.pop() if self._flag_pool else torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(flag, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        self._flag_log.append((event, host, snap))
         if zero_grad:                              # the kernel cleared the flat gradient
             self._clean = [True] * len(self.slots)
             self._release_grads()

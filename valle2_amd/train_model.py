@@ -55,32 +55,44 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
     step, t0, losses = 0, time.perf_counter(), []
     optimizer.zero_grad()
     one_shot = iter(batches) is batches                  # a generator: a single epoch, then stop
+    pending = 0                                          # micro-batches accumulated since the last optimizer step
+
+    def optimizer_step():
+        nonlocal step, pending
+        reducer.finish()
+        optimizer.sync_touched()                         # same update decision per parameter on every rank
+        # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
+        optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
+        step += 1
+        if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
+            log(f'step {step}: train/loss {float(sum(losses[-pending:])) / pending:.4f} '
+                f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
+        pending = 0
+
     while step < config.max_steps:
-        seen = 0
-        for i, batch in enumerate(batches):
-            seen += 1
-            last = (i + 1) % accum == 0
+        steps_before = step
+        for batch in batches:
+            pending += 1
+            last = pending == accum                      # counted within the epoch: Lightning's accumulation window
             reducer.enabled = last                       # accumulate locally, exchange once per step
             loss = model.training_step(batch)
             (loss / accum).backward()                    # buckets are all-reduced as they complete
             losses.append(loss.detach())                 # stays on the device: no host synchronisation per step
-            if not last:
-                continue
-            reducer.finish()
-            optimizer.sync_touched()                     # same update decision per parameter on every rank
-            # mean over ranks + global-norm clip + AdamW + zeroing of the gradients: one flat pass
-            optimizer.step(grad_scale=1.0 / world, max_norm=config.gradient_clip_val, zero_grad=True)
-            step += 1
-            if rank == 0 and step % max(1, config.log_every_n_steps) == 0:
-                log(f'step {step}: train/loss {float(sum(losses[-accum:])) / accum:.4f} '
-                    f'({(time.perf_counter() - t0) / step * 1e3:.0f} ms/step, world {world})')
-            if step >= config.max_steps:
-                break
+            if last:
+                optimizer_step()
+                if step >= config.max_steps:
+                    break
+        if pending and step < config.max_steps:
+            # an epoch that ends inside an accumulation window: Lightning steps the optimizer on the incomplete window
+            # (the leftover micro-batches were accumulated with the exchange off: gather and reduce everything now)
+            optimizer.gather_grads()
+            reducer.enabled = True
+            optimizer_step()
         # Lightning steps a scheduler returned without an 'interval' once per EPOCH (the reference's
         # configure_optimizers returns {'optimizer', 'lr_scheduler'} only, valle_ar.py:182-194): T_0 =
         # lr_warmup counts epochs there, so it does here.
         scheduler.step()
-        if one_shot or seen == 0:
+        if one_shot or step == steps_before:             # a generator is one epoch; an epoch without a step is empty
             break
     optimizer.check_errors()          # a device-side range error of the last step (earlier ones raise at the next step)
     return model, [float(x) for x in losses]
