@@ -85,12 +85,15 @@ int vh_set_tuning(int knob, int value);
  * `tables` is a HOST array of n_tables device pointers, each (vocab[j], d); `vocab` is a HOST array of
  * the n_tables row counts.  An id outside [0, vocab[j]) reads row 0 instead (never out of bounds) and
  * ORs VH_DEVERR_EMBED_ID into *err_flag (device int32, may be NULL); the reference's nn.Embedding raises
- * IndexError there — the host side turns the flag into that exception at its next synchronisation. */
+ * IndexError there — the host side turns the flag into that exception at its next synchronisation.
+ * row_pos0 / row_t0 (device int32 (B), each may be NULL): per-row overrides of pos0 / out_t0 — a ragged batch whose
+ * rows sit at different offsets (text | prompt | target per utterance) is embedded by one launch. */
 enum { VH_DEVERR_EMBED_ID = 1, VH_DEVERR_TARGET = 2 };
 int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
                     int64_t ids_jstride, const float* const* tables, const int32_t* vocab, int n_tables,
                     const float* pe, int pos0, const int32_t* lens, float* out,
-                    int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag, void* stream);
+                    int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
+                    const int32_t* row_pos0, const int32_t* row_t0, void* stream);
 
 /* ---- K3/K4: LayerNorm (eps) with optional adaptive scale/shift ------------------------------
  * replaces nn.LayerNorm (valle/models/modules.py:284) and AdaptiveLayerNorm.forward (:93-99):
@@ -303,10 +306,14 @@ int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream, fl
  * GEMMs issued by the host; these entry points are the hand-written non-GEMM halves.  Gradient
  * buffers marked "+=" are accumulated with fp32 atomics: the caller zeroes them first. */
 /* LayerNorm / AdaptiveLayerNorm backward (modules.py:284, :93-99).  y = s*(gamma*xhat+beta)+t:
- * dx written; dgamma += , dbeta += , and when ada_scale != NULL dscale += , dshift += (all (d)). */
+ * dx written; dgamma += , dbeta += , and when ada_scale != NULL dscale += , dshift += (all (d)).
+ * dres (rows, d) | NULL: added to dx — the gradient of the pre-norm block's residual branch, which bypasses the norm
+ * (x feeds norm AND residual add, modules.py:271-279): no separate elementwise add.  dx must not alias dres.
+ * dcolsum (d) | NULL: += the column sums of the rows written to dx — the bias gradient of the Linear whose output x
+ * was (out-projection / linear_2), without a column-sum launch. */
 int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta, const float* ada_scale,
                      const float* dy, float* dx, float* dgamma, float* dbeta, float* dscale,
-                     float* dshift, int rows, int d, float eps, void* stream);
+                     float* dshift, const float* dres, float* dcolsum, int rows, int d, float eps, void* stream);
 /* exact-erf GELU on a saved pre-activation: dh == NULL → out = gelu(pre); else out = dh*gelu'(pre) */
 int vh_gelu(const float* pre, const float* dh, float* out, int64_t n, void* stream);
 /* P = softmax(S*scale + mask) in place over rows of (B,h,Tq,Tk) with row stride ld >= Tk; same mask
@@ -380,6 +387,11 @@ int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, con
 
 /* out (cols, ldo) = in (rows, cols)^T; out rows are zero-filled from `rows` up to ldo. */
 int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream);
+/* The same for n matrices in ONE launch (every Linear weight of the stack, once per optimizer step, for the dX
+ * products of the backward): `items` is a DEVICE array of n descriptors; tile0 = number of 32x32 output tiles of the
+ * items before this one (tiles of an item: ceil(cols / 32) * ceil(ldo / 32)), total_tiles their sum. */
+typedef struct { const float* in; float* out; int32_t ldi, rows, cols, ldo, tile0, pad_; } vh_transpose_item;
+int vh_transpose_many(const vh_transpose_item* items, int n, int total_tiles, void* stream);
 
 /* Weight gradient dW = dY^T . X of `loss.backward()` (valle/models/valle_ar.py:86):
  *   C (NI, NJ) = A^T . B,  A (M, NI) row stride lda, B (M, NJ) row stride ldb — both stored with the

@@ -18,7 +18,8 @@ cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, d
 torch.manual_seed(0)
 model = get_model_class('ValleAR')(cfg).cuda().train()
 opt = model.configure_optimizers()['optimizer']
-batch = {k: v.cuda() for k, v in synth.synth_ar_batch(cfg, 16, tok_range=(40, 120), code_range=(225, 900), seed=7).items()}
+batch = {k: (v if k.endswith('_lens') else v.cuda())          # lengths stay on the host, as the collate functions leave them
+         for k, v in synth.synth_ar_batch(cfg, 16, tok_range=(40, 120), code_range=(225, 900), seed=7).items()}
 
 
 def step():

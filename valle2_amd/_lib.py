@@ -66,7 +66,7 @@ SIGNATURES = {
     'vh_set_tuning': (C.c_int, [C.c_int, C.c_int]),
     'vh_embed_sum_pe': (C.c_int, [c_i64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_int32), C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64,
-                                  C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     'vh_layernorm': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                C.c_float, C.c_void_p]),
     'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
@@ -120,7 +120,7 @@ SIGNATURES = {
     'vh_ar_decoder_profile_attn': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'vh_layernorm_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                   c_f32p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+                                   c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'vh_gelu': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     'vh_softmax_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
@@ -133,6 +133,7 @@ SIGNATURES = {
     'vh_linear_ex': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_transpose': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
+    'vh_transpose_many': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'vh_gemm_tn_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'vh_gemm_tn': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -192,6 +193,18 @@ def ptr(t: torch.Tensor | None) -> int | None:
     if not t.is_contiguous():
         raise VhError('tensor must be contiguous')
     return t.data_ptr()
+
+
+def to_device_async(t: torch.Tensor, device, dtype=None) -> torch.Tensor:
+    """Small host tensor (lengths, ids) -> device without stalling the host: through pinned memory with a
+    stream-ordered copy.  A plain `.to(device)` of pageable memory waits until the stream has drained — in a training
+    loop that is the whole previous step, so the host could never enqueue ahead of the GPU (5 ms per step at
+    configs[3]).  A tensor that already lives on the device is only converted."""
+    if t.is_cuda:
+        return t.to(device=device, dtype=dtype or t.dtype)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
 
 
 def stream() -> int:

@@ -173,7 +173,7 @@ class LayerNormFn(torch.autograd.Function):
             s = s.contiguous()
             ds, dt = torch.zeros(d, device=x.device), torch.zeros(d, device=x.device)
         check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy),
-                                          ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(dt), rows, d, ctx.eps,
+                                          ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(dt), None, None, rows, d, ctx.eps,
                                           stream()), 'vh_layernorm_bwd')
         if ds is not None:
             ds, dt = ds.view_as(s), dt.view_as(s)
@@ -299,6 +299,113 @@ class CrossEntropyFn(torch.autograd.Function):
         return dl * g, None
 
 
+def _ln_bwd(x, gamma, beta, s, dy, dres, dcol, eps):
+    """LayerNorm / AdaLN backward with the residual-branch gradient added in the same pass and (optionally) the column
+    sums of the result accumulated into `dcol`.  Returns (dx, dgamma, dbeta, dscale, dshift)."""
+    d = x.shape[-1]
+    dx = torch.empty_like(x)
+    dg, db = optim.grad_out(gamma, zero=True), optim.grad_out(beta, zero=True)
+    ds = dt = None
+    if s is not None:
+        st = torch.zeros(2, d, device=x.device, dtype=torch.float32)
+        ds, dt = st[0], st[1]
+    check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy), ptr(dx),
+                                      ptr(dg), ptr(db), ptr(ds), ptr(dt), ptr(dres), ptr(dcol), x.numel() // d, d,
+                                      eps, stream()), 'vh_layernorm_bwd')
+    return dx, dg, db, ds, dt
+
+
+# bias gradients produced ahead of their layer's backward: layer l+1's LayerNorm backward writes dx — the gradient of
+# layer l's output — and accumulates its column sums, which ARE the gradient of layer l's linear_2 bias, into that
+# bias' gradient slot; layer l's backward picks the tensor up here instead of launching a column-sum kernel.
+# id(bias parameter) -> gradient tensor; filled and consumed inside one backward pass (cleared at every forward).
+_BIAS_GRAD_AHEAD = {}
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """One pre-norm block (modules.py:240-280, dropout off) as ONE autograd node:
+        xm = x + out(attn(qkv(norm1(x))));  y = xm + linear_2(gelu(linear_1(norm2(xm)))).
+    The forward is the kernel sequence of the separate Functions; the backward runs the whole block in one Python
+    call with the residual-gradient adds folded into the two LayerNorm backward launches, the out-projection's bias
+    gradient (and the linear_2 bias gradient of the layer BELOW) taken from those launches' column sums, and the
+    dX products reading weights transposed once per optimizer step for the whole stack (kernels.TransposePlan)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2, s1, t1, s2, t2):
+        B, T, n_heads, spec, eps, wts, below_b2 = meta
+        x = x.contiguous()
+        dev, d = x.device, x.shape[1]
+        det = lambda p: None if p is None else p.detach().contiguous()   # noqa: E731
+        xn1 = kernels.layernorm(x, g1.detach(), be1.detach(), ada_scale=det(s1), ada_shift=det(t1), eps=eps)
+        q = torch.empty(B * T, d, device=dev, dtype=torch.float32)
+        k = torch.empty(B, n_heads, T, HEAD_DIM, device=dev, dtype=torch.float32)
+        v = torch.empty_like(k)
+        kernels.linear_qkv(xn1, wqkv.detach(), q, k, v, B, T, n_heads)
+        a = torch.empty(B * T, d, device=dev, dtype=torch.float32)
+        lse2 = torch.empty(B, n_heads, T, device=dev, dtype=torch.float32)
+        kernels.attn_rows(q, k, v, a, B, n_heads, T, T, lse2=lse2, **spec)
+        xm = torch.empty_like(x)
+        kernels.linear(a, wo.detach(), bo.detach(), residual=x, out=xm)
+        xn2 = kernels.layernorm(xm, g2.detach(), be2.detach(), ada_scale=det(s2), ada_shift=det(t2), eps=eps)
+        pre = torch.empty(B * T, w1.shape[0], device=dev, dtype=torch.float32)
+        hid = torch.empty_like(pre)
+        kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU)
+        y = torch.empty_like(x)
+        kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=xm, out=y)
+        ctx.save_for_backward(x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2,
+                              b2, s1, s2)
+        ctx.meta = meta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2, s1,
+         s2) = ctx.saved_tensors
+        B, T, h, spec, eps, wts, below_b2 = ctx.meta
+        d = x.shape[1]
+        dy = dy.contiguous()
+        wqkv_t, wo_t, w1_t, w2_t = wts
+        det = lambda p: None if p is None else p.detach().contiguous()   # noqa: E731
+        # ---- FeedForward
+        dw2 = optim.grad_out(w2)
+        kernels.gemm_tn(dy, hid, out=dw2)                                  # dW2 = dY^T . hid
+        db2 = _BIAS_GRAD_AHEAD.pop(id(b2), None)                           # the layer above summed dY's columns already
+        if db2 is None:
+            db2 = _colsum(dy, b2)
+        dpre = torch.empty_like(pre)                                       # (dY . W2) * gelu'(pre)
+        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=kernels.ACT_GELU_BWD, K=w2_t.shape[1])
+        dw1 = optim.grad_out(w1)
+        kernels.gemm_tn(dpre, xn2, out=dw1)
+        db1 = _colsum(dpre, b1)
+        dxn2 = torch.empty_like(x)
+        kernels.linear_ex(dpre, w1_t, out=dxn2, K=w1_t.shape[1])
+        # ---- norm2 (+ the residual branch's dY, + the out-projection's bias gradient = column sums of the result)
+        dbo = optim.grad_out(bo, zero=True)
+        dxm, dg2, dbe2, ds2, dt2 = _ln_bwd(xm, g2, be2, det(s2), dxn2, dy, dbo, eps)
+        # ---- out-projection
+        dwo = optim.grad_out(wo)
+        kernels.gemm_tn(dxm, a, out=dwo)
+        da = torch.empty_like(x)
+        kernels.linear_ex(dxm, wo_t, out=da, K=wo_t.shape[1])
+        # ---- attention core + QKV projection
+        dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
+        kernels.attn_rows_bwd(q, k, v, a, da, lse2, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, T, **spec)
+        dwqkv = optim.grad_out(wqkv)
+        kernels.gemm_tn(dqkv, xn1, out=dwqkv)
+        dx = None
+        dg1 = dbe1 = ds1 = dt1 = None
+        dxn1 = torch.empty_like(x)
+        kernels.linear_ex(dqkv, wqkv_t, out=dxn1, K=wqkv_t.shape[1])
+        # ---- norm1 (+ the residual branch's gradient; + the bias gradient of the layer below's linear_2)
+        ahead = optim.grad_out(below_b2, zero=True) if below_b2 is not None else None
+        dx, dg1, dbe1, ds1, dt1 = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps)
+        if ahead is not None:
+            _BIAS_GRAD_AHEAD[id(below_b2)] = ahead
+        if s1 is not None:
+            ds1, dt1, ds2, dt2 = ds1.view_as(s1), dt1.view_as(s1), ds2.view_as(s2), dt2.view_as(s2)
+        return (dx, None, dwqkv, dwo, dbo, dg1, dbe1, dg2, dbe2, dw1, db1, dw2, db2, ds1, dt1, ds2, dt2)
+
+
 def linear(x, w, b=None, residual=None):
     return LinearFn.apply(x, w, b, residual)
 
@@ -340,7 +447,50 @@ def encoder_layer_train(layer, x, B, T, spec, embedding=None):
     return x
 
 
+def _stack_transposes(transformer):
+    """Wᵀ of every Linear of the stack for the backward's dX products, refreshed by one launch whenever a weight has
+    changed since the last refresh (an optimizer step, a load): [(Wqkvᵀ, Woᵀ, W1ᵀ, W2ᵀ)] per layer."""
+    from . import engine
+    layers = list(transformer.layers)
+    ws = [w for l in layers for w in (l.self_attn.qkv.weight, l.self_attn.out.weight, l.ffn.linear_1.weight,
+                                      l.ffn.linear_2.weight)]
+    ptrs = tuple(w.data_ptr() for w in ws)
+    state = getattr(transformer, '_vh_wt', None)
+    if state is None or state[0].key != ptrs:
+        plan = kernels.TransposePlan([w.detach() for w in ws], [kernels.pad32(w.shape[0]) for w in ws])
+        state = [plan, None]
+        transformer._vh_wt = state
+    version = (engine._WEIGHTS_EPOCH,) + tuple(w._version for w in ws)
+    if state[1] != version:
+        state[0].run()
+        state[1] = version
+    outs = state[0].outs
+    return [tuple(outs[4 * i:4 * i + 4]) for i in range(len(layers))]
+
+
 def transformer_train(transformer, x, B, T, spec, embedding=None):
-    for layer in transformer.layers:
-        x = encoder_layer_train(layer, x, B, T, spec, embedding)
+    layers = list(transformer.layers)
+    cfg = transformer.hparams
+    fused = (ATTENTION_BACKWARD == 'flash' and cfg.dim_feedforward % 32 == 0 and cfg.d_model % 32 == 0
+             and not any(m.training and m.p > 0 for l in layers for m in (l.dropout1, l.dropout2, l.ffn.dropout)))
+    if not fused:
+        for layer in layers:
+            x = encoder_layer_train(layer, x, B, T, spec, embedding)
+        return x
+    _BIAS_GRAD_AHEAD.clear()
+    wts = _stack_transposes(transformer)
+    for i, layer in enumerate(layers):
+        at, ff = layer.self_attn, layer.ffn
+        below_b2 = layers[i - 1].ffn.linear_2.bias if i > 0 else None
+        if cfg.norm == 'LayerNorm':
+            n1, n2, ada = layer.norm1, layer.norm2, (None, None, None, None)
+        else:
+            n1, n2 = layer.norm1.norm, layer.norm2.norm
+            wb1 = linear(embedding.reshape(1, -1), layer.norm1.project_layer.weight, layer.norm1.project_layer.bias).view(2, -1)
+            wb2 = linear(embedding.reshape(1, -1), layer.norm2.project_layer.weight, layer.norm2.project_layer.bias).view(2, -1)
+            ada = (wb1[0], wb1[1], wb2[0], wb2[1])
+        meta = (B, T, at.n_heads, spec, layer.norm1.eps, wts[i], below_b2)
+        x = EncoderLayerFn.apply(x, meta, at.qkv.weight, at.out.weight, at.out.bias, n1.weight, n1.bias, n2.weight,
+                                 n2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias,
+                                 *ada)
     return x

@@ -14,12 +14,15 @@ struct TablePtrs {
 __global__ __launch_bounds__(256) void embed_sum_pe_kernel(
     const int64_t* __restrict__ ids, int64_t ids_bs, int64_t ids_ts, int64_t ids_js, TablePtrs tabs,
     int n_tables, const float* __restrict__ pe, int pos0, const int32_t* __restrict__ lens,
-    float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d, int32_t* __restrict__ err_flag) {
+    float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d, int32_t* __restrict__ err_flag,
+    const int32_t* __restrict__ row_pos0, const int32_t* __restrict__ row_t0) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
     if (t >= T) return;
     if (lens && t >= lens[b]) return;
+    if (row_pos0) pos0 = row_pos0[b];               // ragged batches: every row its own position / output offset
+    if (row_t0) out_t0 = row_t0[b];
     const int64_t* idp = ids + b * ids_bs + t * ids_ts;
     // ids are range-checked here (the reference's nn.Embedding raises IndexError): an id outside its
     // table reads row 0 and raises the device flag the host polls at its next synchronisation
@@ -48,7 +51,7 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
                                int64_t ids_jstride, const float* const* tables, const int32_t* vocab,
                                int n_tables, const float* pe, int pos0, const int32_t* lens, float* out,
                                int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
-                               void* stream) {
+                               const int32_t* row_pos0, const int32_t* row_t0, void* stream) {
     VH_REQUIRE(ids && tables && vocab && out, VH_EINVAL, "vh_embed_sum_pe: null pointer");
     VH_REQUIRE(n_tables >= 1 && n_tables <= VH_MAX_TABLES, VH_EINVAL,
                "vh_embed_sum_pe: n_tables=%d not in 1..%d", n_tables, VH_MAX_TABLES);
@@ -68,7 +71,7 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
     dim3 grid((T + 3) / 4, B);
     hipLaunchKernelGGL(embed_sum_pe_kernel, grid, dim3(256), 0, (hipStream_t)stream, ids,
                        ids_bstride, ids_tstride, ids_jstride, tp, n_tables, pe, pos0, lens, out,
-                       out_bstride, out_t0, T, d, err_flag);
+                       out_bstride, out_t0, T, d, err_flag, row_pos0, row_t0);
     VH_CHECK_LAUNCH("vh_embed_sum_pe");
     return VH_OK;
 }

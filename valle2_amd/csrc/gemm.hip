@@ -1600,3 +1600,43 @@ extern "C" int vh_transpose(const float* in, int ldi, int rows, int cols, float*
     VH_CHECK_LAUNCH("vh_transpose");
     return VH_OK;
 }
+
+// Many transposes in one launch: workgroup = one 32x32 tile; the item is found by a scan of the (<= a few hundred)
+// descriptors' tile offsets by the first wave.
+__global__ __launch_bounds__(256) void transpose_many_kernel(const vh_transpose_item* __restrict__ items, int n) {
+    __shared__ float t[32][33];
+    __shared__ int s_item;
+    const int tile = blockIdx.x;
+    if (threadIdx.x < 64) {
+        int found = 0;
+        for (int i = threadIdx.x; i < n; i += 64)
+            if (items[i].tile0 <= tile) found = max(found, i);       // tile0 ascending: the last item starting at or before
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) found = max(found, __shfl_xor(found, o));
+        if (threadIdx.x == 0) s_item = found;
+    }
+    __syncthreads();
+    const vh_transpose_item it = items[s_item];
+    const int local = tile - it.tile0, tiles_x = (it.cols + 31) / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = (local / tiles_x) * 32, c0 = (local % tiles_x) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rr = r0 + ty + 8 * i, cc = c0 + tx;
+        t[ty + 8 * i][tx] = (rr < it.rows && cc < it.cols) ? it.in[(int64_t)rr * it.ldi + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int cc = c0 + ty + 8 * i, rr = r0 + tx;
+        if (cc < it.cols && rr < it.ldo) it.out[(int64_t)cc * it.ldo + rr] = t[tx][ty + 8 * i];
+    }
+}
+
+extern "C" int vh_transpose_many(const vh_transpose_item* items, int n, int total_tiles, void* stream) {
+    VH_REQUIRE(items && n > 0 && n <= 4096 && total_tiles > 0, VH_EINVAL, "vh_transpose_many: n=%d total_tiles=%d", n,
+               total_tiles);
+    hipLaunchKernelGGL(transpose_many_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, items, n);
+    VH_CHECK_LAUNCH("vh_transpose_many");
+    return VH_OK;
+}

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ s, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ds,
-    float* __restrict__ dt, int rows, int d, float eps) {
+    float* __restrict__ dt, const float* __restrict__ dres, float* __restrict__ dcol, int rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -38,6 +38,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         sc[i] = (in && s) ? ld4(s + c) : f32x4{1.f, 1.f, 1.f, 1.f};
         ag[i] = ab[i] = as[i] = at[i] = z;
     }
+    f32x4 ac[NV];                                   // column sums of the rows written to dx (dcol)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ac[i] = z;
     for (int row = wid; row < rows; row += nw) {
         const float* xr = x + (int64_t)row * d;
         const float* dyr = dy + (int64_t)row * d;
@@ -82,7 +85,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            if (c < d) st4(dx + (int64_t)row * d + c, (g[i] - m1 - v[i] * m2) * rstd);
+            if (c < d) {
+                f32x4 o = (g[i] - m1 - v[i] * m2) * rstd;
+                // the pre-norm block's residual branch: the gradient that bypasses the norm is added here instead of
+                // by a separate elementwise launch (x feeds the norm AND the residual add, modules.py:271-279)
+                if (dres) o += ld4(dres + (int64_t)row * d + c);
+                st4(dx + (int64_t)row * d + c, o);
+                if (dcol) ac[i] += o;
+            }
         }
     }
     // Column sums: the four waves of the workgroup meet in LDS first, so each column receives ONE atomic
@@ -104,26 +114,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         reduce_to(as, ds);
         reduce_to(at, dt);
     }
+    if (dcol) reduce_to(ac, dcol);
 }
 
 extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta,
                                 const float* ada_scale, const float* dy, float* dx, float* dgamma,
-                                float* dbeta, float* dscale, float* dshift, int rows, int d, float eps,
-                                void* stream) {
+                                float* dbeta, float* dscale, float* dshift, const float* dres, float* dcolsum,
+                                int rows, int d, float eps, void* stream) {
     VH_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, VH_EINVAL, "vh_layernorm_bwd: null pointer");
     VH_REQUIRE(!ada_scale || (beta && dscale && dshift), VH_EINVAL,
                "vh_layernorm_bwd: adaptive form needs beta, dscale, dshift");
     VH_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0 && d <= 2048, VH_EINVAL,
                "vh_layernorm_bwd: bad dims rows=%d d=%d (d multiple of 4, <= 2048)", rows, d);
     VH_REQUIRE(vh_aligned16(x) && vh_aligned16(dy) && vh_aligned16(dx) && vh_aligned16(gamma) &&
-                   vh_aligned16(beta) && vh_aligned16(ada_scale),
+                   vh_aligned16(beta) && vh_aligned16(ada_scale) && vh_aligned16(dres),
                VH_EALIGN, "vh_layernorm_bwd: pointers must be 16-byte aligned");
     if (rows == 0) return VH_OK;
     const int blocks = rows < 4 * 256 ? (rows + 3) / 4 : 256;
     hipStream_t st = (hipStream_t)stream;
 #define LNB(NV)                                                                                    \
     hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, gamma, beta,   \
-                       ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, rows, d, eps)
+                       ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, dres, dcolsum, rows, d, eps)
     if (d <= 256) LNB(1);
     else if (d <= 512) LNB(2);
     else if (d <= 1024) LNB(4);

@@ -24,9 +24,12 @@ def _f32(t, name):
     return t
 
 
-def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None):
+def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None, row_pos0=None, row_t0=None, max_pos=None):
     """out[b, out_t0+t] = sum_j tables[j][ids[b,t,j]] + pe[pos0+t].  ids (B,T) or (B,T,J) int64
-    (any strides); tables: list of (vocab,d); pe (P,1,d)|(P,d)|None; out (B,T_out,d)."""
+    (any strides); tables: list of (vocab,d); pe (P,1,d)|(P,d)|None; out (B,T_out,d).
+    lens / row_pos0 / row_t0: device int32 (B) — valid ids per row and per-row overrides of pos0 / out_t0 (a ragged
+    batch in one launch); with them the caller vouches, through `max_pos` (largest position + 1 any row reaches) and
+    its own layout, that positions stay inside the table and rows inside `out`."""
     if ids.dtype != torch.int64:
         raise _lib.VhError('ids must be int64')
     if ids.dim() == 2:
@@ -36,9 +39,17 @@ def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None):
     if n > J and J != 1:
         raise _lib.VhError(f'{n} tables but ids has {J} codebooks')
     d = tables[0].shape[1]
-    if out.dim() != 3 or out.shape[0] != B or out.shape[2] != d or out_t0 + T > out.shape[1]:
+    if out.dim() != 3 or out.shape[0] != B or out.shape[2] != d or (row_t0 is None and out_t0 + T > out.shape[1]):
         raise _lib.VhError(f'out shape {tuple(out.shape)} does not fit B={B} T={T} d={d} t0={out_t0}')
-    if pe is not None and pos0 + T > pe.shape[0]:
+    if row_pos0 is not None or row_t0 is not None:
+        for t_ in (row_pos0, row_t0, lens):
+            if t_ is not None and (t_.dtype != torch.int32 or t_.numel() != B or not t_.is_cuda):
+                raise _lib.VhError('embed_sum_pe: lens / row_pos0 / row_t0 must be device int32 tensors of B entries')
+        if lens is None or max_pos is None:
+            raise _lib.VhError('embed_sum_pe: per-row offsets need `lens` and `max_pos`')
+        if pe is not None and max_pos > pe.shape[0]:
+            raise _lib.VhError(f'position {max_pos} exceeds the table ({pe.shape[0]})')
+    elif pe is not None and pos0 + T > pe.shape[0]:
         raise _lib.VhError(f'position {pos0 + T} exceeds the table ({pe.shape[0]})')
     if not ids.is_cuda:
         raise _lib.VhError('embed_sum_pe: ids must be on the HIP device')
@@ -49,7 +60,7 @@ def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None):
     check(_lib.lib().vh_embed_sum_pe(
         ids.data_ptr(), ids.stride(0), ids.stride(1), ids.stride(2), arr, vocab, n,
         ptr(_f32(pe, 'pe')), pos0, ptr(lens), ptr(_f32(out, 'out')), out.stride(0), out_t0,
-        B, T, d, ptr(_lib.err_flag(out.device)), stream()), 'vh_embed_sum_pe')
+        B, T, d, ptr(_lib.err_flag(out.device)), ptr(row_pos0), ptr(row_t0), stream()), 'vh_embed_sum_pe')
     return out
 
 
@@ -61,7 +72,7 @@ def ids_to_device(ids, device, vocab, what):
         lo, hi = int(ids.min()), int(ids.max())
         if lo < 0 or hi >= vocab:
             raise IndexError(f'{what}: id {lo if lo < 0 else hi} is outside [0, {vocab}) (index out of range)')
-    return ids.to(device)
+    return _lib.to_device_async(ids, device)
 
 
 def _dev_f32(t, name):
@@ -355,6 +366,32 @@ def transpose(w, ldo=None, out=None):
     check(_lib.lib().vh_transpose(_dev_f32(w, 'w'), w.stride(0), rows, cols, _dev_f32(out, 'out'), ldo, stream()),
           'vh_transpose')
     return out
+
+
+class TransposePlan:
+    """Transposed copies (cols, ldo) of a fixed set of weight matrices, refreshed by ONE launch (vh_transpose_many).
+    The weights must stay where they are (parameters re-homed into FlatAdamW's flat buffer do; the plan is rebuilt by
+    its owner when a data_ptr changes)."""
+
+    def __init__(self, weights, ldos):
+        import numpy as np
+        dev = weights[0].device
+        self.outs = [torch.empty(w.shape[1], ldo, device=dev, dtype=torch.float32) for w, ldo in zip(weights, ldos)]
+        rec = np.zeros(len(weights), dtype=[('in', 'u8'), ('out', 'u8'), ('ldi', 'i4'), ('rows', 'i4'), ('cols', 'i4'),
+                                            ('ldo', 'i4'), ('tile0', 'i4'), ('pad', 'i4')])
+        tile = 0
+        for i, (w, ldo, o) in enumerate(zip(weights, ldos, self.outs)):
+            if w.dim() != 2 or w.stride(1) != 1 or w.dtype != torch.float32 or not w.is_cuda or ldo < w.shape[0]:
+                raise _lib.VhError('TransposePlan: row-major fp32 device matrices, ldo >= rows')
+            rec[i] = (w.data_ptr(), o.data_ptr(), w.stride(0), w.shape[0], w.shape[1], ldo, tile, 0)
+            tile += -(-w.shape[1] // 32) * -(-ldo // 32)
+        self.n, self.tiles = len(weights), tile
+        self.key = tuple(w.data_ptr() for w in weights)
+        self.items = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+
+    def run(self):
+        check(_lib.lib().vh_transpose_many(self.items.data_ptr(), self.n, self.tiles, stream()), 'vh_transpose_many')
+        return self.outs
 
 
 _tn_ws = {}

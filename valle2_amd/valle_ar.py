@@ -87,7 +87,7 @@ class ValleAR(_Base):
         x = torch.empty(b, tx + ty, d, device=dev, dtype=torch.float32)
         self._embed_rows(tokens[:, :tx], codes[:, :ty], x)
         # key padding covers audio only; text padding is NOT masked (valle_ar.py:69-73)
-        kv_len = (codes_lens.to(torch.int64) + tx).to(device=dev, dtype=torch.int32)
+        kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)
         cache = KVCache(self.config.num_layers, b, self.config.n_heads, tx + ty, dev)
         transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
         out = x[:, tx:].reshape(b * ty, d)
@@ -116,7 +116,7 @@ class ValleAR(_Base):
         if self.audio_position_emb.dropout.training and self.audio_position_emb.dropout.p > 0:
             xa = self.audio_position_emb.dropout(xa)
         x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
-        kv_len = (codes_lens.to(torch.int64) + tx).to(device=dev, dtype=torch.int32)
+        kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)
         spec = dict(mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
         x = A.transformer_train(self.transformer, x, b, tx + ty, spec)
         out = x.view(b, tx + ty, d)[:, tx:].reshape(b * ty, d)

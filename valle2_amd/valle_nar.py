@@ -192,16 +192,22 @@ class ValleNAR(_Base):
         if max(tc + ty for tc, ty in zip(tcs, tys)) > pe_a.shape[0] or max(txs) > pe_t.shape[0]:
             raise _lib.VhError('sequence exceeds the positional table (max_len 5000)')
         ty_max = max(tys)
+        pad = torch.nn.utils.rnn.pad_sequence                      # index plumbing: ragged id lists -> padded id tensors
+        i32 = lambda v: _lib.to_device_async(torch.tensor(v, dtype=torch.int32), dev)   # noqa: E731
         out = torch.zeros(B, ty_max, q, device=dev, dtype=torch.int64)
-        for b in range(B):
-            out[b, :tys[b], 0] = firsts[b]
-        # text and acoustic-prompt embeddings do not change from stage to stage: build them once
+        out[:, :, 0] = pad(firsts, batch_first=True)
+        tx_d, tc_d, ty_d = i32(txs), i32(tcs), i32(tys)
+        t0_target = i32([a + c for a, c in zip(txs, tcs)])
+        valid = torch.arange(ty_max, device=dev)[None, :] < ty_d[:, None]          # (B, ty_max) target frames that exist
+        # text and acoustic-prompt embeddings do not change from stage to stage: build them once, ONE launch each for
+        # the whole ragged batch (per-row lengths and offsets travel to the kernel)
         base = torch.zeros(B, total, d, device=dev, dtype=torch.float32)
-        for b in range(B):
-            kernels.embed_sum_pe(texts[b].unsqueeze(0), [self.tokens_emb.weight.detach()], pe_t, 0, base[b:b + 1])
-            if tcs[b]:
-                kernels.embed_sum_pe(pcs[b].unsqueeze(0), self._tables(q), pe_a, 0, base[b:b + 1], out_t0=txs[b])
-        kv_len = torch.tensor(lens, device=dev, dtype=torch.int32) if len(set(lens)) > 1 else None
+        kernels.embed_sum_pe(pad(texts, batch_first=True), [self.tokens_emb.weight.detach()], pe_t, 0, base, lens=tx_d,
+                             row_t0=torch.zeros_like(tx_d), max_pos=max(txs))
+        if max(tcs):
+            kernels.embed_sum_pe(pad(pcs, batch_first=True), self._tables(q), pe_a, 0, base, lens=tc_d, row_t0=tx_d,
+                                 max_pos=max(tcs))
+        kv_len = i32(lens) if len(set(lens)) > 1 else None
         # flat row indices of every target frame, and where each row's run starts in the packed logits
         idx = torch.cat([torch.arange(tys[b], device=dev) + (b * total + txs[b] + tcs[b]) for b in range(B)])
         starts = [0]
@@ -215,16 +221,14 @@ class ValleNAR(_Base):
         toks = torch.empty(starts[-1], device=dev, dtype=torch.int64)
         for n in range(1, q):
             x.copy_(base)
-            for b in range(B):
-                kernels.embed_sum_pe(out[b:b + 1, :tys[b]], self._tables(n), pe_a, tcs[b], x[b:b + 1],
-                                     out_t0=txs[b] + tcs[b])
+            kernels.embed_sum_pe(out, self._tables(n), pe_a, 0, x, lens=ty_d, row_pos0=tc_d, row_t0=t0_target,
+                                 max_pos=max(tc + ty for tc, ty in zip(tcs, tys)))
             transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
                                 embedding=self.stage_embs[n - 1].weight.detach(), scratch=scratch)
             z = x.view(B * total, d).index_select(0, idx)                      # target frames of every row
             logits = kernels.linear(z, self.proj_layers[n - 1].weight.detach())
             kernels.categorical_rows(logits, toks, temperature=cfg.temperature, greedy=greedy, seed=seed,
                                      stream_id=n)
-            for b in range(B):
-                out[b, :tys[b], n] = toks[starts[b]:starts[b + 1]]
+            out[:, :, n][valid] = toks                                          # packed row-major -> (B, ty_max)
         _lib.raise_device_errors(dev)
         return [out[b, :tys[b]].clone() for b in range(B)]
