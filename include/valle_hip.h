@@ -72,7 +72,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
                                        for the remainder); 1 = one graph launch per step */
        VH_TUNE_FFN_SLICE = 7,       /* vh_ffn_decode: hidden columns per workgroup, 0 (default) = chosen from the shape, else 16 / 32 */
        VH_TUNE_FFN_ROWS = 8,        /* vh_ffn_decode: rows per workgroup, 0 (default) = chosen from the shape, else 8 / 16 */
-       VH_TUNE_COUNT = 9 };
+       VH_TUNE_LN_STATS = 9,        /* folded-LayerNorm decode GEMMs on <= 16 rows per workgroup: 0 (default) = row statistics from
+                                       the operand fragments (no second read of the rows), 1 = from their own row loads */
+       VH_TUNE_COUNT = 10 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------

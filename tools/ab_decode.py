@@ -27,6 +27,7 @@ def main(rounds=8):
     # 8 = rows per workgroup, 0 = decode attention variant)
     forms = {'default': {},
              'ffn three launches': {5: 1},
+             'qkv statistics from row loads': {9: 1},
              'ffn fused 32 x 16 rows': {7: 32, 8: 16},
              'ffn fused 16 x 16 rows': {7: 16, 8: 16}}
     if len(sys.argv) > 1:
@@ -37,14 +38,14 @@ def main(rounds=8):
     lib = _lib.lib()
     for r in range(rounds + 1):
         for name, knobs in forms.items():
-            for k in (0, 5, 7, 8):
+            for k in (0, 5, 7, 8, 9):
                 lib.vh_set_tuning(k, knobs.get(k, 0))
             out = m.generate_batch(texts, firsts)
             torch.cuda.synchronize()
             if r:
                 res[name].append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
             outs[name] = out
-    for k in (0, 5, 7, 8):
+    for k in (0, 5, 7, 8, 9):
         lib.vh_set_tuning(k, 0)
     for name, v in res.items():
         print(f'{name:46s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')

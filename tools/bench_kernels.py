@@ -140,6 +140,8 @@ def bench_gemm():
         'ffn fused slice 16 x 8 rows': tuned2(16, 8, ffn),
         'ffn three launches (ffn1 fold + ffn2 split-K + reduce)': ffn_three,
         'qkv fold': lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl),
+        'qkv fold, statistics from row loads': tuned(9, 1, lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl)),
+        'ffn1 fold, statistics from row loads': tuned(9, 1, lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1)),
         'qkv fold, no row groups': tuned(2, 2, lambda: K.linear_qkv_folded(x, fq[nxt()], q, kc, vc, B, 1, 8, cache_len=cl)),
         'ffn1 fold, no row groups': tuned(2, 2, lambda: K.linear_folded(x, f1[nxt()], out=o2, act=1)),
         'out-proj, no row groups': tuned(2, 2, lambda: K.linear(x, wo[nxt()], bo, o1, out=o1)),

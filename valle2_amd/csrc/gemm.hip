@@ -756,7 +756,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 // LN: 0 = none; 1 = rows normalised in the operand load (statistics first, then the products);
 //     2 = folded (vh_ln_fold): the products run on the raw rows against W∘gamma while the statistics
 //         are computed beside them, and the epilogue applies rstd·(acc − mean·c1) + c2 — no
-//         statistics → normalise → MFMA dependency, one workgroup barrier instead of two.
+//         statistics → normalise → MFMA dependency, one workgroup barrier instead of two;
+//     3 = folded, statistics taken from the OPERAND FRAGMENTS (MT = 1): no second read of the rows — the rows are
+//         fresh data of the previous launch, written on other XCDs, and every KB a workgroup pulls of them costs
+//         (profiles/r3_probe_launch_floor.log: ~16 GB/s per CU); one-pass sums about the row's first element.
 template <int MT, int NW, int EPI, int PW, int LN, int NJ>
 __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
@@ -776,6 +779,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     }
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     __shared__ float s_mean[16 * MT], s_rstd[16 * MT];
+    __shared__ __attribute__((aligned(16))) float pst[LN == 3 ? 16 : 1][2 * NW];   // LN == 3: (sum, sum of squares) per wave and row
+    static_assert(LN != 3 || (MT == 1 && NW == 8), "fragment statistics: one row tile, eight waves");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
@@ -803,7 +808,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     // Issue order = return order for s_waitcnt: the LayerNorm rows (L2 hits) go first so their
     // reduction overlaps the weight loads (HBM) issued right behind them; the sched_barrier keeps
     // hipcc from sinking loads between the MFMAs (it would trade round trips for registers).
-    constexpr int ROUNDS = LN ? (16 * MT + 4 * NW - 1) / (4 * NW) : 0;
+    constexpr bool ROWSTATS = LN == 1 || LN == 2;           // statistics from their own loads of whole rows
+    constexpr int ROUNDS = ROWSTATS ? (16 * MT + 4 * NW - 1) / (4 * NW) : 0;
     f32x4 v[NJ];
     auto ln_load = [&](int r0) {
         const int row = (r0 * NW + w) * 4 + g;
@@ -828,7 +834,9 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
         if (i == 0 && row < a.M) { s_mean[row] = mu; s_rstd[row] = rsqrtf(var + ln.eps); }
     };
     STAMP(0);
-    if (LN) ln_load(0);
+    if (ROWSTATS) ln_load(0);
+    float shift = 0.f, fsa = 0.f, fsb = 0.f;               // LN == 3: statistics about the row's first element
+    if (LN == 3) shift = a.A[(int64_t)min(i, a.M - 1) * a.lda];
     issue(0);
     // Epilogue operands (bias / residual / cache position) are fetched NOW by the lanes that will
     // finalise (wave w finalises m-tile w): loaded in the epilogue they would add one more
@@ -838,7 +846,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_res = {0.f, 0.f, 0.f, 0.f}, e_c1 = {0.f, 0.f, 0.f, 0.f};
     int e_pos = 0;
     if (fin) {
-        if (LN == 2) {                       // c2 carries the bias
+        if (LN >= 2) {                       // c2 carries the bias
             e_c1 = ld4(ln.c1 + en);
             e_bias = ld4(ln.c2 + en);
         } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
@@ -849,7 +857,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     STAMP(1);
 
     float mean[MT], rstd[MT];
-    if (LN) {
+    if (ROWSTATS) {
         ln_reduce(0);
 #pragma unroll 1
         for (int r0 = 1; r0 < ROUNDS; ++r0) {
@@ -886,6 +894,14 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
                                     ld4(ln.ada_shift + koff + kbase + 16 * c);
                 }
         }
+        if (LN == 3) {
+#pragma unroll
+            for (int c = 0; c < PW; ++c) {
+                const f32x4 t = xf[c][0] - shift;
+                fsa += (t.x + t.y) + (t.z + t.w);
+                fsb += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+            }
+        }
 #pragma unroll
         for (int c = 0; c < PW; ++c)
 #pragma unroll
@@ -900,6 +916,11 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) st4(&red[w][mt][lane][0], acc[mt]);
+    if (LN == 3) {      // fold the wave's four k groups (lanes i, i+16, i+32, i+48), one pair per wave and row
+        fsa += __shfl_xor(fsa, 16, 64); fsb += __shfl_xor(fsb, 16, 64);
+        fsa += __shfl_xor(fsa, 32, 64); fsb += __shfl_xor(fsb, 32, 64);
+        if (g == 0) { pst[i][2 * w] = fsa; pst[i][2 * w + 1] = fsb; }
+    }
     STAMP(3);
     __syncthreads();
     STAMP(4);
@@ -908,6 +929,19 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
         f32x4 sacc = ld4(&red[0][mt][lane][0]);
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) sacc += ld4(&red[ww][mt][lane][0]);
+        if (LN == 3 && fin) {                // the 8 waves' partial sums, added in wave order
+            f32x4 p[NW / 2];
+#pragma unroll
+            for (int q4 = 0; q4 < NW / 2; ++q4) p[q4] = ld4(&pst[i][4 * q4]);
+            float sa = p[0].x, sb = p[0].y;
+            sa += p[0].z; sb += p[0].w;
+#pragma unroll
+            for (int q4 = 1; q4 < NW / 2; ++q4) { sa += p[q4].x; sb += p[q4].y; sa += p[q4].z; sb += p[q4].w; }
+            const float dm = sa / (float)a.K;
+            const float var = fmaxf(sb / (float)a.K - dm * dm, 0.f);
+            sacc = (sacc - (shift + dm) * e_c1) * rsqrtf(var + ln.eps);
+            if (EPI == EPI_QKV) sacc += e_bias;
+        }
         if (LN == 2 && fin) {                // statistics were published before the barrier above
             const float mu = s_mean[em], rs = s_rstd[em];
             sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
@@ -1065,6 +1099,14 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         return VH_OK;                                                          \
     } while (0)
         if (has_ln) {  // K <= 1024 (check_gemm); statistics need K = 64*NJ
+            if (fold && (rowgroups || mt == 1) && vh_tuning(VH_TUNE_LN_STATS) != 1) {   // statistics from the fragments
+#define SF3(NW, PW) do { SF(1, NW, PW, 3, 1); VH_CHECK_LAUNCH(name); return VH_OK; } while (0)
+                if (a.K == 128) SF3(8, 1);
+                if (a.K == 256) SF3(8, 2);
+                if (a.K == 512) SF3(8, 4);
+                if (a.K == 1024) SF3(8, 4);
+#undef SF3
+            }
             if (fold) {
                 if (a.K == 128) SF_MT(8, 1, 2, 2);
                 if (a.K == 256) SF_MT(8, 2, 2, 4);
