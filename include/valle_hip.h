@@ -219,6 +219,22 @@ size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
 int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
                    int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,
                    int n_split, void* partial, void* stream);
+/* ---- perf mode of the decode step: bf16 K/V cache (opt-in; never the parity path) ---------------
+ * SURVEY.md section 7's "perf mode": the K/V cache — 93 % of the bytes a decode step reads at configs[1] — stored
+ * as bf16 (B, h, S_max, 64), everything else (weights, q, softmax, accumulators, residual stream) fp32 as in the parity
+ * path.  Greedy tokens are NOT guaranteed to equal the reference's; teacher-forced logits agree to atol 5e-2.
+ *   vh_kv_to_bf16            narrows the first `rows` rows of n_streams (b, head) streams of an fp32 cache (row stride
+ *                            64, stream stride S_src * 64) into a bf16 cache (stream stride S_dst * 64), round to
+ *                            nearest even: the prompt pass runs in fp32 and is narrowed once;
+ *   vh_linear_qkv_folded_kv16  vh_linear_qkv_folded for one new row per sequence with the K / V rows appended as bf16;
+ *   vh_attn_decode_kv16      vh_attn_decode (one (b, head) per workgroup, no key split) over the bf16 cache. */
+int vh_kv_to_bf16(const float* src, uint16_t* dst, int n_streams, int rows, int S_src, int S_dst, void* stream);
+int vh_linear_qkv_folded_kv16(const float* A, int lda, const float* Wf, const float* c1, const float* c2, float* q_out,
+                              int ldq, uint16_t* kcache16, uint16_t* vcache16, const int32_t* cache_len, int B,
+                              int d_model, int n_heads, int S_max, float ln_eps, void* stream);
+int vh_attn_decode_kv16(const float* q, int ldq, const uint16_t* kcache16, const uint16_t* vcache16, float* out, int ldo,
+                        const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max, void* stream);
+
 /* ---- K12/K13: greedy sampling + decode-state update + next-token embedding ------------------
  * replaces topk_sampling(top_k=1) (valle/models/utils.py:46-68: argmax, lowest index on ties),
  * the EOS bookkeeping valle/models/valle_ar.py:167-171 and the re-embedding :143-144 for the
@@ -284,6 +300,9 @@ typedef struct {
      * layer the FeedForward of a layer is vh_ffn_decode (two launches instead of three). */
     void *ffn_ws;
     size_t ffn_ws_bytes;
+    /* perf mode (opt-in): nonzero = every layer's kcache / vcache point at bf16 caches (B,h,S_max,64) and the step
+     * runs vh_linear_qkv_folded_kv16 + vh_attn_decode_kv16; needs folded weights in every layer and n_split == 1. */
+    int kv_bf16;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

@@ -638,3 +638,56 @@ def test_ffn_decode_argument_checks(K):
                      workspace=torch.empty(1 << 16, device=DEV))
 
 
+
+
+# ---- perf mode: bf16 K/V cache (opt-in) ---------------------------------------------------------
+@pytest.mark.parametrize('S_max', [64, 320, 1120])
+def test_attn_decode_kv16_matches_fp32_math_on_the_rounded_cache(K, S_max):
+    """vh_attn_decode_kv16 against fp32 attention over the SAME bf16-rounded K/V (the kernel's arithmetic is fp32: what it
+    may differ by is summation order), ragged lengths at chunk edges, NaN / Inf beyond every row's length."""
+    B, h = 32, 8
+    d = 64 * h
+    gen = g(170 + S_max)
+    q = torch.randn(B, d, generator=gen)
+    k = torch.randn(B, h, S_max, 64, generator=gen).bfloat16()
+    v = torch.randn(B, h, S_max, 64, generator=gen).bfloat16()
+    edges = [1, 2, 5, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1087]
+    lens = torch.tensor([min(S_max, edges[i % len(edges)] + (i // len(edges))) for i in range(B)], dtype=torch.int32)
+    ref = torch.empty(B, d)
+    for b in range(B):
+        L = int(lens[b])
+        ref[b] = _sdpa_ref(q[b].view(1, h, 1, 64), k[b:b + 1, :, :L].float(), v[b:b + 1, :, :L].float(), None).reshape(d)
+        k[b, :, L:] = float('nan')
+        v[b, :, L:] = float('inf')
+    out = torch.full((B, d), float('nan'), device=DEV)
+    K.attn_decode_kv16(q.to(DEV), k.to(DEV), v.to(DEV), out, (lens - 1).to(DEV), 1)
+    assert bool(torch.isfinite(out).all()), 'garbage beyond a row\'s length leaked into the attention output'
+    close(out, ref, atol=3e-5)
+
+
+def test_kv_narrowing_and_bf16_append_round_to_nearest_even(K):
+    """vh_kv_to_bf16 == torch's .bfloat16() bit for bit on the valid rows; vh_linear_qkv_folded_kv16 appends exactly the
+    bf16 rounding of what vh_linear_qkv_folded appends in fp32, and leaves q untouched."""
+    from valle2_amd import engine
+    L, B, h, S0, S1 = 2, 5, 2, 37, 64
+    cache = engine.KVCache(L, B, h, S0, DEV)
+    cache.buf.copy_(torch.randn(cache.buf.shape, generator=g(191)) * 3)
+    narrow = cache.narrowed(S1)
+    assert narrow.buf.dtype == torch.bfloat16 and tuple(narrow.buf.shape) == (L, 2, B, h, S1, 64)
+    assert torch.equal(narrow.buf[..., :S0, :].view(torch.int16), cache.buf.bfloat16().view(torch.int16))
+    d = 64 * h
+    gen = g(192)
+    x = (torch.randn(B, d, generator=gen) + 0.2).to(DEV)
+    w = (0.1 * torch.randn(3 * d, d, generator=gen)).to(DEV)
+    folded = K.ln_fold(w, (1 + 0.2 * torch.randn(d, generator=gen)).to(DEV), (0.2 * torch.randn(d, generator=gen)).to(DEV))
+    cl = torch.tensor([3, 0, 36, 10, 63], dtype=torch.int32, device=DEV)
+    k32, v32 = torch.zeros(B, h, S1, 64, device=DEV), torch.zeros(B, h, S1, 64, device=DEV)
+    q32 = torch.empty(B, d, device=DEV)
+    K.linear_qkv_folded(x, folded, q32, k32, v32, B, 1, h, cache_len=cl)
+    k16 = torch.zeros(B, h, S1, 64, device=DEV, dtype=torch.bfloat16)
+    v16 = torch.zeros_like(k16)
+    q16 = torch.empty(B, d, device=DEV)
+    K.linear_qkv_folded_kv16(x, folded, q16, k16, v16, h, cl)
+    assert torch.equal(q16, q32)
+    assert torch.equal(k16.view(torch.int16), k32.bfloat16().view(torch.int16))
+    assert torch.equal(v16.view(torch.int16), v32.bfloat16().view(torch.int16))

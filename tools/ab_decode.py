@@ -26,6 +26,7 @@ def main(rounds=8):
     # name -> {tuning knob: value} (include/valle_hip.h: 5 = FeedForward fused / three launches, 7 = slice width,
     # 8 = rows per workgroup, 0 = decode attention variant)
     forms = {'default': {},
+             'perf mode (bf16 K/V cache)': {'perf': 1},
              'ffn three launches': {5: 1},
              'qkv statistics from row loads': {9: 1},
              'ffn fused 32 x 16 rows': {7: 32, 8: 16},
@@ -40,7 +41,7 @@ def main(rounds=8):
         for name, knobs in forms.items():
             for k in (0, 5, 7, 8, 9):
                 lib.vh_set_tuning(k, knobs.get(k, 0))
-            out = m.generate_batch(texts, firsts)
+            out = m.generate_batch(texts, firsts, perf_mode=bool(knobs.get('perf')))
             torch.cuda.synchronize()
             if r:
                 res[name].append(m.last_generate_stats['decode_ms'] / 511 * 1e3)

@@ -43,7 +43,7 @@ class VhArDecoderDesc(C.Structure):
         ('cache_len', C.c_void_p), ('audio_pos', C.c_void_p), ('eos_count', C.c_void_p),
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
-        ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t),
+        ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t), ('kv_bf16', C.c_int),
     ]
 
 
@@ -97,6 +97,11 @@ SIGNATURES = {
     'vh_attn_rows_bwd': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
                                    c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
+    'vh_kv_to_bf16': (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_linear_qkv_folded_kv16': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
+                                            C.c_void_p, c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    'vh_attn_decode_kv16': (C.c_int, [c_f32p, C.c_int, C.c_void_p, C.c_void_p, c_f32p, C.c_int, c_i32p, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p]),
     'vh_attn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

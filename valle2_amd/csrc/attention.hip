@@ -355,6 +355,161 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
     }
 }
 
+// =============================================================================================
+// perf mode: the same single-row attention over a bf16 K/V cache (B, h, S_max, 64) — half the bytes of the stream
+// that bounds the decode step; q, the softmax and the accumulators stay fp32.  A key row is 64 x 2 B = 128 B = 8
+// lanes x 16 B: lane l holds dimensions 8 (l & 7) .. +7 of key (l >> 3) of a group of 8 keys, so one wave-instruction
+// still moves 1 KiB.  Ring of D register sets of 32 keys (4 loads per operand and set), speculative first bursts
+// before the row's length is known, non-temporal loads — the structure of attn_decode_ring_kernel.
+// =============================================================================================
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x4 ld16_stream(const uint16_t* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+// sum over the 8 lanes of a half DPP row (lanes 8j .. 8j+7)
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_get<0xB1, 0xF>(v, 0.f);
+    v += dpp_get<0x4E, 0xF>(v, 0.f);
+    v += dpp_get<0x141, 0xF>(v, 0.f);     // row_half_mirror: lane i <-> 7 - i inside each half row
+    return v;
+}
+#define BF_LO(w) __uint_as_float((w) << 16)
+#define BF_HI(w) __uint_as_float((w) & 0xffff0000u)
+
+template <int NW, int D>
+__global__ __launch_bounds__(NW * 64) void attn_decode_ring16_kernel(
+    const float* __restrict__ q, int ldq, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    float* __restrict__ out, int ldo, const int32_t* __restrict__ cache_len, int len_bias, int n_heads, int S_max) {
+    __shared__ float s_m[NW], s_l[NW];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
+    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c8 = lane & 7, kg = lane >> 3;
+    const uint16_t* kb = kc + (int64_t)bh * S_max * HD + 8 * c8;
+    const uint16_t* vb = vc + (int64_t)bh * S_max * HD + 8 * c8;
+    constexpr int LPS = 4;                                         // 8 keys per wave-instruction
+    u32x4 kf[D][LPS], vf[D][LPS];
+    int key_limit = S_max - 1;
+    auto load = [&](int c, u32x4 (&kq)[LPS], u32x4 (&vq)[LPS]) {
+        const int key0 = c * 32 + kg;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const int key = min(key0 + 8 * i, key_limit);
+            kq[i] = ld16_stream(kb + (int64_t)key * HD);
+            vq[i] = ld16_stream(vb + (int64_t)key * HD);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load(w + j * NW, kf[j], vf[j]);
+    const int len = cache_len[b] + len_bias;
+    const int c_end = (len + 31) / 32;
+    key_limit = len - 1;
+    const float qscale = 0.125f * LOG2E;
+    const float* qp = q + (int64_t)b * ldq + head * HD + 8 * c8;
+    const f32x4 qa = ld4(qp) * qscale, qb = ld4(qp + 4) * qscale;
+
+    float m = NEG_INF, l = 0.f;
+    f32x4 oa = {0.f, 0.f, 0.f, 0.f}, ob = {0.f, 0.f, 0.f, 0.f};
+    auto reduce = [&](int c, const u32x4 (&kq)[LPS], const u32x4 (&vq)[LPS]) {
+        const int key0 = c * 32 + kg;
+        const bool whole = c * 32 + 32 <= len;
+        float sc[LPS];
+        float cmax = NEG_INF;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const u32x4 kk = kq[i];
+            float d = BF_LO(kk.x) * qa.x + BF_HI(kk.x) * qa.y + BF_LO(kk.y) * qa.z + BF_HI(kk.y) * qa.w;
+            d += BF_LO(kk.z) * qb.x + BF_HI(kk.z) * qb.y + BF_LO(kk.w) * qb.z + BF_HI(kk.w) * qb.w;
+            d = row8_sum(d);
+            sc[i] = (whole || key0 + 8 * i < len) ? d : NEG_INF;
+            cmax = fmaxf(cmax, sc[i]);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 8, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m, cmax);
+        const float alpha = vh_exp2(m - m_new);
+        oa *= alpha; ob *= alpha;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) {
+            const float p = vh_exp2(sc[i] - m_new);
+            l += p;
+            u32x4 vv = vq[i];
+            if (!(whole || key0 + 8 * i < len)) vv = u32x4{0u, 0u, 0u, 0u};   // rows beyond the length: select, not * 0
+            oa += f32x4{BF_LO(vv.x), BF_HI(vv.x), BF_LO(vv.y), BF_HI(vv.y)} * p;
+            ob += f32x4{BF_LO(vv.z), BF_HI(vv.z), BF_LO(vv.w), BF_HI(vv.w)} * p;
+        }
+        m = m_new;
+    };
+    for (int c0 = w; c0 < c_end; c0 += D * NW) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int c = c0 + j * NW;
+            if (c < c_end) {
+                const int cn = c + (D - 1) * NW;
+                if (cn < c_end) load(cn, kf[(j + D - 1) % D], vf[(j + D - 1) % D]);
+                reduce(c, kf[j], vf[j]);
+            }
+        }
+    }
+    // fold the 8 key groups of the wave (lanes l, l^8, l^16, l^32 hold the same dimensions)
+#pragma unroll
+    for (int sh = 8; sh <= 32; sh <<= 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            oa[j] += __shfl_xor(oa[j], sh, 64);
+            ob[j] += __shfl_xor(ob[j], sh, 64);
+        }
+        l += __shfl_xor(l, sh, 64);
+    }
+    if (lane < 8) { st4(&s_o[w][8 * c8], oa); st4(&s_o[w][8 * c8 + 4], ob); }
+    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
+    __syncthreads();
+    if (tid < HD) {
+        float M = s_m[0];
+#pragma unroll
+        for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
+        float L = 0.f, O = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
+            L += s_l[k] * wgt;
+            O += s_o[k][tid] * wgt;
+        }
+        out[(int64_t)b * ldo + head * HD + tid] = O / L;
+    }
+}
+
+// fp32 cache rows -> bf16 cache rows (round to nearest even): the prompt pass runs in fp32, its K/V are narrowed once
+__global__ __launch_bounds__(256) void kv_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                         int rows, int64_t src_stride, int64_t dst_stride) {
+    const int stream = blockIdx.y;
+    const float* s = src + (int64_t)stream * src_stride;
+    uint16_t* d = dst + (int64_t)stream * dst_stride;
+    const int64_t n8 = (int64_t)rows * HD / 8;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f32x4 a = ld4(s + 8 * i), c = ld4(s + 8 * i + 4);
+        auto bf = [](float x) { const uint32_t u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
+        u32x4 o;
+        o.x = bf(a.x) | (bf(a.y) << 16); o.y = bf(a.z) | (bf(a.w) << 16);
+        o.z = bf(c.x) | (bf(c.y) << 16); o.w = bf(c.z) | (bf(c.w) << 16);
+        *reinterpret_cast<u32x4*>(d + 8 * i) = o;
+    }
+}
+
+extern "C" int vh_kv_to_bf16(const float* src, uint16_t* dst, int n_streams, int rows, int S_src, int S_dst, void* stream) {
+    VH_REQUIRE(src && dst && n_streams > 0 && rows >= 0 && rows <= S_src && rows <= S_dst, VH_EINVAL,
+               "vh_kv_to_bf16: n_streams=%d rows=%d S_src=%d S_dst=%d", n_streams, rows, S_src, S_dst);
+    VH_REQUIRE(vh_aligned16(src) && vh_aligned16(dst), VH_EALIGN, "vh_kv_to_bf16: pointers must be 16-byte aligned");
+    if (rows == 0) return VH_OK;
+    const int bx = (int)min((int64_t)64, ((int64_t)rows * HD / 8 + 255) / 256);
+    hipLaunchKernelGGL(kv_to_bf16_kernel, dim3(bx, n_streams), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
+                       (int64_t)S_src * HD, (int64_t)S_dst * HD);
+    VH_CHECK_LAUNCH("vh_kv_to_bf16");
+    return VH_OK;
+}
+
 static thread_local hipEvent_t g_attn_ev[2] = {nullptr, nullptr};
 void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop) { g_attn_ev[0] = start; g_attn_ev[1] = stop; }
 
@@ -373,6 +528,28 @@ __global__ __launch_bounds__(64) void attn_decode_combine_kernel(
         O += pr[s * PART_LD + tid] * wgt;
     }
     out[(int64_t)b * ldo + head * HD + tid] = O / L;
+}
+
+extern "C" int vh_attn_decode_kv16(const float* q, int ldq, const uint16_t* kcache16, const uint16_t* vcache16,
+                                   float* out, int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads,
+                                   int S_max, void* stream) {
+    VH_REQUIRE(q && kcache16 && vcache16 && out && cache_len, VH_EINVAL, "vh_attn_decode_kv16: null pointer");
+    VH_REQUIRE(B > 0 && n_heads > 0 && S_max > 0 && (len_bias == 0 || len_bias == 1), VH_EINVAL,
+               "vh_attn_decode_kv16: bad dims B=%d h=%d S_max=%d len_bias=%d", B, n_heads, S_max, len_bias);
+    VH_REQUIRE(ldq % 4 == 0 && ldq >= n_heads * HD && ldo >= n_heads * HD, VH_EINVAL, "vh_attn_decode_kv16: ldq=%d ldo=%d",
+               ldq, ldo);
+    VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kcache16) && vh_aligned16(vcache16), VH_EALIGN,
+               "vh_attn_decode_kv16: pointers must be 16-byte aligned");
+#define AD16(NW, D)                                                                                                  \
+    hipExtLaunchKernelGGL((attn_decode_ring16_kernel<NW, D>), dim3(1, B * n_heads), dim3(NW * 64), 0, (hipStream_t)stream, \
+                          g_attn_ev[0], g_attn_ev[1], 0, q, ldq, kcache16, vcache16, out, ldo, cache_len, len_bias, n_heads, \
+                          S_max)
+    // ring shape (waves x register sets of 32 keys): 8 x 2 as the fp32 kernel; 16 x 1, 16 x 2, 8 x 3, 8 x 4 and 4 x 4
+    // measured within 3 % of it (461-477 us per decode step, profiles/r3_ab_decode_perf_mode.log)
+    AD16(8, 2);
+#undef AD16
+    VH_CHECK_LAUNCH("vh_attn_decode_kv16");
+    return VH_OK;
 }
 
 extern "C" size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split) {

@@ -58,7 +58,15 @@ struct GemmArgs {
 #define STAMP(k)
 #endif
 
-enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2 };
+enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2,
+       EPI_QKV16 = 3 /* EPI_QKV with the K / V rows appended as bf16 (perf mode of the decode step; skinny kernels only) */ };
+#define IS_QKV(E) ((E) == EPI_QKV || (E) == EPI_QKV16)
+
+// fp32 -> bf16, round to nearest even (finite inputs)
+__device__ __forceinline__ uint32_t vh_bf16_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
 
 // column group of 4 consecutive output columns starting at n (n % 4 == 0) for row m
 template <int EPI>
@@ -770,9 +778,10 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
         a.A += (int64_t)r0 * a.lda;
         if (a.res) a.res += (int64_t)r0 * a.ldr;
         a.out += (int64_t)r0 * a.ldo;
-        if (EPI == EPI_QKV) {                 // T == 1 (host check): row = batch index
-            a.kc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
-            a.vc += (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM;
+        if (IS_QKV(EPI)) {                 // T == 1 (host check): row = batch index
+            const int64_t off = (int64_t)r0 * a.n_heads * a.S_max * VH_HEAD_DIM / (EPI == EPI_QKV16 ? 2 : 1);   // bf16: half
+            a.kc += off;
+            a.vc += off;
             if (a.cache_len) a.cache_len += r0;
         }
         a.M = min(a.M - r0, a.rg_rows);
@@ -851,7 +860,7 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
             e_bias = ld4(ln.c2 + en);
         } else if (EPI == EPI_PLAIN && a.bias) e_bias = ld4(a.bias + en);
         if (EPI == EPI_PLAIN && a.res) e_res = ld4(a.res + (int64_t)em * a.ldr + en);
-        if (EPI == EPI_QKV && a.cache_len) e_pos = a.cache_len[em / a.T];
+        if (IS_QKV(EPI) && a.cache_len) e_pos = a.cache_len[em / a.T];
     }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(1);
@@ -940,12 +949,12 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
             const float dm = sa / (float)a.K;
             const float var = fmaxf(sb / (float)a.K - dm * dm, 0.f);
             sacc = (sacc - (shift + dm) * e_c1) * rsqrtf(var + ln.eps);
-            if (EPI == EPI_QKV) sacc += e_bias;
+            if (IS_QKV(EPI)) sacc += e_bias;
         }
         if (LN == 2 && fin) {                // statistics were published before the barrier above
             const float mu = s_mean[em], rs = s_rstd[em];
             sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
-            if (EPI == EPI_QKV) sacc += e_bias;
+            if (IS_QKV(EPI)) sacc += e_bias;
         }
         if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
@@ -964,7 +973,14 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
                 const int head = c / VH_HEAD_DIM, e = c - head * VH_HEAD_DIM;
                 const int b = em / a.T, t = em - b * a.T;
                 float* base = which == 1 ? a.kc : a.vc;
-                st4(base + (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e, sacc);
+                const int64_t at = (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e;
+                if (EPI == EPI_QKV16) {           // four bf16 = one 8-byte store
+                    const uint64_t lo = vh_bf16_bits(sacc.x) | (vh_bf16_bits(sacc.y) << 16);
+                    const uint64_t hi = vh_bf16_bits(sacc.z) | (vh_bf16_bits(sacc.w) << 16);
+                    *reinterpret_cast<uint64_t*>(reinterpret_cast<uint16_t*>(base) + at) = lo | (hi << 32);
+                } else {
+                    st4(base + at, sacc);
+                }
             }
         }
     }
@@ -1080,7 +1096,7 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         const bool fold = ln.c1 != nullptr;
         // one workgroup per (16 columns, 16 rows) instead of (16 columns, all rows): see the kernel
         const bool rowgroups = vh_tuning(VH_TUNE_ROW_GROUPS) != 2 && mt >= 2 && (!wide || a.K % 2048 == 0) &&
-                               EPI != EPI_PARTIAL && (EPI != EPI_QKV || a.T == 1);
+                               EPI != EPI_PARTIAL && (!IS_QKV(EPI) || a.T == 1);
         GemmArgs ag = a;                  // groups of 16 rows, or of 8 while that keeps the grid within the CUs
         if (rowgroups) {
             ag.rg_rows = (vh_tuning(VH_TUNE_ROW_GROUPS) != 3 && (int)grid.x * ((a.M + 7) / 8) <= 256) ? 8 : 16;
@@ -1133,6 +1149,10 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         }
 #undef SF_MT
 #undef SF
+        if constexpr (EPI == EPI_QKV16) {
+            vh_set_error("%s: bf16 K/V append needs the folded LayerNorm shapes (K in {128,256,512,1024})", name);
+            return VH_EUNSUPPORTED;
+        } else {
         // ---- generic guarded kernel for every other K (multiple of 16)
 #define SK(MT, NW, CH, LN) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI, CH, LN>), grid, dim3(NW * 64), 0, s, a, ln)
@@ -1144,6 +1164,10 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             if (mt == 1) SK(1, 8, 4, false); else if (mt == 2) SK(2, 8, 4, false); else SK(4, 8, 4, false);
         }
 #undef SK
+        }
+    } else if constexpr (EPI == EPI_QKV16) {
+        vh_set_error("%s: bf16 K/V append is the decode path (M <= 64)", name);
+        return VH_EUNSUPPORTED;
     } else {
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
         // The LDS-DMA kernel needs whole 32-wide K slabs; a ragged K goes to the register-staged kernel.
@@ -1289,6 +1313,28 @@ extern "C" int vh_linear_qkv_folded(const float* A, int lda, const float* Wf, co
     if (int rc = check_gemm("vh_linear_qkv_folded", a, ln)) return rc;
     if (int rc = check_folded("vh_linear_qkv_folded", a, ln)) return rc;
     return launch_gemm<EPI_QKV>("vh_linear_qkv_folded", a, ln, (hipStream_t)stream);
+}
+
+// perf mode of the decode step: the same launch with the K / V rows appended to a bf16 cache (B,h,S_max,64)
+extern "C" int vh_linear_qkv_folded_kv16(const float* A, int lda, const float* Wf, const float* c1, const float* c2,
+                                         float* q_out, int ldq, uint16_t* kcache16, uint16_t* vcache16,
+                                         const int32_t* cache_len, int B, int d_model, int n_heads, int S_max,
+                                         float ln_eps, void* stream) {
+    VH_REQUIRE(kcache16 && vcache16, VH_EINVAL, "vh_linear_qkv_folded_kv16: null cache");
+    VH_REQUIRE(B >= 0 && B <= 64 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
+               "vh_linear_qkv_folded_kv16: B=%d d_model=%d n_heads=%d (decode rows, d_model = 64 n_heads)", B, d_model, n_heads);
+    VH_REQUIRE(S_max >= 1 && ldq >= d_model, VH_EINVAL, "vh_linear_qkv_folded_kv16: S_max / ldq");
+    VH_REQUIRE(vh_aligned16(kcache16) && vh_aligned16(vcache16), VH_EALIGN, "vh_linear_qkv_folded_kv16: cache alignment");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = Wf; a.out = q_out; a.ldo = ldq;
+    a.M = B; a.N = 3 * d_model;
+    a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE;
+    a.kc = reinterpret_cast<float*>(kcache16); a.vc = reinterpret_cast<float*>(vcache16); a.cache_len = cache_len;
+    a.T = 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
+    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
+    if (int rc = check_gemm("vh_linear_qkv_folded_kv16", a, ln)) return rc;
+    if (int rc = check_folded("vh_linear_qkv_folded_kv16", a, ln)) return rc;
+    return launch_gemm<EPI_QKV16>("vh_linear_qkv_folded_kv16", a, ln, (hipStream_t)stream);
 }
 
 extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,

@@ -72,6 +72,12 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
             VH_REQUIRE(d->layers[i].w1_f && d->layers[i].w1_c1 && d->layers[i].w1_c2, VH_EINVAL,
                        "vh_ar_decoder: ffn_ws needs the folded linear_1 weights (layer %d)", i);
     }
+    if (d->kv_bf16) {
+        VH_REQUIRE(d->n_split == 1, VH_EUNSUPPORTED, "vh_ar_decoder: the bf16 K/V cache has no key-split form (n_split=%d)",
+                   d->n_split);
+        for (int i = 0; i < d->n_layers; ++i)
+            VH_REQUIRE(d->layers[i].wqkv_f, VH_EINVAL, "vh_ar_decoder: the bf16 K/V cache needs folded weights (layer %d)", i);
+    }
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
     return VH_OK;
@@ -110,10 +116,15 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     // the workspace and the folded weights; else linear_1 and linear_2 (split-K + reduce) as separate launches
     const bool ffn_fused = d.ffn_ws && vh_tuning(VH_TUNE_FFN_FUSED) != 1;
     // decode attention of one layer, optionally bracketed by events (vh_ar_decoder_profile_attn)
+    auto attention = [&](const vh_layer& L) -> int {
+        if (d.kv_bf16)
+            return vh_attn_decode_kv16(d.q, D, (const uint16_t*)L.kcache, (const uint16_t*)L.vcache, d.attn, D, d.cache_len,
+                                       1, B, d.n_heads, d.S_max, s);
+        return vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max, d.n_split,
+                              d.attn_partial, s);
+    };
     auto run_attention = [&](const vh_layer& L) -> int {
-        if (!ev)
-            return vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max, d.n_split,
-                                  d.attn_partial, s);
+        if (!ev) return attention(L);
         hipEvent_t e0, e1;
         if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
             vh_set_error("vh_ar_decoder: hipEventCreate failed");
@@ -126,8 +137,7 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
             kev->push_back(k1);
         }
         (void)hipEventRecord(e0, s);
-        const int arc = vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max,
-                                       d.n_split, d.attn_partial, s);
+        const int arc = attention(L);
         (void)hipEventRecord(e1, s);
         vh_internal_attn_decode_events(nullptr, nullptr);
         ev->push_back(e0);
@@ -137,7 +147,10 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
-        if (L.wqkv_f)
+        if (d.kv_bf16)
+            TRY(vh_linear_qkv_folded_kv16(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, (uint16_t*)L.kcache,
+                                          (uint16_t*)L.vcache, d.cache_len, B, D, d.n_heads, d.S_max, d.ln_eps, s));
+        else if (L.wqkv_f)
             TRY(vh_linear_qkv_folded(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, L.kcache, L.vcache,
                                      d.cache_len, B, 1, D, d.n_heads, d.S_max, d.ln_eps, s));
         else

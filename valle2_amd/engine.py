@@ -28,10 +28,23 @@ class KVCache:
     """(L, 2, B, h, S_max, 64) in one allocation; `length` rows are valid for every batch row
     unless a per-row `cache_len` tensor says otherwise."""
 
-    def __init__(self, n_layers, batch, n_heads, s_max, device):
-        self.buf = torch.empty(n_layers, 2, batch, n_heads, s_max, HEAD_DIM, device=device,
-                               dtype=torch.float32)
+    def __init__(self, n_layers, batch, n_heads, s_max, device, dtype=torch.float32):
+        self.buf = torch.empty(n_layers, 2, batch, n_heads, s_max, HEAD_DIM, device=device, dtype=dtype)
         self.n_layers, self.batch, self.n_heads, self.s_max = n_layers, batch, n_heads, s_max
+
+    @property
+    def bf16(self):
+        return self.buf.dtype == torch.bfloat16
+
+    def narrowed(self, s_max):
+        """A bf16 cache of `s_max` rows per (layer, K|V, row, head) stream holding this fp32 cache's rows (round to
+        nearest even, vh_kv_to_bf16): the decode steps of perf mode read half the bytes."""
+        if self.bf16 or s_max < self.s_max:
+            raise _lib.VhError('KVCache.narrowed: an fp32 cache and s_max >= its length')
+        out = KVCache(self.n_layers, self.batch, self.n_heads, s_max, self.buf.device, dtype=torch.bfloat16)
+        check(_lib.lib().vh_kv_to_bf16(ptr(self.buf), ptr(out.buf), self.n_layers * 2 * self.batch * self.n_heads,
+                                       self.s_max, self.s_max, s_max, stream()), 'vh_kv_to_bf16')
+        return out
 
     def k(self, i):
         return self.buf[i, 0]
@@ -211,6 +224,10 @@ class ArDecoder:
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
         self._folded = folded_layer_norms(model.transformer)   # kept alive: the table holds raw pointers
+        self.kv_bf16 = cache.bf16
+        if self.kv_bf16 and (self._folded is None or self.n_split != 1):
+            raise _lib.VhError('perf mode (bf16 K/V cache) needs the folded LayerNorm weights and rows x heads >= 256 '
+                               f'(one (row, head) per workgroup: n_split = {self.n_split})')
         # FeedForward of a layer as one launch split over dim_feedforward + the slab reduce (vh_ffn_decode)
         ffn_bytes = _lib.lib().vh_ffn_decode_ws_bytes(batch, d, dff) if self._folded is not None else 0
         self.ffn_ws = torch.empty(ffn_bytes // 4, **f32) if ffn_bytes else None
@@ -227,7 +244,8 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
-            sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes)
+            sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes,
+            kv_bf16=int(self.kv_bf16))
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:

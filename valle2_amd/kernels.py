@@ -305,6 +305,32 @@ def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=
     return out
 
 
+def attn_decode_kv16(q, kcache16, vcache16, out, cache_len, len_bias):
+    """attn_decode over a bf16 K/V cache (perf mode); one (row, head) per workgroup."""
+    B, n_heads, S_max, hd = kcache16.shape
+    if hd != HEAD_DIM or kcache16.dtype != torch.bfloat16 or vcache16.dtype != torch.bfloat16 or q.shape[0] != B:
+        raise _lib.VhError('attn_decode_kv16: bf16 caches (B, h, S_max, 64)')
+    if cache_len.dtype != torch.int32 or cache_len.numel() != B:
+        raise _lib.VhError('attn_decode_kv16: cache_len must be int32 (B)')
+    check(_lib.lib().vh_attn_decode_kv16(_dev_f32(q, 'q'), q.stride(0), ptr(kcache16), ptr(vcache16), _dev_f32(out, 'out'),
+                                         out.stride(0), ptr(cache_len), len_bias, B, n_heads, S_max, stream()),
+          'vh_attn_decode_kv16')
+    return out
+
+
+def linear_qkv_folded_kv16(a, folded, q_out, kcache16, vcache16, n_heads, cache_len, eps=1e-5):
+    wf, c1, c2 = folded
+    B, d = a.shape
+    S_max = kcache16.shape[2]
+    if tuple(wf.shape) != (3 * d, d) or tuple(kcache16.shape) != (B, n_heads, S_max, HEAD_DIM) or \
+            kcache16.dtype != torch.bfloat16 or vcache16.dtype != torch.bfloat16:
+        raise _lib.VhError('linear_qkv_folded_kv16: shapes / dtypes')
+    check(_lib.lib().vh_linear_qkv_folded_kv16(_dev_f32(a, 'a'), a.stride(0), ptr(wf), ptr(c1), ptr(c2), q_out.data_ptr(),
+                                               q_out.stride(0), ptr(kcache16), ptr(vcache16), ptr(cache_len), B, d,
+                                               n_heads, S_max, eps, stream()), 'vh_linear_qkv_folded_kv16')
+    return q_out
+
+
 def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next,
                 pos_base=None):
     B = logits.shape[0]

@@ -160,7 +160,8 @@ class ValleAR(_Base):
 
     @_on_device
     @torch.inference_mode()
-    def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False):
+    def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False, perf_mode=False,
+                       forced=None, keep_logits=()):
         """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
         texts[b]: 1-D int64 text ids; first_codes[b]: 1-D int64 first-codebook prompt (no BOS).
         Rows may differ in text and prompt length.  Returns codes (B, max_prompt_len + n_new) int64
@@ -168,7 +169,13 @@ class ValleAR(_Base):
         rows and the tail of shorter rows are EOS-filled; `last_generate_stats['prompt_lens'][b]` is
         where row b's generated tokens start).
         profile_attn=True runs the steps eagerly with HIP events around every decode-attention
-        launch and leaves their mean duration in `last_generate_stats` (measurement only)."""
+        launch and leaves their mean duration in `last_generate_stats` (measurement only).
+        perf_mode=True (opt-in): the decode steps run over a bf16 K/V cache — the prompt pass is
+        the fp32 one, its K/V are narrowed once — everything else fp32; greedy tokens are then NOT guaranteed to be
+        the reference's (teacher-forced logits agree to 5e-2).
+        forced (max_new,) int64 + keep_logits (step indices): TEACHER FORCING for the tolerance tests — step t appends
+        forced[t] whatever the head says (steps run eagerly, one at a time) and the logits (B, V) the head produced at
+        the steps listed in keep_logits are left in `last_generate_stats['logits']`."""
         self._require_layernorm()
         cfg = self.config
         if not cfg.use_kv_cache:
@@ -185,7 +192,7 @@ class ValleAR(_Base):
             parts, stats = [], []
             for s0 in range(0, B, MAX_DECODE_ROWS):
                 parts.append(self.generate_batch(texts[s0:s0 + MAX_DECODE_ROWS], first_codes[s0:s0 + MAX_DECODE_ROWS],
-                                                 max_new=max_new, use_graph=use_graph))
+                                                 max_new=max_new, use_graph=use_graph, perf_mode=perf_mode))
                 stats.append(self.last_generate_stats)
             width = max(p.shape[1] for p in parts)
             out = torch.full((B, width), self.eos_token, device=dev, dtype=torch.int64)
@@ -214,7 +221,8 @@ class ValleAR(_Base):
 
         # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None).  Row b is laid
         # out [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.
-        cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev)
+        # (perf mode: the prompt pass needs its fp32 cache only as long as the prompt; the bf16 cache holds the run)
+        cache = KVCache(cfg.num_layers, B, cfg.n_heads, s0 if perf_mode else s_max, dev)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # prefill | decode phase times
         marks[0].record()
         texts = [kernels.ids_to_device(t, dev, cfg.vocab_size, 'text ids') for t in texts]
@@ -242,14 +250,31 @@ class ValleAR(_Base):
         pos_base = audio_pos.clone()
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
+        if perf_mode:
+            cache = cache.narrowed(s_max)                 # fp32 prompt K/V -> the bf16 cache of the decode steps
         dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph,
                         seed=seed)
         try:
             dec.sample_from(last.contiguous())
             marks[1].record()
             del x, last
+            kept = {}
+            if forced is not None:
+                # teacher forcing: after every step replace the sampled token and its embedding by the given one
+                forced = forced.to(dev)
+                if ragged or forced.numel() < max_new:
+                    raise ValueError('forced: one token per step, equal-length rows')
+                pe = self.audio_position_emb.pe
+                for t in range(max_new):
+                    if t:
+                        dec.run(1)
+                    if t in keep_logits:
+                        kept[t] = dec.logits[:, : dec.V].clone()
+                    codes[:, pl_max + t] = forced[t]
+                    kernels.embed_sum_pe(codes[:, pl_max + t:pl_max + t + 1], [self.audio_emb.weight.detach()], pe,
+                                         pl_max + t, dec.x.view(B, 1, d))
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
-            done, stop = 1, None
+            done, stop = (max_new if forced is not None else 1), None
             attn_ms = attn_floor_ms = attn_kernel_ms = None
             if profile_attn and max_new > 1:
                 attn_ms, attn_floor_ms, attn_kernel_ms = dec.profile_attn(max_new - 1)
@@ -270,7 +295,7 @@ class ValleAR(_Base):
             marks[2].synchronize()
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'ffn_fused': dec.ffn_ws is not None,
+                                        'ffn_fused': dec.ffn_ws is not None, 'kv_bf16': dec.kv_bf16, 'logits': kept,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
