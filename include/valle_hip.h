@@ -66,8 +66,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,he
                                        1 = always through registers, 2 = LDS-DMA whenever eligible */
        VH_TUNE_REDUCE_BLOCK = 3,    /* threads per workgroup of the split-K reduce: 64, 128 (default), 256 */
        VH_TUNE_FFN_FUSED = 5,       /* decode step FeedForward: 0 (default) = vh_ffn_decode (one launch split over dim_feedforward
-                                       + the slab reduce) when the weights are folded, 1 = linear_1 and linear_2 as separate
-                                       launches (vh_linear_folded + vh_linear_ws) */
+                                       + the slab reduce) when the weights are folded and d_model <= 512 (measured slower at
+                                       1024), 1 = always linear_1 and linear_2 as separate launches (vh_linear_folded +
+                                       vh_linear_ws), 2 = vh_ffn_decode wherever it is supported */
        VH_TUNE_GRAPH_STEPS = 6,     /* decode graph: 0 (default) = replay in graphs of 8 consecutive steps (+ single-step graphs
                                        for the remainder); 1 = one graph launch per step */
        VH_TUNE_FFN_SLICE = 7,       /* vh_ffn_decode: hidden columns per workgroup, 0 (default) = chosen from the shape, else 16 / 32 */

@@ -114,7 +114,10 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     const int B = d.B, D = d.d_model;
     // FeedForward as one launch split over dim_feedforward + the slab reduce (vh_ffn_decode) when the caller gave
     // the workspace and the folded weights; else linear_1 and linear_2 (split-K + reduce) as separate launches
-    const bool ffn_fused = d.ffn_ws && vh_tuning(VH_TUNE_FFN_FUSED) != 1;
+    // measured: +1.6 us per step at 12L/512d x 32 rows, but 1.2 us per LAYER slower at 24L/1024d x 8 rows (256 slices of
+    // 16 columns, 8 MB of slabs: profiles/r3_ab_config5_ffn.log) — the default follows the measurements
+    const int ffn_knob = vh_tuning(VH_TUNE_FFN_FUSED);
+    const bool ffn_fused = d.ffn_ws && ffn_knob != 1 && (d.d_model <= 512 || ffn_knob == 2);
     // decode attention of one layer, optionally bracketed by events (vh_ar_decoder_profile_attn)
     auto attention = [&](const vh_layer& L) -> int {
         if (d.kv_bf16)

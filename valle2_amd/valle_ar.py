@@ -295,7 +295,7 @@ class ValleAR(_Base):
             marks[2].synchronize()
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'ffn_fused': dec.ffn_ws is not None, 'kv_bf16': dec.kv_bf16, 'logits': kept,
+                                        'ffn_fused': dec.ffn_ws is not None and d <= 512, 'kv_bf16': dec.kv_bf16, 'logits': kept,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
