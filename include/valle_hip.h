@@ -402,10 +402,14 @@ int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *                     forward of FeedForward.linear_1 keeps it for the GELU backward (modules.py:221);
  *   act == VH_ACT_GELU_BWD : out = acc * gelu'(residual[m][n]) — the backward through nn.GELU fused into
  *                     the dX = dY . W product of linear_2 (residual = the saved pre-activation).
+ *   dcolsum != NULL (N % 128 == 0): the column sums of `out` are ADDED to dcolsum (N floats, fp32 atomics, one per
+ *                     column and tile) — the gradient of linear_1's bias falls out of the product that makes its
+ *                     pre-activation's gradient, without a column-sum launch.
  * The backward's dX = dY . W products run on this NT form with W handed over transposed (vh_transpose),
  * so K here is the forward's N: pad it to a multiple of 32 with zero columns for the fast kernel. */
 int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
-                 float* out, int ldo, float* pre_out, int ldp, int M, int N, int K, int act, void* stream);
+                 float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K, int act,
+                 void* stream);
 
 /* out (cols, ldo) = in (rows, cols)^T; out rows are zero-filled from `rows` up to ldo. */
 int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream);

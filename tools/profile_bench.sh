@@ -1,18 +1,25 @@
 #!/bin/bash
-# Round-end evidence run (on the GPU box through gpurun): the default bench line, the same command under
-# rocprofv3 --kernel-trace --stats, and the two PMC passes for the dominant kernel's HBM traffic
-# (separate passes, no tracing domains beside --kernel-trace).
+# Round-end evidence run (on the GPU box through gpurun): the default bench line as the driver runs it, the same command
+# under rocprofv3 --kernel-trace --stats, the two PMC passes for the dominant kernel's HBM traffic (separate passes, no
+# tracing domain beside --kernel-trace; bench.py also measures the traffic itself through child processes), and the
+# training step's kernel statistics and launch trace.  Summaries land in gpurun_out/prof_bench/ — copy them to profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_bench
 mkdir -p $OUT
 cd $R
-timeout -k 10 500 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
-python3 $R/tools/summarize_prof.py $OUT/stats $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o pmc --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-nar --no-roofline > $OUT/fetch.json 2> $OUT/fetch.err
-python3 $R/tools/summarize_prof.py $OUT/fetch $OUT/pmc_fetch_size.md "rocprofv3 --pmc FETCH_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-nar --no-roofline"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o pmc --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-nar --no-roofline > $OUT/write.json 2> $OUT/write.err
-python3 $R/tools/summarize_prof.py $OUT/write $OUT/pmc_write_size.md "rocprofv3 --pmc WRITE_SIZE -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-nar --no-roofline"
-rm -rf $OUT/stats $OUT/fetch $OUT/write
+P="--no-cpu-baseline --no-traffic --no-config5 --no-beams --no-perf-mode"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $R/bench.py $P > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
+python3 $R/tools/summarize_prof.py $OUT/stats $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py $P"
+Q="--steps 1 --warmup 0 --no-nar --no-roofline --no-train $P"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o pmc --output-format csv -- python3 $R/bench.py $Q > $OUT/fetch.json 2> $OUT/fetch.err
+python3 $R/tools/summarize_prof.py $OUT/fetch $OUT/pmc_fetch_size.md "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py $Q"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o pmc --output-format csv -- python3 $R/bench.py $Q > $OUT/write.json 2> $OUT/write.err
+python3 $R/tools/summarize_prof.py $OUT/write $OUT/pmc_write_size.md "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py $Q"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/train -o t --output-format csv -- python3 $R/tools/bench_train.py steps=4 > $OUT/train.log 2> $OUT/train.err
+python3 $R/tools/summarize_prof.py $OUT/train $OUT/train_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 tools/bench_train.py steps=4 (7 AR + 7 NAR steps of configs[3])"
+timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/tt -o t --output-format csv -- python3 $R/tools/train_trace.py run > $OUT/tt.log 2> $OUT/tt.err
+python3 $R/tools/train_trace.py report $OUT/tt > $OUT/train_trace.md
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/train $OUT/tt

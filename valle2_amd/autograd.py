@@ -372,11 +372,14 @@ class EncoderLayerFn(torch.autograd.Function):
         db2 = _BIAS_GRAD_AHEAD.pop(id(b2), None)                           # the layer above summed dY's columns already
         if db2 is None:
             db2 = _colsum(dy, b2)
-        dpre = torch.empty_like(pre)                                       # (dY . W2) * gelu'(pre)
-        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=kernels.ACT_GELU_BWD, K=w2_t.shape[1])
+        dpre = torch.empty_like(pre)                                       # (dY . W2) * gelu'(pre), + its column sums = db1
+        fold = pre.shape[1] % 128 == 0                                     # (whole 128-column tiles)
+        db1 = optim.grad_out(b1, zero=True) if fold else None
+        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=kernels.ACT_GELU_BWD, K=w2_t.shape[1], colsum=db1)
+        if not fold:
+            db1 = _colsum(dpre, b1)
         dw1 = optim.grad_out(w1)
         kernels.gemm_tn(dpre, xn2, out=dw1)
-        db1 = _colsum(dpre, b1)
         dxn2 = torch.empty_like(x)
         kernels.linear_ex(dpre, w1_t, out=dxn2, K=w1_t.shape[1])
         # ---- norm2 (+ the residual branch's dY, + the out-projection's bias gradient = column sums of the result)

@@ -41,6 +41,7 @@ struct GemmArgs {
     int T, S_max, d_model, n_heads;
     float* aux;   // training forward (EPI_PLAIN, tile kernels): pre-activation acc + bias stored here too
     int ldx;
+    float* colsum;  // training backward (EPI_PLAIN, tile kernels): += column sums of the stored output (a bias gradient)
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
 #ifdef VH_STAMPS
@@ -190,6 +191,21 @@ __device__ __forceinline__ void tile_prefetch(const GemmArgs& a, int m0, int n0,
     }
 }
 
+// Column sums of the tile's stored output, added to a.colsum[n0 ..]: thread (erow = tid >> 5, ec4 = tid & 31) holds the
+// sum over its 16 rows of 4 columns; the 8 row groups meet in LDS (ct is free once every thread has read its rows),
+// then one atomic per column and workgroup.
+__device__ __forceinline__ void tile_colsum(const GemmArgs& a, float* ct, f32x4 csum, int n0, int tid) {
+    __syncthreads();                                   // every thread is done reading ct
+    st4(ct + (tid >> 5) * TN + 4 * (tid & 31), csum);
+    __syncthreads();
+    if (tid < TN) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += ct[r * TN + tid];
+        if (n0 + tid < a.N) atomicAdd(a.colsum + n0 + tid, t);
+    }
+}
+
 // ct: 128 x 132 floats of LDS, free (the main loop ended on a barrier).  D reg e of tile (mt,nt) holds row
 // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
 template <int EPI>
@@ -219,6 +235,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         const uint32_t voff = (uint32_t)(erow * a.ldo + 4 * ec4) * 4u;
         char* xbase = (EPI == EPI_PLAIN && a.aux) ? (char*)(a.aux + (int64_t)m0 * a.ldx + n0) : nullptr;
         const uint32_t xoff = (uint32_t)(erow * a.ldx + 4 * ec4) * 4u;
+        f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             f32x4 v = ld4(cr + it * 8 * LDC);
@@ -237,7 +254,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
                 }
             }
             st4((float*)(base + (int64_t)it * 8 * a.ldo * 4 + voff), v);
+            if (EPI == EPI_PLAIN) csum += v;
         }
+        if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, ct, csum, n0, tid);
         return;
     }
     if (interior && qkv_tile) {                        // a K or V tile: scatter rows into cache[b][head][pos][64]
@@ -260,7 +279,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         return;
     }
     // ---- edge tiles (ragged M or N) and QKV with d_model not a multiple of 128: guarded general form
-    if (en >= a.N) return;
+    if (en >= a.N) return;                             // (never with a.colsum: the host requires N % 128 == 0 then)
     const bool ecol_full = en + 3 < a.N;
     float* qdst = nullptr;
     bool qcache = false;
@@ -274,6 +293,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             qcache = true;
         }
     }
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int row = erow + 8 * it, m = m0 + row;
@@ -301,10 +321,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             if (a.act == VH_ACT_GELU_BWD) {
                 const f32x4 p = e.resv[it];
                 v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
-                st4(a.out + (int64_t)m * a.ldo + en, v);
             } else {
-                st4(a.out + (int64_t)m * a.ldo + en, v + e.resv[it]);
+                v += e.resv[it];
             }
+            st4(a.out + (int64_t)m * a.ldo + en, v);
+            csum += v;
         } else {                                       // ragged last column group (e.g. N = 1025 logits)
             for (int j = 0; j < 4 && en + j < a.N; ++j) {
                 float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
@@ -316,6 +337,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             }
         }
     }
+    // (the column-sum epilogue serves whole column groups only: the host refuses it for N % 4 != 0; every thread of a
+    // tile that reaches this point — en < N is uniform per column group, not per wave — must take part in the barrier,
+    // so edge tiles whose column groups end inside the tile are refused by the host as well: N % 128 == 0)
+    if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, ct, csum, n0, tid);
 }
 
 template <int EPI>
@@ -1087,7 +1112,7 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
 template <int EPI>
 static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s) {
     if (a.M == 0) return VH_OK;
-    const bool train_epi = a.aux != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
+    const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
@@ -1196,11 +1221,13 @@ extern "C" int vh_linear(const float* A, int lda, const float* W, const float* b
 }
 
 extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual,
-                            int ldr, float* out, int ldo, float* pre_out, int ldp, int M, int N, int K, int act,
-                            void* stream) {
+                            int ldr, float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K,
+                            int act, void* stream) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
     a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K; a.aux = pre_out; a.ldx = ldp;
+    a.colsum = dcolsum;
+    VH_REQUIRE(!dcolsum || N % 128 == 0, VH_EUNSUPPORTED, "vh_linear_ex: dcolsum needs N %% 128 == 0 (N=%d)", N);
     LnFuse ln{};
     VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF || act == VH_ACT_GELU_BWD, VH_EINVAL,
                "vh_linear_ex: act=%d", act);

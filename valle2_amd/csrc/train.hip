@@ -19,14 +19,15 @@ __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.
 // Waves stride over rows and keep their column partial sums in registers; one atomicAdd per
 // column per WORKGROUP at the end.
 // ---------------------------------------------------------------------------------------------
+#define LNB_WAVES 8
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ s, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ds,
     float* __restrict__ dt, const float* __restrict__ dres, float* __restrict__ dcol, int rows, int d, float eps) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int wid = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * LNB_WAVES;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 gm[NV], bt[NV], sc[NV], ag[NV], ab[NV], as[NV], at[NV];
 #pragma unroll
@@ -41,18 +42,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     f32x4 ac[NV];                                   // column sums of the rows written to dx (dcol)
 #pragma unroll
     for (int i = 0; i < NV; ++i) ac[i] = z;
-    for (int row = wid; row < rows; row += nw) {
-        const float* xr = x + (int64_t)row * d;
-        const float* dyr = dy + (int64_t)row * d;
-        f32x4 v[NV], g[NV];
-        float sum = 0.f;
+    // A wave walks its rows one after the other, and a row is a chain of four wave reductions: the next row's three
+    // operand rows (x, dy, the residual branch's gradient) are requested BEFORE this row is reduced, so the memory
+    // round trip hides behind the chain instead of being paid per row (45.7 -> see profiles/r3_train_kernel_stats.md).
+    f32x4 vn[NV], gn[NV], rn[NV];
+    auto load_row = [&](int row) {
+        const int64_t o = (int64_t)row * d;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
-            v[i] = c < d ? ld4(xr + c) : z;
-            g[i] = c < d ? ld4(dyr + c) : z;
+            vn[i] = c < d ? ld4(x + o + c) : z;
+            gn[i] = c < d ? ld4(dy + o + c) : z;
+            rn[i] = (dres && c < d) ? ld4(dres + o + c) : z;
+        }
+    };
+    if (wid < rows) load_row(wid);
+    for (int row = wid; row < rows; row += nw) {
+        f32x4 v[NV], g[NV], r[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = vn[i]; g[i] = gn[i]; r[i] = rn[i];
             sum += hsum4(v[i]);
         }
+        if (row + nw < rows) load_row(row + nw);
         const float mu = wave_sum(sum) / (float)d;
         float ss = 0.f;
 #pragma unroll
@@ -86,26 +99,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
         for (int i = 0; i < NV; ++i) {
             const int c = (lane + 64 * i) * 4;
             if (c < d) {
-                f32x4 o = (g[i] - m1 - v[i] * m2) * rstd;
                 // the pre-norm block's residual branch: the gradient that bypasses the norm is added here instead of
                 // by a separate elementwise launch (x feeds the norm AND the residual add, modules.py:271-279)
-                if (dres) o += ld4(dres + (int64_t)row * d + c);
+                const f32x4 o = (g[i] - m1 - v[i] * m2) * rstd + r[i];
                 st4(dx + (int64_t)row * d + c, o);
                 if (dcol) ac[i] += o;
             }
         }
     }
-    // Column sums: the four waves of the workgroup meet in LDS first, so each column receives ONE atomic
+    // Column sums: the waves of the workgroup meet in LDS first, so each column receives ONE atomic
     // per workgroup and quantity.  (Per-wave atomics — 2M adds onto the same 1024 addresses at 16k rows —
     // ran at the contended-atomic rate of the chip and took 250 us per launch, 8x the row work.)
-    __shared__ __attribute__((aligned(16))) float colbuf[4][NV * 256];
+    __shared__ __attribute__((aligned(16))) float colbuf[LNB_WAVES][NV * 256];
     const int w = threadIdx.x >> 6;
     auto reduce_to = [&](f32x4 (&part)[NV], float* __restrict__ dst) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) st4(&colbuf[w][(lane + 64 * i) * 4], part[i]);
         __syncthreads();
-        for (int c = threadIdx.x; c < d; c += 256)
-            atomicAdd(dst + c, (colbuf[0][c] + colbuf[1][c]) + (colbuf[2][c] + colbuf[3][c]));
+        for (int c = threadIdx.x; c < d; c += LNB_WAVES * 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < LNB_WAVES; ++k) t += colbuf[k][c];
+            atomicAdd(dst + c, t);
+        }
         __syncthreads();
     };
     reduce_to(ag, dgamma);
@@ -130,10 +146,10 @@ extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float*
                    vh_aligned16(beta) && vh_aligned16(ada_scale) && vh_aligned16(dres),
                VH_EALIGN, "vh_layernorm_bwd: pointers must be 16-byte aligned");
     if (rows == 0) return VH_OK;
-    const int blocks = rows < 4 * 256 ? (rows + 3) / 4 : 256;
+    const int blocks = rows < LNB_WAVES * 256 ? (rows + LNB_WAVES - 1) / LNB_WAVES : 256;
     hipStream_t st = (hipStream_t)stream;
 #define LNB(NV)                                                                                    \
-    hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(256), 0, st, x, gamma, beta,   \
+    hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(LNB_WAVES * 64), 0, st, x, gamma, beta,   \
                        ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, dres, dcolsum, rows, d, eps)
     if (d <= 256) LNB(1);
     else if (d <= 512) LNB(2);

@@ -356,10 +356,11 @@ def pad32(n):
     return (n + 31) // 32 * 32
 
 
-def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None):
+def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None, colsum=None):
     """vh_linear_ex: out = act(a @ w.T + bias) + residual on the tile kernels whatever M is, with the training
     epilogues (pre_out: also store the pre-activation; ACT_GELU_BWD: out = (a @ w.T) * gelu'(residual)).
-    `K` overrides the contraction width (operands whose rows are zero-padded to a multiple of 32)."""
+    `K` overrides the contraction width (operands whose rows are zero-padded to a multiple of 32).
+    colsum (N,) fp32, N % 128 == 0: += the column sums of `out` (a bias gradient) in the same launch."""
     M = a.shape[0]
     N = w.shape[0]
     K = K or a.shape[1]
@@ -377,7 +378,7 @@ def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NO
         _dev_f32(residual, 'residual') if residual is not None else None,
         residual.stride(0) if residual is not None else 0, _dev_f32(out, 'out'), out.stride(0),
         _dev_f32(pre_out, 'pre_out') if pre_out is not None else None,
-        pre_out.stride(0) if pre_out is not None else 0, M, N, K, act, stream()), 'vh_linear_ex')
+        pre_out.stride(0) if pre_out is not None else 0, ptr(colsum), M, N, K, act, stream()), 'vh_linear_ex')
     return out
 
 
