@@ -360,6 +360,18 @@ int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, c
 /* bias gradient: out[c] += sum_r x[r, c] */
 int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
 
+/* ---- AdaptiveLayerNorm projections of a whole stack (training) ------------------------------------
+ * out[i, :] = emb W_i^T + b_i for the n project_layer Linears of a stack (valle/models/modules.py:94-96; n = 2 per
+ * EncoderLayer), one (1, K) stage embedding for all, in ONE launch; and their backward in one launch:
+ *   dw_i (N, K) = dout_i^T emb (an outer product: the Linear saw one input row), db_i = dout_i   — both WRITTEN,
+ *   demb (K) += sum_i dout_i W_i   (fp32 atomics; the caller zeroes it; NULL: not wanted).
+ * items: DEVICE array of n descriptors; dw / db / b may be NULL.  N = 2 K for the reference's modules; K % 4 == 0,
+ * K <= 2048. */
+typedef struct { const float* w; const float* b; float* dw; float* db; } vh_adaproj_item;
+int vh_adaproj_fwd(const vh_adaproj_item* items, int n, const float* emb, float* out, int N, int K, void* stream);
+int vh_adaproj_bwd(const vh_adaproj_item* items, int n, const float* emb, const float* dout, float* demb, int N, int K,
+                   void* stream);
+
 /* ---- NAR stage sampler -------------------------------------------------------------------------
  * replaces `Categorical(logits=logits / temperature).sample()` of ValleNAR.generate
  * (valle/models/valle_nar.py:160) for `rows` rows of (rows, V) logits (row stride ld):

@@ -139,6 +139,8 @@ SIGNATURES = {
                                c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_transpose': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     'vh_transpose_many': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'vh_adaproj_fwd': (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    'vh_adaproj_bwd': (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_gemm_tn_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'vh_gemm_tn': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                              C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -299,20 +299,60 @@ class CrossEntropyFn(torch.autograd.Function):
         return dl * g, None
 
 
-def _ln_bwd(x, gamma, beta, s, dy, dres, dcol, eps):
+def _ln_bwd(x, gamma, beta, s, dy, dres, dcol, eps, dst=None):
     """LayerNorm / AdaLN backward with the residual-branch gradient added in the same pass and (optionally) the column
-    sums of the result accumulated into `dcol`.  Returns (dx, dgamma, dbeta, dscale, dshift)."""
+    sums of the result accumulated into `dcol`.  `dst` (2, d), zero on entry: where the AdaLN scale / shift gradients
+    are accumulated.  Returns (dx, dgamma, dbeta)."""
     d = x.shape[-1]
     dx = torch.empty_like(x)
     dg, db = optim.grad_out(gamma, zero=True), optim.grad_out(beta, zero=True)
     ds = dt = None
     if s is not None:
-        st = torch.zeros(2, d, device=x.device, dtype=torch.float32)
-        ds, dt = st[0], st[1]
+        ds, dt = dst[0], dst[1]
     check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy), ptr(dx),
                                       ptr(dg), ptr(db), ptr(ds), ptr(dt), ptr(dres), ptr(dcol), x.numel() // d, d,
                                       eps, stream()), 'vh_layernorm_bwd')
-    return dx, dg, db, ds, dt
+    return dx, dg, db
+
+
+class AdaProjFn(torch.autograd.Function):
+    """(n, 2d) = [emb @ W_i.T + b_i for the n AdaptiveLayerNorm project_layer Linears of a stack] in one launch, and
+    their whole backward in one launch (outer-product weight gradients, vh_adaproj_fwd / _bwd)."""
+
+    @staticmethod
+    def _items(ws, bs, dws, dbs, dev):
+        import numpy as np
+        rec = np.zeros(len(ws), dtype=[('w', 'u8'), ('b', 'u8'), ('dw', 'u8'), ('db', 'u8')])
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            rec[i] = (w.data_ptr(), b.data_ptr(), dws[i].data_ptr() if dws else 0, dbs[i].data_ptr() if dbs else 0)
+        return _lib.to_device_async(torch.from_numpy(rec.view(np.uint8).copy()), dev)
+
+    @staticmethod
+    def forward(ctx, emb, *params):
+        ws, bs = params[0::2], params[1::2]
+        n, (N, K) = len(ws), ws[0].shape
+        if any(tuple(w.shape) != (N, K) or not w.is_contiguous() for w in ws) or any(b.numel() != N for b in bs):
+            raise _lib.VhError('AdaProjFn: equal-shaped contiguous project_layer weights')
+        emb = emb.detach().reshape(-1).contiguous()
+        out = torch.empty(n, N, device=emb.device, dtype=torch.float32)
+        items = AdaProjFn._items([w.detach() for w in ws], [b.detach() for b in bs], None, None, emb.device)
+        check(_lib.lib().vh_adaproj_fwd(ptr(items), n, ptr(emb), ptr(out), N, K, stream()), 'vh_adaproj_fwd')
+        ctx.save_for_backward(emb, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        emb, *params = ctx.saved_tensors
+        ws, bs = params[0::2], params[1::2]
+        n, (N, K) = len(ws), ws[0].shape
+        dout = dout.contiguous()
+        dws = [optim.grad_out(w) for w in ws]
+        dbs = [optim.grad_out(b) for b in bs]
+        items = AdaProjFn._items([w.detach() for w in ws], [b.detach() for b in bs], dws, dbs, emb.device)
+        demb = torch.zeros(K, device=emb.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        check(_lib.lib().vh_adaproj_bwd(ptr(items), n, ptr(emb), ptr(dout), ptr(demb), N, K, stream()), 'vh_adaproj_bwd')
+        grads = [g for pair in zip(dws, dbs) for g in pair]
+        return (None if demb is None else demb.view(1, K), *grads)
 
 
 # bias gradients produced ahead of their layer's backward: layer l+1's LayerNorm backward writes dx — the gradient of
@@ -331,8 +371,12 @@ class EncoderLayerFn(torch.autograd.Function):
     dX products reading weights transposed once per optimizer step for the whole stack (kernels.TransposePlan)."""
 
     @staticmethod
-    def forward(ctx, x, meta, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2, s1, t1, s2, t2):
-        B, T, n_heads, spec, eps, wts, below_b2 = meta
+    def forward(ctx, x, meta, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2, ada_all):
+        # AdaLN: meta carries this layer's (scale, shift) pairs as views of the stack's projections (ada_all, made by
+        # AdaProjFn) and the slices of the ONE gradient buffer every layer accumulates into; only the first layer
+        # receives ada_all as a differentiable input and hands that buffer back as its gradient (it runs last)
+        B, T, n_heads, spec, eps, wts, below_b2, ada, ada_grad = meta
+        s1, t1, s2, t2 = ada if ada is not None else (None, None, None, None)
         x = x.contiguous()
         dev, d = x.device, x.shape[1]
         det = lambda p: None if p is None else p.detach().contiguous()   # noqa: E731
@@ -352,16 +396,17 @@ class EncoderLayerFn(torch.autograd.Function):
         kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU)
         y = torch.empty_like(x)
         kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=xm, out=y)
-        ctx.save_for_backward(x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2,
-                              b2, s1, s2)
+        ctx.save_for_backward(x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2)
         ctx.meta = meta
+        ctx.returns_ada = ada_all is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2, s1,
-         s2) = ctx.saved_tensors
-        B, T, h, spec, eps, wts, below_b2 = ctx.meta
+        x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2 = ctx.saved_tensors
+        B, T, h, spec, eps, wts, below_b2, ada, ada_grad = ctx.meta
+        s1, _, s2, _ = ada if ada is not None else (None, None, None, None)
+        dst1, dst2, ada_grads = ada_grad if ada_grad is not None else (None, None, None)
         d = x.shape[1]
         dy = dy.contiguous()
         wqkv_t, wo_t, w1_t, w2_t = wts
@@ -384,7 +429,7 @@ class EncoderLayerFn(torch.autograd.Function):
         kernels.linear_ex(dpre, w1_t, out=dxn2, K=w1_t.shape[1])
         # ---- norm2 (+ the residual branch's dY, + the out-projection's bias gradient = column sums of the result)
         dbo = optim.grad_out(bo, zero=True)
-        dxm, dg2, dbe2, ds2, dt2 = _ln_bwd(xm, g2, be2, det(s2), dxn2, dy, dbo, eps)
+        dxm, dg2, dbe2 = _ln_bwd(xm, g2, be2, det(s2), dxn2, dy, dbo, eps, dst2)
         # ---- out-projection
         dwo = optim.grad_out(wo)
         kernels.gemm_tn(dxm, a, out=dwo)
@@ -395,18 +440,15 @@ class EncoderLayerFn(torch.autograd.Function):
         kernels.attn_rows_bwd(q, k, v, a, da, lse2, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, T, **spec)
         dwqkv = optim.grad_out(wqkv)
         kernels.gemm_tn(dqkv, xn1, out=dwqkv)
-        dx = None
-        dg1 = dbe1 = ds1 = dt1 = None
         dxn1 = torch.empty_like(x)
         kernels.linear_ex(dqkv, wqkv_t, out=dxn1, K=wqkv_t.shape[1])
         # ---- norm1 (+ the residual branch's gradient; + the bias gradient of the layer below's linear_2)
         ahead = optim.grad_out(below_b2, zero=True) if below_b2 is not None else None
-        dx, dg1, dbe1, ds1, dt1 = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps)
+        dx, dg1, dbe1 = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps, dst1)
         if ahead is not None:
             _BIAS_GRAD_AHEAD[id(below_b2)] = ahead
-        if s1 is not None:
-            ds1, dt1, ds2, dt2 = ds1.view_as(s1), dt1.view_as(s1), ds2.view_as(s2), dt2.view_as(s2)
-        return (dx, None, dwqkv, dwo, dbo, dg1, dbe1, dg2, dbe2, dw1, db1, dw2, db2, ds1, dt1, ds2, dt2)
+        dada = ada_grads if ctx.returns_ada else None            # the whole stack's buffer, complete once layer 0 is done
+        return (dx, None, dwqkv, dwo, dbo, dg1, dbe1, dg2, dbe2, dw1, db1, dw2, db2, dada)
 
 
 def linear(x, w, b=None, residual=None):
@@ -482,18 +524,27 @@ def transformer_train(transformer, x, B, T, spec, embedding=None):
         return x
     _BIAS_GRAD_AHEAD.clear()
     wts = _stack_transposes(transformer)
+    ada_all = ada_vals = ada_grads = None
+    d = cfg.d_model
+    if cfg.norm != 'LayerNorm':
+        # every AdaLN (scale, shift) of the stack from ONE launch; their gradients meet in one zeroed buffer that the
+        # first layer's node hands back to autograd
+        projs = [p for l in layers for n in (l.norm1, l.norm2) for p in (n.project_layer.weight, n.project_layer.bias)]
+        ada_all = AdaProjFn.apply(embedding, *projs)                          # (2 L, 2 d)
+        ada_vals = ada_all.detach()
+        ada_grads = torch.zeros_like(ada_vals)
     for i, layer in enumerate(layers):
         at, ff = layer.self_attn, layer.ffn
         below_b2 = layers[i - 1].ffn.linear_2.bias if i > 0 else None
-        if cfg.norm == 'LayerNorm':
-            n1, n2, ada = layer.norm1, layer.norm2, (None, None, None, None)
+        if ada_all is None:
+            n1, n2, ada, ada_grad = layer.norm1, layer.norm2, None, None
         else:
             n1, n2 = layer.norm1.norm, layer.norm2.norm
-            wb1 = linear(embedding.reshape(1, -1), layer.norm1.project_layer.weight, layer.norm1.project_layer.bias).view(2, -1)
-            wb2 = linear(embedding.reshape(1, -1), layer.norm2.project_layer.weight, layer.norm2.project_layer.bias).view(2, -1)
-            ada = (wb1[0], wb1[1], wb2[0], wb2[1])
-        meta = (B, T, at.n_heads, spec, layer.norm1.eps, wts[i], below_b2)
+            av, gv = ada_vals[2 * i:2 * i + 2].view(2, 2, d), ada_grads[2 * i:2 * i + 2].view(2, 2, d)
+            ada = (av[0, 0], av[0, 1], av[1, 0], av[1, 1])              # (scale, shift) of norm1, of norm2
+            ada_grad = (gv[0], gv[1], ada_grads)
+        meta = (B, T, at.n_heads, spec, layer.norm1.eps, wts[i], below_b2, ada, ada_grad)
         x = EncoderLayerFn.apply(x, meta, at.qkv.weight, at.out.weight, at.out.bias, n1.weight, n1.bias, n2.weight,
                                  n2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias,
-                                 *ada)
+                                 ada_all if i == 0 else None)
     return x

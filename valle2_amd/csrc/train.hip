@@ -497,3 +497,109 @@ extern "C" int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* e
     VH_CHECK_LAUNCH("vh_adamw_flat");
     return VH_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// AdaptiveLayerNorm projections of a whole stack in one launch each way: out[i] = emb W_i^T + b_i for the n = 2 L
+// project_layer Linears (valle/models/modules.py:94-96), one (1, d) stage embedding for all of them.  As separate
+// Linears their backward was ~10 tiny launches each (transpose, two skinny GEMMs, an M = 1 weight-gradient GEMM, a
+// column sum, fills and adds): 300 of the 617 launches of a NAR training step.  The weight gradient of a Linear with
+// ONE input row is an outer product: dW_i = dout_i^T emb, db_i = dout_i; demb = sum_i dout_i W_i.
+// One wave per 8 output rows of one item; K = d <= 2048 (NV float4 per lane).
+// ---------------------------------------------------------------------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void adaproj_fwd_kernel(const vh_adaproj_item* __restrict__ items,
+                                                          const float* __restrict__ emb, float* __restrict__ out, int N,
+                                                          int K) {
+    const int lane = threadIdx.x & 63, item = blockIdx.y;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    if (n0 >= N) return;
+    const vh_adaproj_item it = items[item];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 e[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) e[i] = (lane + 64 * i) * 4 < K ? ld4(emb + (lane + 64 * i) * 4) : z;
+    for (int n = n0; n < min(N, n0 + 8); ++n) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < K) acc += hsum4(ld4(it.w + (int64_t)n * K + c) * e[i]);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) out[(int64_t)item * N + n] = acc + (it.b ? it.b[n] : 0.f);
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void adaproj_bwd_kernel(const vh_adaproj_item* __restrict__ items,
+                                                          const float* __restrict__ emb, const float* __restrict__ dout,
+                                                          float* __restrict__ demb, int N, int K) {
+    const int lane = threadIdx.x & 63, item = blockIdx.y;
+    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
+    if (n0 >= N) return;
+    const vh_adaproj_item it = items[item];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 e[NV], acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        e[i] = (lane + 64 * i) * 4 < K ? ld4(emb + (lane + 64 * i) * 4) : z;
+        acc[i] = z;
+    }
+    for (int n = n0; n < min(N, n0 + 8); ++n) {
+        const float g = dout[(int64_t)item * N + n];
+        if (lane == 0 && it.db) it.db[n] = g;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < K) {
+                if (it.dw) st4(it.dw + (int64_t)n * K + c, e[i] * g);
+                acc[i] += ld4(it.w + (int64_t)n * K + c) * g;
+            }
+        }
+    }
+    if (demb) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < K) {
+                atomicAdd(demb + c, acc[i].x); atomicAdd(demb + c + 1, acc[i].y);
+                atomicAdd(demb + c + 2, acc[i].z); atomicAdd(demb + c + 3, acc[i].w);
+            }
+        }
+    }
+}
+
+static int adaproj_check(const char* name, const vh_adaproj_item* items, int n, const float* emb, int N, int K) {
+    VH_REQUIRE(items && emb && n > 0 && n <= 4096, VH_EINVAL, "%s: null pointer or n=%d", name, n);
+    VH_REQUIRE(N > 0 && K > 0 && K % 4 == 0 && K <= 2048, VH_EUNSUPPORTED, "%s: N=%d K=%d (K %% 4 == 0, K <= 2048)", name, N, K);
+    VH_REQUIRE(vh_aligned16(emb), VH_EALIGN, "%s: emb must be 16-byte aligned", name);
+    return VH_OK;
+}
+
+extern "C" int vh_adaproj_fwd(const vh_adaproj_item* items, int n, const float* emb, float* out, int N, int K, void* stream) {
+    if (int rc = adaproj_check("vh_adaproj_fwd", items, n, emb, N, K)) return rc;
+    VH_REQUIRE(out, VH_EINVAL, "vh_adaproj_fwd: null out");
+    const dim3 grid((N + 31) / 32, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 256) hipLaunchKernelGGL(adaproj_fwd_kernel<1>, grid, dim3(256), 0, st, items, emb, out, N, K);
+    else if (K <= 512) hipLaunchKernelGGL(adaproj_fwd_kernel<2>, grid, dim3(256), 0, st, items, emb, out, N, K);
+    else if (K <= 1024) hipLaunchKernelGGL(adaproj_fwd_kernel<4>, grid, dim3(256), 0, st, items, emb, out, N, K);
+    else hipLaunchKernelGGL(adaproj_fwd_kernel<8>, grid, dim3(256), 0, st, items, emb, out, N, K);
+    VH_CHECK_LAUNCH("vh_adaproj_fwd");
+    return VH_OK;
+}
+
+extern "C" int vh_adaproj_bwd(const vh_adaproj_item* items, int n, const float* emb, const float* dout, float* demb,
+                              int N, int K, void* stream) {
+    if (int rc = adaproj_check("vh_adaproj_bwd", items, n, emb, N, K)) return rc;
+    VH_REQUIRE(dout, VH_EINVAL, "vh_adaproj_bwd: null dout");
+    const dim3 grid((N + 31) / 32, n);
+    hipStream_t st = (hipStream_t)stream;
+    if (K <= 256) hipLaunchKernelGGL(adaproj_bwd_kernel<1>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
+    else if (K <= 512) hipLaunchKernelGGL(adaproj_bwd_kernel<2>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
+    else if (K <= 1024) hipLaunchKernelGGL(adaproj_bwd_kernel<4>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
+    else hipLaunchKernelGGL(adaproj_bwd_kernel<8>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
+    VH_CHECK_LAUNCH("vh_adaproj_bwd");
+    return VH_OK;
+}
+
