@@ -38,6 +38,9 @@ TRAIN_FULL_BATCH = 16                       # configs[3]: per-GPU B=16
 
 TRAIN_LOGIT_STRIDE = 61                     # teacher-forced logits kept at every 61st audio position
 NAR_BIG_TEXT, NAR_BIG_FRAMES = 400, 2475    # configs[4]: 400 text + 225 prompt + 2250 target frames
+NAR_FULL = dict(MID, norm='AdaptiveLayerNorm')   # configs[2] at full size (round 3): 12L/512d, batch 64, 256 text + 768 frames
+NAR_FULL_BATCH, NAR_FULL_TEXT, NAR_FULL_FRAMES = 64, 256, 768
+NAR_FULL_ROWS, NAR_FULL_STRIDE, NAR_FULL_STAGE = (0, 1, 31, 63), 29, 3      # what the fixture keeps of the (64, 618, 1024) logits
 NAR_BIG_STRIDE = 29
 SAMPLING_FILTERS = [(50, 1.0, 1.0), (5, 0.9, 0.7), (0, 0.8, 1.0), (20, 0.5, 1.3)]   # (top_k, tok_p, temperature)
 MHA_SHAPES = [(512, 8, 4, 5), (256, 4, 8, 10), (128, 2, 16, 20)]  # reference tests/test_modules.py:9-13
@@ -117,6 +120,17 @@ def nar_big_inputs():
     sd = synth.make_state_dict(cfg, 'ValleNAR', seed=17, rich=True)
     batch = synth.synth_nar_batch(cfg, 1, n_tokens=NAR_BIG_TEXT, n_frames=NAR_BIG_FRAMES, seed=313)
     return NAR_BIG, sd, batch
+
+
+def nar_full_inputs(rows=None):
+    """configs[2]: the 12L/512d NAR stack over batch 64 x (256 text + 768 frames) = 1024 positions.  `rows`: only these
+    utterances of the batch (rows are independent in the NAR forward: the CPU suite re-runs two of them)."""
+    cfg = cfg_of(NAR_FULL)
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=29, rich=True)
+    batch = synth.synth_nar_batch(cfg, NAR_FULL_BATCH, n_tokens=NAR_FULL_TEXT, n_frames=NAR_FULL_FRAMES, seed=1234)
+    if rows is not None:
+        batch = {k: v[list(rows)] for k, v in batch.items()}
+    return NAR_FULL, sd, batch
 
 
 def ar_eos_inputs(eos_row=None):
@@ -289,6 +303,19 @@ def _ref_nar_big(ref):
     return out
 
 
+def _ref_nar_full(ref):
+    kw, sd, batch = nar_full_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['nar'].ValleNAR(cfg).eval()
+    m.load_state_dict(sd)
+    tx = int(batch['tokens_lens'].max())
+    tok = m.tokens_position_emb(m.tokens_emb(batch['tokens']))
+    y, p = m._prepare_audio_codes(batch['codes'], NAR_FULL_STAGE)
+    z, _ = m.transformer(torch.cat([tok, m.audio_position_emb(y)], dim=1), embedding=m.stage_embs[NAR_FULL_STAGE - 1].weight)
+    logits = m.proj_layers[NAR_FULL_STAGE - 1](z[list(NAR_FULL_ROWS), tx + p:][:, ::NAR_FULL_STRIDE])
+    return {'logits': logits, 'prefix': torch.tensor(p)}
+
+
 def _ref_sampling_filter(ref):
     """The deterministic part of topk_sampling at top_k > 1 / top_p < 1 (valle/models/utils.py:46-68): the
     filtered scores that top_k_top_p_filtering hands to multinomial (their -inf pattern = the support) and
@@ -390,6 +417,7 @@ REFERENCE_RUNNERS = {
     'sampling': _ref_sampling,
     'sampling_filter': _ref_sampling_filter,
     'ar_generate_full': lambda ref: _ref_generate(ref, 'full'),
+    'nar_full': _ref_nar_full,
     'ar_prefill_full': _ref_prefill_full,
     'ar_train_full': _ref_ar_train_full,
     'nar_big': _ref_nar_big,

@@ -176,11 +176,20 @@ def nar_big():
     return out
 
 
+def nar_full():
+    """configs[2] at full size: the oracle re-runs utterances 0 and 1 of the 64 (rows are independent in the NAR forward)."""
+    kw, sd, batch = C.nar_full_inputs(rows=C.NAR_FULL_ROWS[:2])
+    cfg = C.cfg_of(kw)
+    logits, p = O.nar_stage_logits(sd, cfg, batch, C.NAR_FULL_STAGE)
+    assert p == min(C.NAR_FULL_FRAMES // 3, 3 * cfg.quantization_factor)
+    return {'logits': logits[:, ::C.NAR_FULL_STRIDE].contiguous()}
+
+
 # golden keys that a runner reproduces only as a prefix (full-size cases trimmed for CPU time)
-PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin')}
+PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin'), 'nar_full': ('logits',)}
 
 ORACLE_RUNNERS = {
-    'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full,
+    'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full, 'nar_full': nar_full,
     'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
     'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
     'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,

@@ -100,7 +100,7 @@ def test_config3_nar_training_step_matches_the_oracle():
     kw = dict(C.MID, norm='AdaptiveLayerNorm')
     cfg = C.cfg_of(kw)
     sd = synth.make_state_dict(cfg, 'ValleNAR', seed=23, rich=True)
-    batch = synth.synth_nar_batch(cfg, 4, n_tokens=80, n_frames=450, seed=77)
+    batch = synth.synth_nar_batch(cfg, C.TRAIN_FULL_BATCH, n_tokens=80, n_frames=450, seed=77)    # B = 16, as configs[3]
     stage = 5
     params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
     with torch.enable_grad():
@@ -118,6 +118,21 @@ def test_config3_nar_training_step_matches_the_oracle():
             continue
         torch.testing.assert_close(p.grad.cpu(), g, rtol=1e-3, atol=2e-6 + 1e-3 * float(g.abs().max()),
                                    msg=lambda s, n=n: f'{n}: {s}')
+
+
+def test_config2_full_size_nar_stage_logits_match_the_reference():
+    """configs[2] at its full size — the 12L/512d NAR stack over batch 64 x 1024 positions, as `bench.py`'s `nar` leg
+    runs it — against the real reference's sub-modules (tests/golden/gen_golden.py → nar_full: rows 0, 1, 31, 63 of the
+    batch, every 29th target frame of stage 3; logits atol 2e-4, rtol 1e-4)."""
+    gold = load_golden('nar_full')
+    kw, sd, batch = C.nar_full_inputs()
+    assert batch['codes'].shape[:2] == (64, 768) and batch['tokens'].shape == (64, 256)
+    m = build('ValleNAR', kw, sd)
+    with torch.no_grad():
+        logits, p = m.stage_logits(batch, C.NAR_FULL_STAGE)
+    assert p == int(gold['prefix']) == 150 and tuple(logits.shape) == (64, 768 - 150, 1024)
+    got = logits[list(C.NAR_FULL_ROWS)][:, ::C.NAR_FULL_STRIDE].cpu()
+    torch.testing.assert_close(got, gold['logits'], atol=2e-4, rtol=1e-4)
 
 
 def test_config4_nar_stage_logits_match_the_reference():
