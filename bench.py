@@ -520,7 +520,7 @@ def main():
                     'marker_bracket_us = two marker events recorded around the same launch (event + dispatch overhead '
                     'included; not used), marker_floor_us = that bracket with nothing inside; traffic = PMC FETCH_SIZE/WRITE_SIZE from separate '
                     'rocprofv3 --pmc passes of this workload, committed under profiles/ (null when absent)'}
-        measured = None if (args.small or args.no_traffic) else measure_attn_traffic(rows, new)
+        measured = None if (args.small or args.no_traffic or world > 1) else measure_attn_traffic(rows, new)
         pmc = REPO / 'profiles' / 'attn_decode_traffic.json'
         if measured:
             result['roofline']['traffic'] = measured['bytes_per_launch']
@@ -542,7 +542,7 @@ def main():
                       + 2 * cfg.num_layers * rows * cfg.d_model for t in range(1, new)]
         result['roofline']['decode_algorithmic_bytes_total'] = 4.0 * sum(step_elems)
 
-    if rank == 0 and not args.no_beams:
+    if rank == 0 and world == 1 and not args.no_beams:       # secondary objects: the N = 1 line only (N > 1 measures scaling)
         # the reference's own signature (valle_ar.py:136-138): ONE utterance, num_beams = 32 replicated rows, greedy;
         # rows are never deduplicated, so this costs what the 32-distinct-utterances headline costs
         log('beams: generate() of one utterance with num_beams=32')
@@ -563,7 +563,7 @@ def main():
                            'prefill_ms': st_b['prefill_ms'],
                            'vs_distinct_rows': (rows * new / dtb) / (value / world)}
 
-    if rank == 0 and not args.no_perf_mode:
+    if rank == 0 and world == 1 and not args.no_perf_mode:
         # SURVEY section 7's perf mode, a LABELLED SECONDARY line (narrower storage than the reference: never the headline,
         # never `dtype`): the same generate over a bf16 K/V cache, everything else fp32
         log('perf_mode: the same generate over a bf16 K/V cache')
@@ -591,7 +591,7 @@ def main():
             'frac': gbs_p / HBM_PEAK_GBS, 'vs_f32_headline': (rows * new / dtp) / (value / world),
             'greedy_tokens_equal_to_f32_run': float((out_p == out).float().mean())}
 
-    if rank == 0 and not args.no_config5 and not args.small:
+    if rank == 0 and world == 1 and not args.no_config5 and not args.small:
         result['config5'] = config5_leg(dev)
 
     if rank == 0 and world == 1 and not args.no_nar and not args.small:

@@ -35,4 +35,4 @@ def test_bench_small_four_ranks_on_one_gpu():
     assert train['ar_ms_per_step'] > 0 and train['nar_ms_per_step'] > 0
     assert train['ar_allreduce_bytes'] > 0 and train['nar_allreduce_bytes'] > 0     # the exchange ran (world > 1)
     assert 0 < train['ar_frac'] < 1 and 0 < train['nar_frac'] < 1
-    assert 'beams' in r and r['beams']['value'] > 0
+    assert 'beams' not in r and 'perf_mode' not in r           # secondary objects belong to the N = 1 line
