@@ -285,28 +285,37 @@ __global__ __launch_bounds__(256) void cross_entropy_kernel(
     const float* __restrict__ logits, int ld, int V, const int64_t* __restrict__ target,
     float* __restrict__ loss, float* __restrict__ dlogits, int ldd, float inv_rows, int rows,
     int32_t* __restrict__ err_flag) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* lr = logits + (int64_t)row * ld;
-    float m = NEG_INF;
-    for (int j = lane; j < V; j += 64) m = fmaxf(m, lr[j]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int j = lane; j < V; j += 64) l += expf(lr[j] - m);
-    l = wave_sum(l);
-    const float lse = m + logf(l);
-    const int64_t t64 = target[row];
-    const bool ok = t64 >= 0 && t64 < V;            // F.cross_entropy raises for a class outside [0, V)
-    const int tgt = ok ? (int)t64 : -1;
+    __shared__ float s_part[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float part = 0.f;                               // this wave's share of the mean loss
+    bool bad = false;
+    // a wave walks rows; the loss leaves the workgroup as ONE atomic (one per row — 14 400 adds onto one address —
+    // ran at the contended-atomic rate of the memory side and was most of the launch: 195 us for 118 MB of traffic)
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+        const float* lr = logits + (int64_t)row * ld;
+        float m = NEG_INF;
+        for (int j = lane; j < V; j += 64) m = fmaxf(m, lr[j]);
+        m = wave_max(m);
+        float l = 0.f;
+        for (int j = lane; j < V; j += 64) l += expf(lr[j] - m);
+        l = wave_sum(l);
+        const float lse = m + logf(l);
+        const int64_t t64 = target[row];
+        const bool ok = t64 >= 0 && t64 < V;        // F.cross_entropy raises for a class outside [0, V)
+        const int tgt = ok ? (int)t64 : -1;
+        part += (lse - (ok ? lr[tgt] : 0.f)) * inv_rows;
+        bad |= !ok;
+        if (dlogits) {
+            float* dr = dlogits + (int64_t)row * ldd;
+            for (int j = lane; j < V; j += 64) dr[j] = (expf(lr[j] - lse) - (j == tgt ? 1.f : 0.f)) * inv_rows;
+        }
+    }
     if (lane == 0) {
-        atomicAdd(loss, (lse - (ok ? lr[tgt] : 0.f)) * inv_rows);
-        if (!ok && err_flag) atomicOr(err_flag, VH_DEVERR_TARGET);
+        s_part[w] = part;
+        if (bad && err_flag) atomicOr(err_flag, VH_DEVERR_TARGET);
     }
-    if (dlogits) {
-        float* dr = dlogits + (int64_t)row * ldd;
-        for (int j = lane; j < V; j += 64) dr[j] = (expf(lr[j] - lse) - (j == tgt ? 1.f : 0.f)) * inv_rows;
-    }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]));
 }
 
 extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
@@ -318,7 +327,8 @@ extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_
         vh_set_error("vh_cross_entropy: hipMemsetAsync failed");
         return VH_ELAUNCH;
     }
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, logits, ld, V, target,
+    const int ce_blocks = (rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048;
+    hipLaunchKernelGGL(cross_entropy_kernel, dim3(ce_blocks), dim3(256), 0, st, logits, ld, V, target,
                        loss, dlogits, ldd, 1.0f / (float)rows, rows, err_flag);
     VH_CHECK_LAUNCH("vh_cross_entropy");
     return VH_OK;
