@@ -54,11 +54,10 @@ const char* vh_last_error(void);
 
 /* Kernel-selection knobs for benchmarking A/B runs in one process (0 = built-in default).
  * Results are identical up to fp32 summation order whatever the setting. */
-enum { VH_TUNE_DECODE_VARIANT = 0,  /* 0 = default (ring kernel 7 when one (b,head) per CU and n_split == 1, else burst 1);
-                                       1 = 32-key burst kernel, 2 = 16-key pipelined, 3 = burst with temporal loads,
-                                       4..9 = ring kernels (waves x register sets x keys: 8x3x32, 16x1x32, 12x2x32, 8x2x32,
-                                       16x2x16, 8x4x16), 10.. = diagnostics without arithmetic */
-       VH_TUNE_DECODE_WAVES = 1,    /* waves per decode-attention workgroup: 4, 8 or 16 */
+enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring kernel, 8 waves x 2 register sets of 32 keys, when there
+                                       is one (b, head) per CU and no key split; else the 32-key burst kernel), 1 = always the burst
+                                       kernel */
+       VH_TUNE_DECODE_WAVES = 1,    /* waves per workgroup of the burst kernel: 4, 8 or 16 (nonzero also selects the burst kernel) */
        VH_TUNE_ROW_GROUPS = 2,      /* decode GEMMs (16 < M <= 64): 1 (default) = one workgroup per 16 rows x 16 columns,
                                        (8 rows while the grid stays within the CUs), 2 = one workgroup per
                                        16 columns (all rows), 3 = groups of 16 rows only */

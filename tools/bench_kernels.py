@@ -41,32 +41,17 @@ def bench_attn():
         bytes_ = 2 * B * S * 512 * 4
         res = {}
         for rnd in range(3):
-            for variant in (1, 2, 3):
-                for waves in (4, 8, 16):
-                    for ns in (1, 2, 4):
-                        if waves == 16 and ns > 1 or waves == 4 and ns == 1:
-                            continue
-                        lib.vh_set_tuning(0, variant)
-                        lib.vh_set_tuning(1, waves)
-                        ws = K.attn_decode_ws(B, h, ns, DEV)
-                        i = [0]
-
-                        def fn():
-                            kc, vc = caches[i[0] % 12]
-                            i[0] += 1
-                            K.attn_decode(q, kc, vc, out, cl, 1, ns, ws)
-                        res.setdefault((variant, waves, ns), []).append(timeit(fn, iters=48))
-        for rnd in range(3):                      # ring kernels (round 2): the variant fixes waves x register sets
-            for variant in (4, 5, 6, 7, 8, 9):
+            for variant, waves, ns in ((0, 0, 1), (1, 16, 1), (1, 8, 1), (1, 8, 2), (1, 4, 2), (1, 4, 4)):
                 lib.vh_set_tuning(0, variant)
-                lib.vh_set_tuning(1, 0)
+                lib.vh_set_tuning(1, waves)
+                ws = K.attn_decode_ws(B, h, ns, DEV)
                 i = [0]
 
                 def fn():
                     kc, vc = caches[i[0] % 12]
                     i[0] += 1
-                    K.attn_decode(q, kc, vc, out, cl, 1, 1, None)
-                res.setdefault((variant, 0, 1), []).append(timeit(fn, iters=48))
+                    K.attn_decode(q, kc, vc, out, cl, 1, ns, ws)
+                res.setdefault((variant, waves, ns), []).append(timeit(fn, iters=48))
         for k, v in sorted(res.items(), key=lambda kv: statistics.median(kv[1])):
             us = statistics.median(v)
             print(f'attn S={S} variant={k[0]} waves={k[1]} n_split={k[2]}: {us:7.2f} us  '

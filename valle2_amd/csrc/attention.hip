@@ -120,109 +120,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     }
 }
 
-// Pipelined variant: 16-key chunks, two named register sets (A/B): the loads of chunk c+NW are in
-// flight while chunk c is reduced, so the wave never idles between a burst and its use.
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
-    const float* __restrict__ q, int ldq, const float* __restrict__ kc,
-    const float* __restrict__ vc, float* __restrict__ out, int ldo,
-    const int32_t* __restrict__ cache_len, int len_bias, int n_heads, int S_max, int n_split,
-    float* __restrict__ partial) {
-    __shared__ float s_m[NW], s_l[NW];
-    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
-    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
-    const int split = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int c16 = lane & 15, g = lane >> 4;
-    const int len = cache_len[b] + len_bias;
-    const int nchunks = (len + 15) >> 4;
-    const int cps = (nchunks + n_split - 1) / n_split;
-    const int c_begin = split * cps;
-    const int c_end = min(nchunks, c_begin + cps);
-
-    const float qscale = 0.125f * LOG2E;
-    const f32x4 q4 = ld4(q + (int64_t)b * ldq + head * HD + 4 * c16) * qscale;
-    const float* kb = kc + (int64_t)bh * S_max * HD + 4 * c16;
-    const float* vb = vc + (int64_t)bh * S_max * HD + 4 * c16;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-
-    float m = NEG_INF, l = 0.f;
-    f32x4 o = zero4;
-    f32x4 kA[4], vA[4], kB[4], vB[4];
-    auto load = [&](int c, f32x4 (&kf)[4], f32x4 (&vf)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = c * 16 + g + 4 * i;
-            const bool in = c < c_end && key < len;
-            kf[i] = in ? ld4(kb + (int64_t)key * HD) : zero4;
-            vf[i] = in ? ld4(vb + (int64_t)key * HD) : zero4;
-        }
-    };
-    auto reduce = [&](int c, const f32x4 (&kf)[4], const f32x4 (&vf)[4]) {
-        float s[4];
-        float cmax = NEG_INF;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 t = kf[i] * q4;
-            const float d = row16_sum((t.x + t.y) + (t.z + t.w));
-            s[i] = (c * 16 + g + 4 * i < len) ? d : NEG_INF;
-            cmax = fmaxf(cmax, s[i]);
-        }
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
-        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-        const float m_new = fmaxf(m, cmax);
-        const float alpha = vh_exp2(m - m_new);
-        o *= alpha;
-        l *= alpha;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float p = vh_exp2(s[i] - m_new);
-            l += p;
-            o += vf[i] * p;
-        }
-        m = m_new;
-    };
-    int c = c_begin + w;
-    load(c, kA, vA);
-    while (c < c_end) {
-        load(c + NW, kB, vB);
-        reduce(c, kA, vA);
-        c += NW;
-        if (c >= c_end) break;
-        load(c + NW, kA, vA);
-        reduce(c, kB, vB);
-        c += NW;
-    }
-#pragma unroll
-    for (int sh = 16; sh <= 32; sh <<= 1) {
-        o.x += __shfl_xor(o.x, sh, 64); o.y += __shfl_xor(o.y, sh, 64);
-        o.z += __shfl_xor(o.z, sh, 64); o.w += __shfl_xor(o.w, sh, 64);
-        l += __shfl_xor(l, sh, 64);
-    }
-    if (lane < 16) st4(&s_o[w][4 * c16], o);
-    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
-    __syncthreads();
-    if (tid < HD) {
-        float M = s_m[0];
-#pragma unroll
-        for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
-        float L = 0.f, O = 0.f;
-#pragma unroll
-        for (int k = 0; k < NW; ++k) {
-            const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);
-            L += s_l[k] * wgt;
-            O += s_o[k][tid] * wgt;
-        }
-        if (n_split == 1) {
-            out[(int64_t)b * ldo + head * HD + tid] = O / L;
-        } else {
-            float* pr = partial + ((int64_t)bh * n_split + split) * PART_LD;
-            pr[tid] = O;
-            if (tid == 0) { pr[HD] = M; pr[HD + 1] = L; }
-        }
-    }
-}
-
 // Ring variant (round 2).  The burst kernel has its 256 KB per CU in flight only at the moment its 16 waves have
 // all just issued; each wave then waits for its whole burst, reduces it, and only then asks again, and its very first
 // request waits for a dependent load of cache_len[b].  Here a wave owns a ring of D register sets of 32 keys each:
@@ -231,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_pipe_kernel(
 // the length has arrived), so the stream starts with the kernel.  The read ceiling of this part is 6.3-6.5 TB/s
 // for any read-only kernel (tools/probe_read_bw.hip, corrected: its first version dropped loop remainders and
 // reported 8 TB/s); the 8 x 2 ring reaches 6.0-6.1 TB/s inside the decode step.
-template <int NW, int D, int CK = 32, bool NOCOMP = false>
+template <int NW, int D, int CK = 32>
 __global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ kc,
     const float* __restrict__ vc, float* __restrict__ out, int ldo,
@@ -281,12 +178,6 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_ring_kernel(
     float m = NEG_INF, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     auto reduce = [&](int c, const f32x4 (&kq)[LPS], const f32x4 (&vq)[LPS]) {
-        if (NOCOMP) {                                             // diagnostic: the loads alone (wrong results)
-#pragma unroll
-            for (int i = 0; i < LPS; ++i) o += kq[i] + vq[i];
-            m = 0.f; l = 1.f;
-            return;
-        }
         const int key0 = c * CK + g;
         const bool whole = c * CK + CK <= len;                    // wave-uniform: no masking for interior chunks
         float sc[LPS];
@@ -579,30 +470,19 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
 #define AD(KERN, ...)                                                                              \
     hipExtLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, q, ldq, \
                           kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
-    int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
-    const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
     // default: one (b, head) per CU and no key split -> the ring kernel (8 waves x 2 register sets of 32 keys, speculative
-    // start: 605.9 vs 615.2 us per decode step, profiles/r2_ab_decode_ring.log); otherwise the burst kernel
-    if (variant == 0 && big && n_split == 1 && nw == 0) variant = 7;
-    const int waves = nw ? nw : (big ? 16 : 4);
-    if (variant >= 4) {          // ring kernels: 4 = 8 waves x 3 sets, 5 = 16 waves x 1 set + speculative start, 6 = 12 x 2, 7 = 8 x 2
-        if (variant == 4) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 3); }
-        else if (variant == 5) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 1); }
-        else if (variant == 6) { const int waves = 12; AD(attn_decode_ring_kernel, 12, 2); }
-        else if (variant == 7) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 2); }
-        else if (variant == 8) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 2, 16); }
-        else if (variant == 9) { const int waves = 8; AD(attn_decode_ring_kernel, 8, 4, 16); }
-        else if (variant == 10) { const int waves = 16; AD(attn_decode_ring_kernel, 16, 1, 32, true); }   // diagnostic: no compute
-        else { const int waves = 8; AD(attn_decode_ring_kernel, 8, 2, 32, true); }                         // diagnostic
-    } else if (variant == 3) {          // burst kernel with plain (temporal) loads, for A/B runs
-        if (waves == 16) AD(attn_decode_kernel, 16, false); else if (waves == 8) AD(attn_decode_kernel, 8, false);
-        else AD(attn_decode_kernel, 4, false);
-    } else if (variant != 2) {   // default: burst kernel, non-temporal K/V loads
+    // start: 605.9 vs 615.2 us per decode step, profiles/r2_ab_decode_ring.log); otherwise — key splits, more (b, head)
+    // pairs than CUs — the burst kernel.  VH_TUNE_DECODE_VARIANT = 1 forces the burst kernel (A/B); the other ring
+    // shapes round 2 measured (8x3, 16x1, 12x2, 16x2x16-key, 8x4x16-key; profiles/r2_attn_ab.log) were slower and are gone.
+    const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
+    const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
+    if (variant != 1 && big && n_split == 1 && nw == 0) {
+        const int waves = 8;
+        AD(attn_decode_ring_kernel, 8, 2);
+    } else {
+        const int waves = nw ? nw : (big ? 16 : 4);
         if (waves == 16) AD(attn_decode_kernel, 16, true); else if (waves == 8) AD(attn_decode_kernel, 8, true);
         else AD(attn_decode_kernel, 4, true);
-    } else {
-        if (waves == 16) AD(attn_decode_pipe_kernel, 16); else if (waves == 8) AD(attn_decode_pipe_kernel, 8);
-        else AD(attn_decode_pipe_kernel, 4);
     }
 #undef AD
     if (n_split > 1)
