@@ -33,6 +33,7 @@ AR_FULL = dict(MID, norm='LayerNorm', num_beams=32, top_k=1, max_audio_len=512)
 AR_TRAIN_FULL = dict(MID, norm='LayerNorm')
 BIG = dict(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0)
 NAR_BIG = dict(BIG, norm='AdaptiveLayerNorm')
+AR_BIG = dict(BIG, norm='LayerNorm', num_beams=8, top_k=1, max_audio_len=48)   # configs[4]'s AR leg (round 3)
 FULL_TEXT, FULL_FRAMES = 256, 767           # configs[1]: 256 text + BOS + 767 codec tokens = 1024
 TRAIN_FULL_BATCH = 16                       # configs[3]: per-GPU B=16
 
@@ -82,11 +83,13 @@ def ar_train_inputs():
 
 
 def ar_generate_inputs(which):
-    kw = {'tiny': AR_TINY, 'mid': AR_MID, 'full': AR_FULL}[which]
+    kw = {'tiny': AR_TINY, 'mid': AR_MID, 'full': AR_FULL, 'big': AR_BIG}[which]
     cfg = cfg_of(kw)
     sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=5, rich=True), cfg)
     if which == 'full':   # BASELINE.json configs[1] at full size: 32 beams, 256 text + BOS + 767 codec tokens
         utt = synth.synth_utterance(cfg, FULL_TEXT // 2, FULL_TEXT // 2, FULL_FRAMES, seed=1234)
+    elif which == 'big':    # BASELINE.json configs[4], AR leg: 24L/1024d/h16, 8 beams, 400 text + BOS + 225 codec tokens
+        utt = synth.synth_utterance(cfg, 200, 200, 225, seed=1234)
     elif which == 'tiny':   # BASELINE.json configs[0]: 128 text + 256 EnCodec tokens (255 + BOS)
         utt = synth.synth_utterance(cfg, 64, 64, 255, seed=1234)
     else:                 # reduced configs[1]: 12L/512d, short prompt so the fixture stays small
@@ -417,6 +420,7 @@ REFERENCE_RUNNERS = {
     'sampling': _ref_sampling,
     'sampling_filter': _ref_sampling_filter,
     'ar_generate_full': lambda ref: _ref_generate(ref, 'full'),
+    'ar_generate_big': lambda ref: _ref_generate(ref, 'big'),
     'nar_full': _ref_nar_full,
     'ar_prefill_full': _ref_prefill_full,
     'ar_train_full': _ref_ar_train_full,

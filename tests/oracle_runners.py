@@ -141,6 +141,13 @@ def ar_generate_full():
     return {'tokens': res['tokens'], 'margin': res['margin']}
 
 
+def ar_generate_big():
+    """configs[4]'s AR leg (24L/1024d, 8 beams, 626-token prompt): the oracle re-runs the first steps of the 48."""
+    kw, sd, utt = C.ar_generate_inputs('big')
+    res = _generate(dict(kw, max_audio_len=4), sd, utt)
+    return {'tokens': res['tokens'], 'margin': res['margin']}
+
+
 def ar_prefill_full():
     kw, sd, text, codes, pos = C.ar_prefill_full_inputs()
     cfg = C.cfg_of(kw)
@@ -186,10 +193,11 @@ def nar_full():
 
 
 # golden keys that a runner reproduces only as a prefix (full-size cases trimmed for CPU time)
-PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin'), 'nar_full': ('logits',)}
+PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin'), 'ar_generate_big': ('tokens', 'margin'), 'nar_full': ('logits',)}
 
 ORACLE_RUNNERS = {
-    'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full, 'nar_full': nar_full,
+    'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full, 'ar_generate_big': ar_generate_big,
+    'nar_full': nar_full,
     'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
     'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
     'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,

@@ -56,6 +56,29 @@ def test_config1_full_size_greedy_tokens_match_the_reference():
     assert torch.equal(rows[:, 768:].cpu(), gold['tokens'][None].expand(32, -1))
 
 
+def test_config4_ar_leg_greedy_tokens_match_the_reference():
+    """configs[4]'s AR leg at its own prompt size — 24L/1024d/h16, 8 beams, 400 text + BOS + 225 codec tokens — against
+    the real reference (ar_generate_big.npz, 48 greedy steps, minimum margin 1.6e-2).  This is the shape that takes the
+    paths configs[1] does not: 8 x 16 = 128 (row, head) pairs -> key-split attention + combine launch, the folded
+    LayerNorm at K = 1024 (two K passes, statistics from the fragments), the three-launch FeedForward (d_model > 512)."""
+    from tests.test_models_gpu import tokens_match
+    gold = load_golden('ar_generate_big')
+    kw, sd, utt = C.ar_generate_inputs('big')
+    assert kw['num_layers'] == 24 and kw['d_model'] == 1024 and utt[1].shape[0] == 225 and int(gold['steps']) == 48
+    m = build('ValleAR', kw, sd)
+    out = m.generate(*[u.to(DEV) for u in utt])
+    st = m.last_generate_stats
+    assert st['n_split'] == 2 and st['s0'] == 626 and not st['ffn_fused']
+    tokens_match(out, gold['tokens'], gold['margin'])
+    assert torch.equal(out.cpu(), gold['tokens'])
+    # the logits the decoder's head produced on the reference's trajectory, at the steps the fixture keeps
+    steps = list(range(0, 48, 6))
+    text = torch.cat([utt[0], utt[2]]).to(DEV)
+    m.generate_batch([text] * 8, [utt[1][:, 0].to(DEV)] * 8, max_new=48, forced=gold['tokens'], keep_logits=steps)
+    got = torch.stack([m.last_generate_stats['logits'][t][0] for t in steps]).cpu()
+    torch.testing.assert_close(got, gold['logits_row0'], atol=2e-4, rtol=1e-4)
+
+
 def test_config1_full_size_prefill_logits_match_the_reference():
     gold = load_golden('ar_prefill_full')
     kw, sd, text, codes, pos = C.ar_prefill_full_inputs()

@@ -32,7 +32,7 @@ def test_oracle_matches_reference_golden(name):
 def test_greedy_tokens_are_exact_and_margins_recorded():
     # the golden carries the per-step top-1/top-2 margin so GPU tests can tell a real
     # divergence from a near-tie (SURVEY.md §7 "hard parts")
-    for name in ('ar_generate_tiny', 'ar_generate_mid', 'ar_generate_full'):
+    for name in ('ar_generate_tiny', 'ar_generate_mid', 'ar_generate_full', 'ar_generate_big'):
         gold = load_golden(name)
         assert gold['tokens'].dtype == torch.int64
         assert int(gold['steps']) == gold['margin'].numel() == gold['tokens'].numel()
