@@ -274,6 +274,14 @@ class ArDecoder:
                                 self.eos_count, self.sum_logprobs, m[1], m[2], self.audio_pos,
                                 self.cache_len, self.x, pos_base=self.pos_base)
 
+    def capture(self):
+        """Record the step graphs now (host work only: capture enqueues nothing).  generate_batch calls it right after
+        the prompt pass is enqueued, so the ~1.7 ms of capture + instantiate run on the host while the GPU is busy."""
+        if self.use_graph and not self._captured:
+            cap = _capture_stream(torch.cuda.current_device())
+            check(_lib.lib().vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
+            self._captured = True
+
     def run(self, n_steps):
         """Enqueue n_steps decode steps on the current stream (graph replay when enabled)."""
         if n_steps <= 0:
@@ -281,12 +289,7 @@ class ArDecoder:
         s = stream()
         L = _lib.lib()
         if self.use_graph:
-            if not self._captured:
-                cap = _capture_stream(torch.cuda.current_device())
-                cap.wait_stream(torch.cuda.current_stream())
-                check(L.vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
-                torch.cuda.current_stream().wait_stream(cap)
-                self._captured = True
+            self.capture()
             check(L.vh_ar_decoder_replay(self._h, n_steps, s), 'vh_ar_decoder_replay')
         else:
             for _ in range(n_steps):

@@ -241,13 +241,15 @@ class ValleAR(_Base):
                 self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :pls[b]], x[b:b + 1])
             lens = torch.tensor([t + p for t, p in zip(txs, pls)], **i32)
             fwd = dict(x_len_dev=torch.tensor(txs, **i32), kv_len=lens)
+        # (the decode loop's small state goes up BEFORE the prompt pass is enqueued: a host->device copy behind it
+        # would hold the host until the pass has finished, and the decoder is built and captured during the pass)
+        cache_len = _lib.to_device_async(torch.tensor([t + p - 1 for t, p in zip(txs, pls)], dtype=torch.int32), dev)
+        audio_pos = _lib.to_device_async(torch.tensor(pls, dtype=torch.int32), dev)   # cache_len: +1 by the sample step
+        pos_base = audio_pos.clone()
         transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
                             scratch=ForwardScratch(B * s0, d, cfg.dim_feedforward, dev), **fwd)
         if ragged:
             last = x[torch.arange(B, device=dev), lens.long() - 1]
-        cache_len = torch.tensor([t + p - 1 for t, p in zip(txs, pls)], **i32)    # +1 by the sample step
-        audio_pos = torch.tensor(pls, **i32)
-        pos_base = audio_pos.clone()
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
         if perf_mode:
@@ -255,6 +257,7 @@ class ValleAR(_Base):
         dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph,
                         seed=seed)
         try:
+            dec.capture()
             dec.sample_from(last.contiguous())
             marks[1].record()
             del x, last
