@@ -74,7 +74,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_FFN_ROWS = 8,        /* vh_ffn_decode: rows per workgroup, 0 (default) = chosen from the shape, else 8 / 16 */
        VH_TUNE_LN_STATS = 9,        /* folded-LayerNorm decode GEMMs on <= 16 rows per workgroup: 0 (default) = row statistics from
                                        the operand fragments (no second read of the rows), 1 = from their own row loads */
-       VH_TUNE_COUNT = 10 };
+       VH_TUNE_TAIL_SPLIT = 10,     /* vh_linear_ex with a workspace: 0 (default) = the tiles beyond the last multiple of 256 are
+                                       computed as K slices + a fix-up launch when they would fill <= half of the CUs, 1 = never */
+       VH_TUNE_COUNT = 11 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------
@@ -417,10 +419,19 @@ int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *                     column and tile) — the gradient of linear_1's bias falls out of the product that makes its
  *                     pre-activation's gradient, without a column-sum launch.
  * The backward's dX = dY . W products run on this NT form with W handed over transposed (vh_transpose),
- * so K here is the forward's N: pad it to a multiple of 32 with zero columns for the fast kernel. */
+ * so K here is the forward's N: pad it to a multiple of 32 with zero columns for the fast kernel.
+ *   workspace (optional, vh_linear_ex_ws_bytes(M, N, K) bytes, 16-byte aligned): lets the product split its TAIL.
+ *                     128 x 128 tiles are dealt to 256 CUs, so T tiles cost ceil(T / 256) rounds: 320 tiles (10240
+ *                     training positions x a 512-wide projection) take as long as 512.  With a workspace the tiles
+ *                     beyond the last multiple of 256 — when they would occupy at most half of the CUs — are computed
+ *                     as 2..8 K slices each (one workgroup per slice, raw sums to the workspace) and a small second
+ *                     launch adds the slices in slice order and applies the epilogue: deterministic, but those tiles'
+ *                     sums are associated differently from an unsplit run.  vh_linear_ex_ws_bytes returns 0 for a
+ *                     shape that is not split (<= 16 MiB otherwise); NULL or a smaller workspace = never split. */
+size_t vh_linear_ex_ws_bytes(int M, int N, int K);
 int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
                  float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K, int act,
-                 void* stream);
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* out (cols, ldo) = in (rows, cols)^T; out rows are zero-filled from `rows` up to ldo. */
 int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream);

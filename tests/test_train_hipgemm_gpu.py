@@ -111,6 +111,47 @@ def test_linear_ex_training_epilogues(M):
     torch.testing.assert_close(dx.cpu(), dl[:, :1025] @ wp, atol=5e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('M,N,Kd', [(10240, 512, 512), (10240 - 37, 512, 1536), (2300, 2048, 512), (8192 + 5, 512, 256)])
+def test_linear_ex_tail_split(M, N, Kd):
+    """vh_linear_ex with a workspace: the tiles beyond the last multiple of 256 run as K slices + the fix-up launch
+    (320 / 320 / 288 / 260 tiles here; the last shape splits 2 ways only: K / split >= 128).  Every epilogue of the
+    fix-up against torch, and against the unsplit kernel (knob 10 = 1) on the same inputs."""
+    from valle2_amd import _lib, kernels as K
+    assert _lib.lib().vh_linear_ex_ws_bytes(M, N, Kd) > 0
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, Kd, generator=g).to(DEV)
+    w = (0.05 * torch.randn(N, Kd, generator=g)).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(DEV)
+    ref_pre = torch.addmm(b, a, w.t())
+    outs = {}
+    for knob in (0, 1):
+        _lib.lib().vh_set_tuning(10, knob)
+        try:
+            pre, cs = torch.empty(M, N, device=DEV), torch.zeros(N, device=DEV)
+            plain = K.linear_ex(a, w, bias=b, residual=res, out=torch.empty(M, N, device=DEV), colsum=cs)
+            act = K.linear_ex(a, w, bias=b, pre_out=pre, act=K.ACT_GELU, out=torch.empty(M, N, device=DEV))
+            bwd = K.linear_ex(a, w, residual=ref_pre, act=K.ACT_GELU_BWD, out=torch.empty(M, N, device=DEV))
+        finally:
+            _lib.lib().vh_set_tuning(10, 0)
+        outs[knob] = (plain, cs, pre, act, bwd)
+    plain, cs, pre, act, bwd = outs[0]
+    tol = dict(atol=5e-5, rtol=2e-5)
+    torch.testing.assert_close(plain, ref_pre + res, **tol)
+    torch.testing.assert_close(cs, (ref_pre + res).sum(0), atol=2e-2, rtol=1e-4)
+    torch.testing.assert_close(pre, ref_pre, **tol)
+    torch.testing.assert_close(act, F.gelu(ref_pre), **tol)
+    p = ref_pre.clone().requires_grad_()
+    F.gelu(p).backward(a @ w.t())
+    torch.testing.assert_close(bwd, p.grad, **tol)
+    n_whole = ((M + 127) // 128 * (N // 128)) // 256 * 256          # whole tiles: the same kernel path, bit for bit
+    rows_whole = n_whole // (N // 128) * 128
+    for x, y in zip(outs[0], outs[1]):
+        if x.dim() == 2:
+            assert torch.equal(x[:rows_whole], y[:rows_whole])
+            torch.testing.assert_close(x[rows_whole:], y[rows_whole:], **tol)
+
+
 def test_ffn_function_matches_the_unfused_composition():
     """FfnFn (fused GELU forward / backward) against LinearFn + GeluFn + LinearFn on the same inputs."""
     from valle2_amd import autograd as A

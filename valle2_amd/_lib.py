@@ -136,7 +136,8 @@ SIGNATURES = {
                                C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
     'vh_colsum': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_linear_ex': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
-                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'vh_linear_ex_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'vh_transpose': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     'vh_transpose_many': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'vh_adaproj_fwd': (C.c_int, [C.c_void_p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_void_p]),

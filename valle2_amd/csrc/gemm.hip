@@ -472,8 +472,18 @@ __device__ unsigned vh_tile_hwid[8192 * 2];
 // avoided by an XOR swizzle of the 16-byte chunk index with (row >> 1) & 7 — applied to the per-lane
 // SOURCE address of the DMA and to the fragment reads alike (cdna_hip_programming.md rule 21).
 // =============================================================================================
+// Tail split.  The grid's tiles are dealt to 256 CUs, so T tiles cost ceil(T / 256) tile-times whatever T is: 320 tiles
+// (16 x 640 training positions through a 512-wide projection) run as long as 512 do.  With a TailSplit the first
+// n_whole tiles (a multiple of 256) are computed whole and each of the remaining tiles as `split` K slices of k_len,
+// one workgroup per slice, whose raw sums go to ws[(tail tile * split + slice)][128][128]; tile_tail_fixup_kernel adds
+// the slices in slice order and applies the epilogue.  n_whole == number of tiles: no tail, the kernel as before.
+struct TailSplit {
+    int n_whole, split, k_len;
+    float* ws;
+};
+
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int tiles_m, int tiles_n) {
+__global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int tiles_m, int tiles_n, TailSplit ts) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];  // [buf][A|W][row][32] (+ slack for the epilogue)
     // Outside the main loop the wave runs at raised priority: its scalar/vector bookkeeping competes for issue slots
     // with the MFMA stream of the CU's other workgroup, and a short prologue / epilogue is worth more than the few
@@ -488,11 +498,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 
     // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD
     // a contiguous run of tiles; tiles are numbered n-fastest so a run shares its A row panel in L2.
-    const int nwg = tiles_m * tiles_n;
+    const int nwg = ts.n_whole;                           // (the whole tiles; the K slices of the tail tiles follow them)
     const int bid = blockIdx.x;
+    const bool tail = bid >= nwg;                         // workgroup-uniform
     const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int unit = bid - nwg;
+    const int tile = tail ? nwg + unit / ts.split
+                          : (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
     const int m0 = (tile / tiles_n) * TM, n0 = (tile % tiles_n) * TN;
+    const int k_len = tail ? ts.k_len : a.k_len;
+    const int k_ofs = tail ? (unit % ts.split) * ts.k_len : blockIdx.y * a.k_len;
 
     // DMA staging: wave w issues pieces q = 8w .. 8w+7 of a slab (16 pieces of A, then 16 of W); lane L of a
     // piece fills LDS slot L = (row in the 8-row group, chunk position p): it must fetch chunk p ^ swz(row).
@@ -501,8 +516,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
     // loop then holds no vector address arithmetic at all, which matters because ordinary VALU instructions and
     // MFMAs share an issue port (every one of them is a bubble in the MFMA stream of a CU's other workgroup too).
     const int ws = __builtin_amdgcn_readfirstlane(w);
-    const char* baseA = (const char*)(a.A + (int64_t)m0 * a.lda + blockIdx.y * a.k_len);
-    const char* baseW = (const char*)(a.W + (int64_t)n0 * a.K + blockIdx.y * a.k_len);
+    const char* baseA = (const char*)(a.A + (int64_t)m0 * a.lda + k_ofs);
+    const char* baseW = (const char*)(a.W + (int64_t)n0 * a.K + k_ofs);
     uint32_t voff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -531,12 +546,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = a.k_len / TK;
+    const int nk = k_len / TK;
 #pragma unroll
     for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
 
     TileEpi epi;                                          // residual and bias, fetched now (see tile_epilogue)
-    tile_prefetch<EPI>(a, m0, n0, tid, epi);
+    if (!tail) tile_prefetch<EPI>(a, m0, n0, tid, epi);
     __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): slab 0 (and the residual prefetch) landed
     __syncthreads();
     // Main loop.  Each K step is four groups of 16 MFMAs on one register set of fragments; the other set is
@@ -631,7 +646,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 #endif
 
     __builtin_amdgcn_s_setprio(3);
-    tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
+    if (tail) {                                           // raw sums of this K slice -> its 128 x 128 slab
+        GemmArgs p = a;
+        p.ldo = TN;
+        p.out = ts.ws + (int64_t)unit * TM * TN - ((int64_t)m0 * TN + n0);
+        tile_epilogue<EPI_PARTIAL>(p, acc, &lds[0][0][0], m0, n0, tid, epi);
+    } else {
+        tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
+    }
 #ifdef VH_TILE_PROBE
     if ((tid & 63) == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + (tid >> 6)) * 200 + 197] = clock64();
 #endif
@@ -1057,6 +1079,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     st4(a.out + (int64_t)m * a.ldo + n, acc + res4);
 }
 
+// The tail tiles of a TailSplit launch: sum of the K slices in slice order + the EPI_PLAIN epilogue (bias, pre-activation
+// copy, GELU / GELU', residual, column sums).  One workgroup per (tail tile, band of 32 rows); thread (erow = tid >> 5,
+// ec4 = tid & 31) owns 4 columns of rows erow + 8 it.  N % 128 == 0 (the host only splits then), M may end inside a tile.
+__global__ __launch_bounds__(256) void tile_tail_fixup_kernel(GemmArgs a, TailSplit ts, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float ct[8 * TN];
+    const int tid = threadIdx.x, ec4 = tid & 31, erow = tid >> 5;
+    const int t = blockIdx.x >> 2, band = blockIdx.x & 3;
+    const int tile = ts.n_whole + t;
+    const int m0 = (tile / tiles_n) * TM + band * 32, n0 = (tile % tiles_n) * TN, en = n0 + 4 * ec4;
+    const float* slab = ts.ws + (int64_t)t * ts.split * TM * TN + (band * 32 + erow) * TN + 4 * ec4;
+    const f32x4 bias4 = a.bias ? ld4(a.bias + en) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int m = m0 + erow + 8 * it;
+        if (m >= a.M) break;
+        f32x4 v = ld4(slab + it * 8 * TN);
+        for (int c = 1; c < ts.split; ++c) v += ld4(slab + (int64_t)c * TM * TN + it * 8 * TN);
+        v += bias4;
+        if (a.aux) st4(a.aux + (int64_t)m * a.ldx + en, v);
+        if (a.act == VH_ACT_GELU_ERF) {
+            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+        }
+        if (a.act == VH_ACT_GELU_BWD) {
+            const f32x4 p = ld4(a.res + (int64_t)m * a.ldr + en);
+            v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+        } else if (a.res) {
+            v += ld4(a.res + (int64_t)m * a.ldr + en);
+        }
+        st4(a.out + (int64_t)m * a.ldo + en, v);
+        csum += v;
+    }
+    if (a.colsum) {
+        st4(ct + erow * TN + 4 * ec4, csum);
+        __syncthreads();
+        if (tid < TN) {
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) s += ct[r * TN + tid];
+            atomicAdd(a.colsum + n0 + tid, s);
+        }
+    }
+}
+
+// K slices per tail tile (0 = no tail split) and the number of whole tiles in front of them
+static int tail_plan(int M, int N, int K, int* n_whole) {
+    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    const int r = tiles % 256;
+    *n_whole = tiles;
+    if (tiles < 256 || r == 0 || r > 128 || N % TN != 0 || K % TK != 0 || vh_tuning(VH_TUNE_TAIL_SPLIT) == 1) return 0;
+    int split = min(8, 256 / r);
+    while (split >= 2 && (K % (split * TK) != 0 || K / split < 128)) --split;
+    if (split < 2) return 0;
+    *n_whole = tiles - r;
+    return split;
+}
+
+extern "C" size_t vh_linear_ex_ws_bytes(int M, int N, int K) {
+    int n_whole;
+    const int split = tail_plan(M, N, K, &n_whole);
+    const int tiles = ((M + TM - 1) / TM) * ((N + TN - 1) / TN);
+    return split ? (size_t)(tiles - n_whole) * split * TM * TN * sizeof(float) : 0;
+}
+
 static int splitk_plan(int M, int N, int K) {
     // number of K slices (0 = do not split)
     if (M > 64) {
@@ -1110,7 +1196,8 @@ static int check_gemm(const char* name, const GemmArgs& a, const LnFuse& ln) {
 #define SKINNY_ARGS(g) (g).A, (g).W, (g).lda, (g).K, (g).k_len, (g).M, (g).N
 
 template <int EPI>
-static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s) {
+static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, float* tail_ws = nullptr,
+                       size_t tail_ws_bytes = 0) {
     if (a.M == 0) return VH_OK;
     const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
@@ -1196,10 +1283,21 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
     } else {
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
         // The LDS-DMA kernel needs whole 32-wide K slabs; a ragged K goes to the register-staged kernel.
-        if (a.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1)
-            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
-        else
+        if (a.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1) {
+            TailSplit ts{tm * tn, 1, a.K, nullptr};
+            if constexpr (EPI == EPI_PLAIN) {
+                int n_whole;
+                const int split = tail_ws ? tail_plan(a.M, a.N, a.K, &n_whole) : 0;
+                if (split && tail_ws_bytes >= (size_t)(tm * tn - n_whole) * split * TM * TN * sizeof(float))
+                    ts = TailSplit{n_whole, split, a.K / split, tail_ws};
+            }
+            const int tail = tm * tn - ts.n_whole;
+            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(ts.n_whole + tail * ts.split), dim3(256), 0, s, a, tm, tn,
+                               ts);
+            if (tail) hipLaunchKernelGGL(tile_tail_fixup_kernel, dim3(tail * 4), dim3(256), 0, s, a, ts, tn);
+        } else {
             hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
+        }
     }
     VH_CHECK_LAUNCH(name);
     return VH_OK;
@@ -1222,7 +1320,7 @@ extern "C" int vh_linear(const float* A, int lda, const float* W, const float* b
 
 extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual,
                             int ldr, float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K,
-                            int act, void* stream) {
+                            int act, void* workspace, size_t workspace_bytes, void* stream) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
     a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K; a.aux = pre_out; a.ldx = ldp;
@@ -1235,8 +1333,9 @@ extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float
                "vh_linear_ex: VH_ACT_GELU_BWD takes the saved pre-activation as `residual`, no bias, no pre_out");
     VH_REQUIRE(ldo >= N && (!residual || ldr >= N) && (!pre_out || (ldp >= N && ldp % 4 == 0 && vh_aligned16(pre_out))),
                VH_EINVAL, "vh_linear_ex: ldo/ldr/ldp");
+    VH_REQUIRE(vh_aligned16(workspace), VH_EALIGN, "vh_linear_ex: workspace must be 16-byte aligned");
     if (int rc = check_gemm("vh_linear_ex", a, ln)) return rc;
-    return launch_gemm<EPI_PLAIN>("vh_linear_ex", a, ln, (hipStream_t)stream);
+    return launch_gemm<EPI_PLAIN>("vh_linear_ex", a, ln, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }
 
 extern "C" int vh_linear_qkv(const float* A, int lda, const float* Wqkv, float* q_out, int ldq,
@@ -1394,7 +1493,8 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
     if (M > 64) {                                 // tile kernel, K slices in gridDim.y
         const int tm = (M + TM - 1) / TM, tn = (N + TN - 1) / TN;
         if (part.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1)
-            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
+            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn,
+                               TailSplit{tm * tn, 1, part.k_len, nullptr});
         else
             hipLaunchKernelGGL((gemm_tile_kernel<EPI_PARTIAL>), dim3(tm * tn, splits), dim3(256), 0, s, part, tm, tn);
         const int items_t = M * (lds_ / 4);

@@ -356,6 +356,22 @@ def pad32(n):
     return (n + 31) // 32 * 32
 
 
+_TAIL_WS = {}
+
+
+def _tail_ws(device, stream_handle, M, N, K):
+    """Workspace of vh_linear_ex's tail split (K slices of the tiles beyond the last multiple of 256; <= 16 MiB), one per
+    (device, stream): launches of one stream run in order, so they can share it."""
+    need = _lib.lib().vh_linear_ex_ws_bytes(M, N, K)
+    if not need:
+        return None
+    key = (device.index, stream_handle)
+    ws = _TAIL_WS.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = _TAIL_WS[key] = torch.empty(max(need, 1 << 24) // 4, device=device, dtype=torch.float32)
+    return ws
+
+
 def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None, colsum=None):
     """vh_linear_ex: out = act(a @ w.T + bias) + residual on the tile kernels whatever M is, with the training
     epilogues (pre_out: also store the pre-activation; ACT_GELU_BWD: out = (a @ w.T) * gelu'(residual)).
@@ -373,12 +389,15 @@ def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NO
     for t, name in ((residual, 'residual'), (pre_out, 'pre_out'), (out, 'out')):
         if t is not None and (tuple(t.shape) != (M, N) or t.stride(1) != 1):
             raise _lib.VhError(f'linear_ex: {name} must be a row-major ({M},{N}) tensor')
+    st = stream()
+    ws = _tail_ws(a.device, st, M, N, K)
     check(_lib.lib().vh_linear_ex(
         _dev_f32(a, 'a'), a.stride(0), _dev_f32(w, 'w'), ptr(bias),
         _dev_f32(residual, 'residual') if residual is not None else None,
         residual.stride(0) if residual is not None else 0, _dev_f32(out, 'out'), out.stride(0),
         _dev_f32(pre_out, 'pre_out') if pre_out is not None else None,
-        pre_out.stride(0) if pre_out is not None else 0, ptr(colsum), M, N, K, act, stream()), 'vh_linear_ex')
+        pre_out.stride(0) if pre_out is not None else 0, ptr(colsum), M, N, K, act, ptr(ws),
+        ws.numel() * 4 if ws is not None else 0, st), 'vh_linear_ex')
     return out
 
 
