@@ -160,35 +160,53 @@ struct TileEpi {
     f32x4 bias4;
 };
 
+// The epilogue operands of a tile are fetched in two parts: bias + residual rows 0..95 (EPI_EARLY of the 16 row groups)
+// right after the first operand slab is requested, the last four row groups once the K loop has issued its last MFMA
+// (tile_prefetch_late).  All 16 at the start is 68 registers held through the whole K loop on top of 64 accumulators
+// and 32 fragment registers: the allocator spilled three of them to scratch, each spill waiting for ITS load — three
+// serial memory round trips in front of every tile.
+#define EPI_EARLY 12
+
 template <int EPI>
-__device__ __forceinline__ void tile_prefetch(const GemmArgs& a, int m0, int n0, int tid, TileEpi& e) {
+__device__ __forceinline__ void tile_prefetch_rows(const GemmArgs& a, int m0, int n0, int tid, TileEpi& e, int it0, int it1) {
     const int ec4 = tid & 31, erow = tid >> 5;
     const int en = n0 + 4 * ec4;
-    e.bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (EPI != EPI_PLAIN) return;
     const bool interior = m0 + TM <= a.M && n0 + TN <= a.N;         // wave-uniform
     if (interior) {
-        if (a.bias) e.bias4 = ld4(a.bias + en);
         if (a.res) {
             const char* base = (const char*)(a.res + (int64_t)m0 * a.ldr + n0);
             const uint32_t voff = (uint32_t)(erow * a.ldr + 4 * ec4) * 4u;
 #pragma unroll
-            for (int it = 0; it < 16; ++it)
+            for (int it = it0; it < it1; ++it)
                 e.resv[it] = ld4((const float*)(base + (int64_t)it * 8 * a.ldr * 4 + voff));
         } else {
 #pragma unroll
-            for (int it = 0; it < 16; ++it) e.resv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int it = it0; it < it1; ++it) e.resv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     } else {
         const bool ecol_full = en + 3 < a.N;
-        if (a.bias && ecol_full) e.bias4 = ld4(a.bias + en);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
+        for (int it = it0; it < it1; ++it) {
             const int m = m0 + erow + 8 * it;
             e.resv[it] = (a.res && ecol_full && m < a.M) ? ld4(a.res + (int64_t)m * a.ldr + en)
                                                          : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void tile_prefetch(const GemmArgs& a, int m0, int n0, int tid, TileEpi& e) {
+    const int en = n0 + 4 * (tid & 31);
+    e.bias4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (EPI != EPI_PLAIN) return;
+    if (a.bias && en + 3 < a.N) e.bias4 = ld4(a.bias + en);
+    tile_prefetch_rows<EPI>(a, m0, n0, tid, e, 0, EPI_EARLY);
+}
+
+template <int EPI>
+__device__ __forceinline__ void tile_prefetch_late(const GemmArgs& a, int m0, int n0, int tid, TileEpi& e) {
+    if (EPI != EPI_PLAIN) return;
+    tile_prefetch_rows<EPI>(a, m0, n0, tid, e, EPI_EARLY, 16);
 }
 
 // Column sums of the tile's stored output, added to a.colsum[n0 ..]: thread (erow = tid >> 5, ec4 = tid & 31) holds the
@@ -451,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_kernel(GemmArgs a, int tiles
     for (int kt = 0; kt + 1 < nk; ++kt) kstep(kt, std::true_type{});
     kstep(nk - 1, std::false_type{});
 
+    tile_prefetch_late<EPI>(a, m0, n0, tid, epi);
     tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
 }
 
@@ -552,7 +571,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 
     TileEpi epi;                                          // residual and bias, fetched now (see tile_epilogue)
     if (!tail) tile_prefetch<EPI>(a, m0, n0, tid, epi);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0): slab 0 (and the residual prefetch) landed
+    // Slab 0 only: loads return in issue order, so with the epilogue operands requested AFTER the slab the wave may go
+    // on with those still in flight — they are 48 KB per tile against the slab's 32 KB, and waiting for them here cost
+    // the K = 512 shapes 7-12 % (bias + residual against plain).  The first K step's vmcnt(0) meets them.
+    // (the count must be exact — a larger one would let the slab's youngest load stay outstanding too)
+    const bool res_early = EPI == EPI_PLAIN && !tail && a.res && m0 + TM <= a.M && n0 + TN <= a.N;
+    if (res_early && a.bias)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | (EPI_EARLY + 1));   // vmcnt(13): bias4 + 12 residual row groups
+    else if (res_early)
+        __builtin_amdgcn_s_waitcnt(0x0F70 | EPI_EARLY);         // vmcnt(12)
+    else
+        __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
     __syncthreads();
     // Main loop.  Each K step is four groups of 16 MFMAs on one register set of fragments; the other set is
     // read from LDS four MFMAs into the group, so its latency sits under the remaining twelve.  The next
@@ -629,6 +658,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
     } else {
         kstep(kt, B0{}, std::false_type{});
     }
+    if (!tail) tile_prefetch_late<EPI>(a, m0, n0, tid, epi);   // under the last MFMAs' drain and the epilogue's LDS transpose
     __syncthreads();
 #ifdef VH_TILE_PROBE
     if (lane == 0) { tp[194] = clock64(); tp[195] = wall_clock64(); tp[196] = t_entry; }
