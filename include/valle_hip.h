@@ -124,7 +124,10 @@ int vh_linear(const float* A, int lda, const float* W, const float* bias, const 
  * slice order by a second small kernel (bitwise reproducible; no floating-point atomics).  The same
  * is done for M > 64 when the (M,N) grid has at most 256 tiles of 128x128 and K >= 1024 (one
  * utterance through the NAR stack, a short prefill): K slices in the second grid dimension of the
- * tile kernel.
+ * tile kernel.  With MORE than 256 tiles the workspace serves the tile kernel's tail split instead (the tiles
+ * beyond the last multiple of 256 as K slices + a fix-up launch when they would fill at most half of the CUs:
+ * vh_linear_ex below) — a prompt pass of 8 x 1100 positions has 276 tiles per 512-wide projection, two rounds for
+ * the work of 1.08.
  * Falls back to vh_linear when the shape does not split or workspace == NULL. */
 size_t vh_linear_ws_bytes(int M, int N, int K);
 int vh_linear_ws(const float* A, int lda, const float* W, const float* bias, const float* residual,

@@ -177,6 +177,29 @@ def test_linear_splitk_tile_path(K, M, N, K_, tile_staging):
     close(o1, K.linear(a.to(DEV), w.to(DEV), bias.to(DEV)).cpu(), atol=5e-5)
 
 
+@pytest.mark.parametrize('M,N,K_', [(9000, 512, 2048), (8800, 512, 512), (4300, 1024, 1024)])
+def test_linear_ws_tail_split(K, M, N, K_):
+    """vh_linear_ws with more than 256 tiles and a short tail (284 / 276 / 272 tiles): the tile kernel's tail split behind
+    the inference entry point (a prompt pass of 8 x 1100 positions); integer data exact, in-place residual, replays equal."""
+    from valle2_amd import _lib
+    assert _lib.lib().vh_linear_ws_bytes(M, N, K_) > 0
+    a = torch.randint(-3, 4, (M, K_), generator=g(190)).float()
+    w = torch.randint(-3, 4, (N, K_), generator=g(191)).float()
+    assert torch.equal(K.linear_ws(a.to(DEV), w.to(DEV)).cpu(), a @ w.T)
+    a = torch.randn(M, K_, generator=g(192))
+    w = torch.randn(N, K_, generator=g(193)) / K_ ** 0.5
+    bias, res = torch.randn(N, generator=g(194)), torch.randn(M, N, generator=g(195))
+    resd = res.to(DEV)
+    out = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV), resd, out=resd, act=1)      # residual aliases out
+    close(out, F.gelu(F.linear(a, w, bias)) + res, atol=5e-5)
+    o1 = K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV))
+    assert torch.equal(o1, K.linear_ws(a.to(DEV), w.to(DEV), bias.to(DEV)))
+    ref = K.linear(a.to(DEV), w.to(DEV), bias.to(DEV))                               # the unsplit launch
+    whole = (M + 127) // 128 * (N // 128) // 256 * 256 // (N // 128) * 128
+    assert torch.equal(o1[:whole], ref[:whole])
+    close(o1[whole:], ref[whole:].cpu(), atol=5e-5)
+
+
 @pytest.mark.parametrize('M', [7, 32, 200])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_epilogues(K, M, act):

@@ -1193,7 +1193,8 @@ static int splitk_plan(int M, int N, int K) {
 
 extern "C" size_t vh_linear_ws_bytes(int M, int N, int K) {
     const int splits = splitk_plan(M, N, K);
-    return splits ? (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float) : 0;
+    if (splits) return (size_t)splits * M * ((N + 3) / 4 * 4) * sizeof(float);
+    return M > 64 ? vh_linear_ex_ws_bytes(M, N, K) : 0;      // the tile kernel's tail split (see TailSplit)
 }
 
 // =============================================================================================
@@ -1497,6 +1498,9 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
                             const float* residual, int ldr, float* out, int ldo, int M, int N, int K,
                             int act, void* workspace, size_t workspace_bytes, void* stream) {
     const int splits = splitk_plan(M, N, K);
+    if (!splits && workspace && M > 64 && vh_linear_ex_ws_bytes(M, N, K))   // many tiles with a short tail: split the tail
+        return vh_linear_ex(A, lda, W, bias, residual, ldr, out, ldo, nullptr, 0, nullptr, M, N, K, act, workspace,
+                            workspace_bytes, stream);
     if (!splits || !workspace)
         return vh_linear(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, act, nullptr, nullptr,
                          nullptr, nullptr, 0.f, stream);

@@ -142,7 +142,6 @@ class ForwardScratch:
         L = _lib.lib()
         self.ws_bytes = max(L.vh_linear_ws_bytes(rows, d, d), L.vh_linear_ws_bytes(rows, d, dff),
                             L.vh_linear_ws_bytes(rows, dff, d))
-        # zeroed once: its head holds the arrival counters of the single-launch split-K (include/valle_hip.h)
         self.ws = torch.zeros(self.ws_bytes // 4, device=device, dtype=torch.float32) if self.ws_bytes else None
 
 
