@@ -200,6 +200,42 @@ def test_linear_ws_tail_split(K, M, N, K_):
     close(o1[whole:], ref[whole:].cpu(), atol=5e-5)
 
 
+@pytest.mark.parametrize('seed', range(24))
+def test_linear_dispatch_sweep(K, seed):
+    """Seeded random shapes across every dispatch boundary of the GEMM entry points (skinny <= 64 rows / tile kernel,
+    split-K of few tiles, the tail split beyond a multiple of 256 tiles, ragged N, K a multiple of 16 but not of 32 ->
+    register-staged tile kernel): vh_linear, vh_linear_ws and vh_linear_ex with random epilogues against torch; integer
+    operands first (sums exact in fp32, so any dropped or doubled K slice shows), then real data."""
+    import random
+    from valle2_amd import _lib
+    rnd = random.Random(1000 + seed)
+    M = rnd.choice([1, 5, 16, 33, 64, 65, 127, 300, 1000, 2049, 4300, 8800, 9001, 10240, 12000])
+    N = rnd.choice([64, 128, 512, 1024, 1025, 1536, 2048]) if M < 9000 else rnd.choice([512, 1024])
+    K_ = rnd.choice([128, 256, 512, 1024, 2048, 48, 1008])
+    use_bias, use_res, act = rnd.random() < 0.7, rnd.random() < 0.6, rnd.choice([0, 1])
+    a = torch.randint(-2, 3, (M, K_), generator=g(seed)).float()
+    w = torch.randint(-2, 3, (N, K_), generator=g(seed + 50)).float()
+    ad, wd = a.to(DEV), w.to(DEV)
+    ref = a @ w.T
+    assert torch.equal(K.linear(ad, wd).cpu(), ref)
+    assert torch.equal(K.linear_ws(ad, wd).cpu(), ref)
+    assert torch.equal(K.linear_ex(ad, wd).cpu(), ref)
+    a = torch.randn(M, K_, generator=g(seed + 100))
+    w = torch.randn(N, K_, generator=g(seed + 150)) / K_ ** 0.5
+    bias = torch.randn(N, generator=g(seed + 200)) if use_bias else None
+    res = torch.randn(M, N, generator=g(seed + 250)) if use_res else None
+    ref = F.linear(a, w, bias)
+    ref = (F.gelu(ref) if act else ref) + (res if use_res else 0)
+    dv = lambda t: None if t is None else t.to(DEV)
+    resd = None
+    if use_res:                                             # rows 16-byte aligned (the boundary's contract): pad N = 1025
+        resd = torch.zeros(M, (N + 3) // 4 * 4, device=DEV)[:, :N]
+        resd.copy_(res)
+    for fn in (K.linear, K.linear_ws, K.linear_ex):
+        out = fn(a.to(DEV), w.to(DEV), bias=dv(bias), residual=resd, act=act)
+        close(out, ref, atol=6e-5)
+
+
 @pytest.mark.parametrize('M', [7, 32, 200])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_epilogues(K, M, act):
