@@ -71,6 +71,7 @@ def parse():
     ap.add_argument('--no-beams', action='store_true')
     ap.add_argument('--no-config5', action='store_true')
     ap.add_argument('--no-perf-mode', action='store_true')
+    ap.add_argument('--no-rows64', action='store_true')
     ap.add_argument('--no-traffic', action='store_true', help='do not start the rocprofv3 --pmc child processes')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)   # one generate, nothing else
     ap.add_argument('--extras-deadline', type=float, default=600.0,
@@ -592,6 +593,37 @@ def main():
             'algorithmic_bytes_total': dec_bytes_p, 'achieved': gbs_p, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s',
             'frac': gbs_p / HBM_PEAK_GBS, 'vs_f32_headline': (rows * new / dtp) / (value / world),
             'greedy_tokens_equal_to_f32_run': float((out_p == out).float().mean())}
+
+    if rank == 0 and world == 1 and not args.no_rows64 and not args.small:
+        # A LABELLED SECONDARY line: the same fp32 generate with TWICE the rows BASELINE.json names (64 distinct utterances,
+        # the most one decode launch serves).  The GEMM chain of a decode step costs per step, not per row, so the whole
+        # step's HBM fraction rises with the rows: what the 32-row step lacks to north_star's 50 % is not in the kernels.
+        log('rows64: the same generate with 64 distinct utterances')
+        utts64 = [synth.synth_utterance(cfg, text // 2, text - text // 2, frames, seed=1234 + u) for u in range(2 * rows)]
+        texts64 = [torch.cat([u[0], u[2]]).to(dev) for u in utts64]
+        firsts64 = [u[1][:, 0].to(dev) for u in utts64]
+        model.generate_batch(texts64, firsts64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            out64 = model.generate_batch(texts64, firsts64)
+        torch.cuda.synchronize()
+        dt64 = (time.perf_counter() - t0) / reps
+        st64 = model.last_generate_stats
+        bytes64 = 4.0 * sum(cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
+                            + 2 * cfg.num_layers * 2 * rows * (st64['s0'] + t) * cfg.d_model
+                            + 2 * cfg.num_layers * 2 * rows * cfg.d_model for t in range(1, new))
+        gbs64 = bytes64 / (st64['decode_ms'] * 1e-3) / 1e9
+        result['rows64'] = {
+            'label': 'SECONDARY, not the metric: configs[1] with 64 rows instead of 32 (fp32, same prompt and new tokens)',
+            'rows': 2 * rows, 'value': 2 * rows * new / dt64, 'unit': 'tokens/s', 'ms_per_generate': dt64 * 1e3,
+            'prefill_ms': st64['prefill_ms'], 'decode_ms_per_step': st64['decode_ms'] / (new - 1),
+            'algorithmic_bytes_total': bytes64, 'achieved': gbs64, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s',
+            'frac': gbs64 / HBM_PEAK_GBS, 'vs_32_rows': (2 * rows * new / dt64) / (value / world),
+            'first_32_rows_equal_to_headline_run': bool((out64[:rows] == out).all())}
+        del utts64, texts64, firsts64, out64
+        torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_config5 and not args.small:
         result['config5'] = config5_leg(dev)
