@@ -211,7 +211,7 @@ class ValleAR(_Base):
         ragged = len(set(txs)) > 1 or len(set(pls)) > 1
         tx_max, pl_max = max(txs), max(pls)
         s0 = max(t + p for t, p in zip(txs, pls))                           # longest row's context
-        s_max = (s0 + max_new + 31) // 32 * 32          # whole 32-key chunks per (row, head) block (vh_attn_decode_pipe)
+        s_max = (s0 + max_new + 31) // 32 * 32          # whole 32-key chunks per (row, head) block (the ring kernel reads ahead in chunks of 32 keys)
         if pl_max + max_new > self.audio_position_emb.pe.shape[0] or tx_max > self.tokens_position_emb.pe.shape[0]:
             raise _lib.VhError('sequence exceeds the positional table (max_len 5000)')
         codes = torch.full((B, pl_max + max_new), self.eos_token, device=dev, dtype=torch.int64)
