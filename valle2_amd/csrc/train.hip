@@ -56,16 +56,20 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(
             rn[i] = (dres && c < d) ? ld4(dres + o + c) : z;
         }
     };
-    if (wid < rows) load_row(wid);
+    // (d_model <= 512 only: at NV >= 4 the second set of three rows does not fit beside the nine per-column accumulators
+    // — the allocator spilled 16..700 registers to scratch — so the wide shapes fetch each row when they get to it)
+    constexpr bool AHEAD = NV <= 2;
+    if (AHEAD && wid < rows) load_row(wid);
     for (int row = wid; row < rows; row += nw) {
         f32x4 v[NV], g[NV], r[NV];
         float sum = 0.f;
+        if (!AHEAD) load_row(row);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             v[i] = vn[i]; g[i] = gn[i]; r[i] = rn[i];
             sum += hsum4(v[i]);
         }
-        if (row + nw < rows) load_row(row + nw);
+        if (AHEAD && row + nw < rows) load_row(row + nw);
         const float mu = wave_sum(sum) / (float)d;
         float ss = 0.f;
 #pragma unroll
