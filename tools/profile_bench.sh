@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd $R
 timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-P="--no-cpu-baseline --no-traffic --no-config5 --no-beams --no-perf-mode"
+P="--no-cpu-baseline --no-traffic --no-config5 --no-beams --no-perf-mode --no-rows64"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats --output-format csv -- python3 $R/bench.py $P > $OUT/bench_under_rocprof.json 2> $OUT/stats.err
 python3 $R/tools/summarize_prof.py $OUT/stats $OUT/kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 bench.py $P"
 Q="--steps 1 --warmup 0 --no-nar --no-roofline --no-train $P"
@@ -18,8 +18,12 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o pmc
 python3 $R/tools/summarize_prof.py $OUT/fetch $OUT/pmc_fetch_size.md "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python3 bench.py $Q"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o pmc --output-format csv -- python3 $R/bench.py $Q > $OUT/write.json 2> $OUT/write.err
 python3 $R/tools/summarize_prof.py $OUT/write $OUT/pmc_write_size.md "rocprofv3 --kernel-trace --pmc WRITE_SIZE -- python3 bench.py $Q"
+# MFMA pipe utilisation of the MFMA-bound kernels (prompt pass, NAR stage): one counter pass, kernel trace only
+U="--steps 1 --warmup 0 --no-roofline --no-train $P --no-rows64"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o pmc --output-format csv -- python3 $R/bench.py $U > $OUT/mfma.json 2> $OUT/mfma.err
+python3 $R/tools/summarize_prof.py $OUT/mfma $OUT/pmc_mfma_busy.md "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py $U"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/train -o t --output-format csv -- python3 $R/tools/bench_train.py steps=4 > $OUT/train.log 2> $OUT/train.err
 python3 $R/tools/summarize_prof.py $OUT/train $OUT/train_kernel_stats.md "rocprofv3 --kernel-trace --stats -- python3 tools/bench_train.py steps=4 (7 AR + 7 NAR steps of configs[3])"
 timeout -k 10 300 rocprofv3 --kernel-trace -d $OUT/tt -o t --output-format csv -- python3 $R/tools/train_trace.py run > $OUT/tt.log 2> $OUT/tt.err
 python3 $R/tools/train_trace.py report $OUT/tt > $OUT/train_trace.md
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/train $OUT/tt
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/train $OUT/tt

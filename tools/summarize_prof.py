@@ -54,6 +54,22 @@ def main(src, dst, title=''):
         for k, v in sorted(agg.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2]))[:120]:
             out.append(f'| {k[0]} | {k[1]} | {k[2]} | {len(v)} | {sum(v) / len(v):.1f} | {min(v):.1f} | {max(v):.1f} |')
         out.append('')
+        # derived: MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over the 1024 SIMDs) over the
+        # dispatch's shader cycles (GRBM_GUI_ACTIVE is summed over the 8 XCDs) x 1024 SIMDs — MI355X_MICROARCH.md
+        util = []
+        for (kern, grid, name), v in agg.items():
+            if name != 'SQ_VALU_MFMA_BUSY_CYCLES':
+                continue
+            act = agg.get((kern, grid, 'GRBM_GUI_ACTIVE'))
+            if act and sum(act) > 0 and sum(v) > 0:
+                cyc = sum(act) / len(act) / 8.0
+                util.append((sum(v) / len(v) / (cyc * 1024.0), kern, grid, len(v), cyc))
+        if util:
+            out += ['## MFMA pipe utilisation per kernel (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs))', '',
+                    '| kernel | grid | dispatches | shader cycles per dispatch | MFMA busy |', '|---|---|---|---|---|']
+            for u, kern, grid, n, cyc in sorted(util, reverse=True):
+                out.append(f'| {kern} | {grid} | {n} | {cyc:.0f} | {100 * u:.1f} % |')
+            out.append('')
     open(dst, 'w').write('\n'.join(out) + '\n')
     print(f'wrote {dst}')
 
