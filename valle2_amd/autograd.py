@@ -389,7 +389,7 @@ class EncoderLayerFn(torch.autograd.Function):
         lse2 = torch.empty(B, n_heads, T, device=dev, dtype=torch.float32)
         kernels.attn_rows(q, k, v, a, B, n_heads, T, T, lse2=lse2, **spec)
         xm = torch.empty_like(x)
-        kernels.linear(a, wo.detach(), bo.detach(), residual=x, out=xm)
+        kernels.linear_ex(a, wo.detach(), bias=bo.detach(), residual=x, out=xm)    # (tile kernel with the tail split)
         xn2 = kernels.layernorm(xm, g2.detach(), be2.detach(), ada_scale=det(s2), ada_shift=det(t2), eps=eps)
         pre = torch.empty(B * T, w1.shape[0], device=dev, dtype=torch.float32)
         hid = torch.empty_like(pre)
