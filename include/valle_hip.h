@@ -76,7 +76,8 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
                                        the operand fragments (no second read of the rows), 1 = from their own row loads */
        VH_TUNE_TAIL_SPLIT = 10,     /* vh_linear_ex with a workspace: 0 (default) = the tiles beyond the last multiple of 256 are
                                        computed as K slices + a fix-up launch when they would fill <= half of the CUs, 1 = never */
-       VH_TUNE_COUNT = 11 };
+       VH_TUNE_TN_WGS = 11,         /* vh_gemm_tn: workgroups the contraction split aims at, 0 (default) = 256 (one per CU) */
+       VH_TUNE_COUNT = 12 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------

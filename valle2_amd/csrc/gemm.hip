@@ -1773,7 +1773,11 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 static int tn_plan(int M, int NI, int NJ) {
     const int tiles = ((NI + TM - 1) / TM) * ((NJ + TN - 1) / TN);
     const int slabs = (M + TK - 1) / TK;
-    int splits = 512 / tiles;                              // two workgroups per CU
+    // one workgroup per CU: a lone workgroup already runs its MFMA stream at 94 % of what two resident ones reach
+    // together, and half the slices are half the slab traffic (tools/ab_tn_split.py: 512 -> 256 workgroups is equal on
+    // the 64-tile weights and 5-6 % faster on the 16- and 48-tile ones at 16 k contraction rows)
+    const int wgs = vh_tuning(VH_TUNE_TN_WGS) > 0 ? vh_tuning(VH_TUNE_TN_WGS) : 256;
+    int splits = wgs / tiles;
     if (splits > slabs / 8) splits = slabs / 8;            // at least 8 slabs (256 rows) per slice
     if (splits > 64) splits = 64;
     return splits < 1 ? 1 : splits;
