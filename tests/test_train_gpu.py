@@ -102,6 +102,22 @@ def test_embedding_backward_and_colsum():
     out.backward(dy.to(DEV))
     for a, b in zip(dt, tabs):
         close(a.grad, b.grad, atol=1e-5)
+    # a padded batch: every row ends in a run of ONE id (the kernel adds such runs up before its atomic), 512 columns,
+    # a length that is not a multiple of the 32 positions a workgroup walks
+    d, T = 512, 107
+    tab = torch.randn(40, d, generator=g(33)).requires_grad_()
+    ids = torch.randint(0, 40, (3, T, 1), generator=g(34))
+    for b, n_real in enumerate((107, 60, 1)):
+        ids[b, n_real:] = 39
+    pe = sinusoid_table(d, 128)
+    dy = torch.randn(3, T, d, generator=g(35))
+    ref = F.embedding(ids[..., 0], tab) + pe[:T, 0]
+    ref.backward(dy)
+    td = tab.detach().to(DEV).requires_grad_()
+    out = A.EmbedSumPeFn.apply(ids.to(DEV), pe.to(DEV), 0, td)
+    close(out, ref)
+    out.backward(dy.to(DEV))
+    close(td.grad, tab.grad, atol=2e-5)
 
 
 @pytest.mark.parametrize('mode', ['prefix', 'full'])

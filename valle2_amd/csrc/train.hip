@@ -341,23 +341,52 @@ extern "C" int vh_cross_entropy(const float* logits, int ld, int V, const int64_
 // ---------------------------------------------------------------------------------------------
 // Embedding backward: dtable[ids[b,t]] += dout[b, t0+t, :]   (scatter-add, fp32 atomics)
 // ---------------------------------------------------------------------------------------------
+// A workgroup owns EMB_RUN consecutive positions of one batch row and a thread owns columns: it walks the positions and
+// adds up consecutive ones that hit the SAME table row before issuing the atomic.  A padded batch ends every row in a
+// run of one id (a third of configs[3]'s positions): per-position atomics put thousands of adds on that one table row
+// and ran at the contended-atomic rate (157 us per AR step for 8.4 M adds); runs collapse 16:1 here.
+#define EMB_RUN 16
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, int64_t ids_bs,
                                                         int64_t ids_ts, const float* __restrict__ dout,
                                                         int64_t dout_bs, int t0, float* __restrict__ dtable,
                                                         int vocab, int T, int d,
                                                         int32_t* __restrict__ err_flag) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int b = blockIdx.y;
-    if (t >= T) return;
-    const int64_t id = ids[b * ids_bs + t * ids_ts];
-    if (id < 0 || id >= vocab) {                    // never scatter outside the table
-        if (err_flag && lane == 0) atomicOr(err_flag, VH_DEVERR_EMBED_ID);
-        return;
+    __shared__ int sid[EMB_RUN];                                     // the run's table rows, -1 = skip (bad id / beyond T)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int t_begin = blockIdx.x * EMB_RUN;
+    if (tid < EMB_RUN) {
+        const int t = t_begin + tid;
+        int64_t id = -1;
+        if (t < T) {
+            id = ids[b * ids_bs + t * ids_ts];
+            if (id < 0 || id >= vocab) {                             // never scatter outside the table
+                if (err_flag) atomicOr(err_flag, VH_DEVERR_EMBED_ID);
+                id = -1;
+            }
+        }
+        sid[tid] = (int)id;
     }
-    const float* src = dout + b * dout_bs + (int64_t)(t0 + t) * d;
-    float* dst = dtable + id * d;
-    for (int c = lane; c < d; c += 64) atomicAdd(dst + c, src[c]);
+    __syncthreads();
+    const float* src = dout + b * dout_bs + (int64_t)(t0 + t_begin) * d;
+    for (int c = tid; c < d; c += 256) {
+        float v[EMB_RUN];
+#pragma unroll
+        for (int i = 0; i < EMB_RUN; ++i) v[i] = sid[i] >= 0 ? src[(int64_t)i * d + c] : 0.f;   // all in flight at once
+        int cur = -1;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < EMB_RUN; ++i) {
+            const int id = sid[i];
+            if (id != cur) {
+                if (cur >= 0) atomicAdd(dtable + (int64_t)cur * d + c, acc);
+                cur = id;
+                acc = v[i];
+            } else {
+                acc += v[i];
+            }
+        }
+        if (cur >= 0) atomicAdd(dtable + (int64_t)cur * d + c, acc);
+    }
 }
 
 extern "C" int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
@@ -366,7 +395,7 @@ extern "C" int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids
     VH_REQUIRE(ids && dout && dtable && vocab > 0 && B >= 0 && T >= 0 && d > 0, VH_EINVAL,
                "vh_embed_bwd: bad args");
     if (B == 0 || T == 0) return VH_OK;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, ids,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + EMB_RUN - 1) / EMB_RUN, B), dim3(256), 0, (hipStream_t)stream, ids,
                        ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, vocab, T, d, err_flag);
     VH_CHECK_LAUNCH("vh_embed_bwd");
     return VH_OK;
