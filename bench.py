@@ -256,12 +256,49 @@ def config5_leg(dev):
     gbs = dec_bytes / (st['decode_ms'] * 1e-3) / 1e9
     del m
     torch.cuda.empty_cache()
-    return {'workload': 'configs[4] AR leg: 24L/1024d/h16/dff4096 greedy generate_batch, 8 rows, 400 text + BOS + 2250 '
-                        'codec tokens -> 256 new tokens (context 2651..2907), fp32',
-            'value': rows * new / dt, 'unit': 'tokens/s', 'ms_per_generate': dt * 1e3, 'prefill_ms': st['prefill_ms'],
-            'decode_ms_per_step': st['decode_ms'] / (new - 1), 'algorithmic_bytes_total': dec_bytes,
-            'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
-            'n_split': st['n_split']}
+    res = {'workload': 'configs[4] AR leg: 24L/1024d/h16/dff4096 greedy generate_batch, 8 rows, 400 text + BOS + 2250 '
+                       'codec tokens -> 256 new tokens (context 2651..2907), fp32',
+           'value': rows * new / dt, 'unit': 'tokens/s', 'ms_per_generate': dt * 1e3, 'prefill_ms': st['prefill_ms'],
+           'decode_ms_per_step': st['decode_ms'] / (new - 1), 'algorithmic_bytes_total': dec_bytes,
+           'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'bound': 'hbm',
+           'n_split': st['n_split']}
+    # ---- NAR leg of the same configuration: the 7 remaining codebooks of a whole 30 s utterance per row (valle_nar.py:107-165):
+    # 400 text + 225-frame acoustic prompt + 2250 target frames = 2875 positions per row, one 24-layer forward per stage
+    log('config5: 24L/1024d NAR, 7 stages over 8 x 2875 positions')
+    prompt_frames, target = 225, 2250
+    ncfg = ConfigValle(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0,
+                       norm='AdaptiveLayerNorm')
+    nsd = synth.make_state_dict(ncfg, 'ValleNAR', seed=0, rich=True)
+    nar = get_model_class('ValleNAR')(ncfg)
+    nar.load_state_dict(nsd)
+    nar = nar.to(dev).eval()
+    g = torch.Generator().manual_seed(11)
+    n_texts = [torch.randint(0, ncfg.vocab_size, (text,), generator=g).to(dev) for _ in range(rows)]
+    n_prompts = [torch.randint(0, ncfg.num_audio_tokens, (prompt_frames, ncfg.num_quantizers), generator=g).to(dev)
+                 for _ in range(rows)]
+    n_firsts = [torch.randint(0, ncfg.num_audio_tokens, (target,), generator=g).to(dev) for _ in range(rows)]
+    nar.generate_batch(n_texts, n_prompts, n_firsts, greedy=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    codes = nar.generate_batch(n_texts, n_prompts, n_firsts, greedy=True)
+    torch.cuda.synchronize()
+    dtn = time.perf_counter() - t0
+    assert len(codes) == rows and tuple(codes[0].shape) == (target, ncfg.num_quantizers)
+    stages = ncfg.num_quantizers - 1
+    pos = text + prompt_frames + target
+    flop = stages * (2.0 * L * l_pl * rows * pos + 4.0 * d * pos * pos * L * rows
+                     + 2.0 * d * ncfg.num_audio_tokens * rows * target)
+    res['nar'] = {'workload': 'configs[4] NAR leg: 24L/1024d AdaLN stack, 8 rows x (400 text + 225-frame prompt + 2250 target '
+                              'frames), codebooks 2..8 (7 stages, greedy), fp32',
+                  'ms_total': dtn * 1e3, 'ms_per_stage': dtn * 1e3 / stages,
+                  'value': rows * target * stages / dtn, 'unit': 'codec tokens/s',
+                  'flop': flop, 'tflops': flop / dtn / 1e12, 'peak_tflops': MFMA_F32_PEAK_TF,
+                  'frac': flop / dtn / 1e12 / MFMA_F32_PEAK_TF, 'bound': 'mfma'}
+    res['joint_note'] = ('a whole 30 s utterance needs 2250 AR steps (first codebook; the step above is the LAST 256 of them, '
+                         'where the K/V stream is longest) and then the NAR leg')
+    del nar
+    torch.cuda.empty_cache()
+    return res
 
 
 def spawn_ranks(n):
