@@ -369,6 +369,7 @@ def _tail_ws(device, stream_handle, M, N, K):
     ws = _TAIL_WS.get(key)
     if ws is None or ws.numel() * 4 < need:
         if len(_TAIL_WS) >= 8:                       # streams come and go: keep the most recent few (16 MiB each)
+            torch.cuda.synchronize(device)           # (rare: nothing in flight may still be writing the one let go)
             _TAIL_WS.pop(next(iter(_TAIL_WS)))
         ws = _TAIL_WS[key] = torch.empty(max(need, 1 << 24) // 4, device=device, dtype=torch.float32)
     return ws
