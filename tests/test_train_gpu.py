@@ -120,6 +120,29 @@ def test_embedding_backward_and_colsum():
     close(td.grad, tab.grad, atol=2e-5)
 
 
+@pytest.mark.parametrize('n,N,K_', [(5, 256, 128), (24, 1024, 512), (3, 200, 1024)])
+def test_adaproj_forward_backward(n, N, K_):
+    """AdaProjFn (every AdaptiveLayerNorm project_layer of a stack in one launch each way) against nn.Linear: outputs,
+    weight / bias gradients (outer products) and the gradient of the shared stage embedding (every (layer, row block)
+    adds onto the same K addresses: reduced over the workgroup's waves before the atomics)."""
+    from valle2_amd import autograd as A
+    emb = torch.randn(1, K_, generator=g(70)).requires_grad_()
+    ws = [(0.1 * torch.randn(N, K_, generator=g(71 + i))).requires_grad_() for i in range(n)]
+    bs = [torch.randn(N, generator=g(171 + i)).requires_grad_() for i in range(n)]
+    dout = torch.randn(n, N, generator=g(72))
+    ref = torch.cat([F.linear(emb, w, b) for w, b in zip(ws, bs)])
+    ref.backward(dout)
+    ed = emb.detach().to(DEV).requires_grad_()
+    pd = [t.detach().to(DEV).requires_grad_() for pair in zip(ws, bs) for t in pair]
+    out = A.AdaProjFn.apply(ed, *pd)
+    close(out, ref, atol=2e-5)
+    out.backward(dout.to(DEV))
+    close(ed.grad, emb.grad, atol=1e-4, rtol=1e-4)
+    for i in range(n):
+        close(pd[2 * i].grad, ws[i].grad, atol=1e-6)
+        close(pd[2 * i + 1].grad, bs[i].grad, atol=1e-6)
+
+
 @pytest.mark.parametrize('mode', ['prefix', 'full'])
 def test_qkv_attention_backward(mode):
     from oracle.valle_oracle import build_attn_mask

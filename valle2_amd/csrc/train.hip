@@ -573,13 +573,14 @@ __global__ __launch_bounds__(256) void adaproj_fwd_kernel(const vh_adaproj_item*
     }
 }
 
+#define ADA_ROWS 16     // output rows per wave
 template <int NV>
 __global__ __launch_bounds__(256) void adaproj_bwd_kernel(const vh_adaproj_item* __restrict__ items,
                                                           const float* __restrict__ emb, const float* __restrict__ dout,
                                                           float* __restrict__ demb, int N, int K) {
-    const int lane = threadIdx.x & 63, item = blockIdx.y;
-    const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
-    if (n0 >= N) return;
+    __shared__ __attribute__((aligned(16))) float red[4][NV * 256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, item = blockIdx.y;
+    const int n0 = (blockIdx.x * 4 + w) * ADA_ROWS;
     const vh_adaproj_item it = items[item];
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     f32x4 e[NV], acc[NV];
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256) void adaproj_bwd_kernel(const vh_adaproj_item*
         e[i] = (lane + 64 * i) * 4 < K ? ld4(emb + (lane + 64 * i) * 4) : z;
         acc[i] = z;
     }
-    for (int n = n0; n < min(N, n0 + 8); ++n) {
+    for (int n = n0; n < min(N, n0 + ADA_ROWS); ++n) {
         const float g = dout[(int64_t)item * N + n];
         if (lane == 0 && it.db) it.db[n] = g;
 #pragma unroll
@@ -600,15 +601,14 @@ __global__ __launch_bounds__(256) void adaproj_bwd_kernel(const vh_adaproj_item*
             }
         }
     }
-    if (demb) {
+    // d emb: every (item, row block) adds a K-vector onto the SAME K addresses.  Per-wave atomics were 1.5 M adds onto
+    // 512 addresses at configs[3] (24 norms x 1024 rows) and ran at the contended-atomic rate: 317 us for a launch whose
+    // 50 MB of weight gradients need 10.  The four waves meet in LDS first and a wave covers 16 rows: 8 x fewer adds.
+    if (demb) {                                          // (uniform: every thread reaches the barrier)
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + 64 * i) * 4;
-            if (c < K) {
-                atomicAdd(demb + c, acc[i].x); atomicAdd(demb + c + 1, acc[i].y);
-                atomicAdd(demb + c + 2, acc[i].z); atomicAdd(demb + c + 3, acc[i].w);
-            }
-        }
+        for (int i = 0; i < NV; ++i) st4(&red[w][(lane + 64 * i) * 4], acc[i]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < K; c += 256) atomicAdd(demb + c, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
     }
 }
 
@@ -636,7 +636,7 @@ extern "C" int vh_adaproj_bwd(const vh_adaproj_item* items, int n, const float* 
                               int N, int K, void* stream) {
     if (int rc = adaproj_check("vh_adaproj_bwd", items, n, emb, N, K)) return rc;
     VH_REQUIRE(dout, VH_EINVAL, "vh_adaproj_bwd: null dout");
-    const dim3 grid((N + 31) / 32, n);
+    const dim3 grid((N + 4 * ADA_ROWS - 1) / (4 * ADA_ROWS), n);
     hipStream_t st = (hipStream_t)stream;
     if (K <= 256) hipLaunchKernelGGL(adaproj_bwd_kernel<1>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
     else if (K <= 512) hipLaunchKernelGGL(adaproj_bwd_kernel<2>, grid, dim3(256), 0, st, items, emb, dout, demb, N, K);
