@@ -38,7 +38,10 @@ enum { VH_OK = 0, VH_EINVAL = -1, VH_EALIGN = -2, VH_EUNSUPPORTED = -3, VH_ELAUN
 
 /* activation fused in a GEMM epilogue */
 enum { VH_ACT_NONE = 0, VH_ACT_GELU_ERF = 1,
-       VH_ACT_GELU_BWD = 2 /* vh_linear_ex only: out = acc * gelu'(residual) (backward through the activation) */ };
+       VH_ACT_GELU_BWD = 2,   /* vh_linear_ex only: out = acc * gelu'(residual) (backward through the activation) */
+       VH_ACT_GELU_ERF_D = 3, /* vh_linear_ex only: out = gelu(acc + bias), pre_out = gelu'(acc + bias) — the forward keeps
+                                 the DERIVATIVE instead of the pre-activation (erf is evaluated once for both) ... */
+       VH_ACT_MUL = 4         /* ... so that the backward is out = acc * residual[m][n], no transcendental in its epilogue */ };
 
 /* attention mask modes (analytic; no (B,h,T,T) tensor is ever materialised) */
 enum {
@@ -417,6 +420,10 @@ int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  * vh_linear_ex = vh_linear (same tile kernels, M of any size) with the two epilogues training needs:
  *   pre_out != NULL : the pre-activation acc + bias is ALSO stored to pre_out (row stride ldp) — the
  *                     forward of FeedForward.linear_1 keeps it for the GELU backward (modules.py:221);
+ *   act == VH_ACT_GELU_ERF_D (pre_out required) / VH_ACT_MUL (residual required, no bias, no pre_out): the pair the
+ *                     training step uses — forward stores gelu'(pre) in pre_out, backward multiplies by it; the
+ *                     GELU'-epilogue of VH_ACT_GELU_BWD (erf + exp on 64 values per lane and tile) held the biggest
+ *                     product of the backward at 75 % MFMA-busy against 84 % for a plain epilogue.
  *   act == VH_ACT_GELU_BWD : out = acc * gelu'(residual[m][n]) — the backward through nn.GELU fused into
  *                     the dX = dY . W product of linear_2 (residual = the saved pre-activation).
  *   dcolsum != NULL (N % 128 == 0): the column sums of `out` are ADDED to dcolsum (N floats, fp32 atomics, one per

@@ -103,6 +103,16 @@ def test_linear_ex_training_epilogues(M):
     p = ref_pre.clone().requires_grad_()
     F.gelu(p).backward(dy @ w2)
     torch.testing.assert_close(dpre.cpu(), p.grad, atol=3e-5, rtol=1e-5)
+    # the pair the training step uses: the forward keeps gelu'(pre) instead of pre, the backward multiplies by it
+    dact = torch.empty(M, dff, device=DEV)
+    hid2 = K.linear_ex(x.to(DEV), w1.to(DEV), bias=b1.to(DEV), pre_out=dact, act=K.ACT_GELU_D,
+                       out=torch.empty(M, dff, device=DEV))
+    torch.testing.assert_close(hid2.cpu(), F.gelu(ref_pre), atol=2e-5, rtol=1e-5)
+    pp = ref_pre.clone().requires_grad_()
+    F.gelu(pp).backward(torch.ones_like(pp))
+    torch.testing.assert_close(dact.cpu(), pp.grad, atol=2e-5, rtol=1e-5)
+    dpre2 = K.linear_ex(dy.to(DEV), wt, residual=dact, act=K.ACT_MUL, out=torch.empty(M, dff, device=DEV))
+    torch.testing.assert_close(dpre2.cpu(), p.grad, atol=3e-5, rtol=1e-5)
     # ragged head: K = 1025 zero-padded to 1056 on both operands
     wp = 0.05 * torch.randn(1025, d, generator=g)
     dl = torch.zeros(M, 1056)
@@ -132,10 +142,13 @@ def test_linear_ex_tail_split(M, N, Kd):
             plain = K.linear_ex(a, w, bias=b, residual=res, out=torch.empty(M, N, device=DEV), colsum=cs)
             act = K.linear_ex(a, w, bias=b, pre_out=pre, act=K.ACT_GELU, out=torch.empty(M, N, device=DEV))
             bwd = K.linear_ex(a, w, residual=ref_pre, act=K.ACT_GELU_BWD, out=torch.empty(M, N, device=DEV))
+            dact = torch.empty(M, N, device=DEV)
+            act_d = K.linear_ex(a, w, bias=b, pre_out=dact, act=K.ACT_GELU_D, out=torch.empty(M, N, device=DEV))
+            mul = K.linear_ex(a, w, residual=res, act=K.ACT_MUL, out=torch.empty(M, N, device=DEV))
         finally:
             _lib.lib().vh_set_tuning(10, 0)
-        outs[knob] = (plain, cs, pre, act, bwd)
-    plain, cs, pre, act, bwd = outs[0]
+        outs[knob] = (plain, cs, pre, act, bwd, act_d, dact, mul)
+    plain, cs, pre, act, bwd, act_d, dact, mul = outs[0]
     tol = dict(atol=5e-5, rtol=2e-5)
     torch.testing.assert_close(plain, ref_pre + res, **tol)
     torch.testing.assert_close(cs, (ref_pre + res).sum(0), atol=2e-2, rtol=1e-4)
@@ -144,6 +157,11 @@ def test_linear_ex_tail_split(M, N, Kd):
     p = ref_pre.clone().requires_grad_()
     F.gelu(p).backward(a @ w.t())
     torch.testing.assert_close(bwd, p.grad, **tol)
+    torch.testing.assert_close(act_d, F.gelu(ref_pre), **tol)
+    pg = ref_pre.clone().requires_grad_()
+    F.gelu(pg).backward(torch.ones_like(pg))
+    torch.testing.assert_close(dact, pg.grad, **tol)
+    torch.testing.assert_close(mul, (a @ w.t()) * res, atol=2e-4, rtol=2e-5)
     n_whole = ((M + 127) // 128 * (N // 128)) // 256 * 256          # whole tiles: the same kernel path, bit for bit
     rows_whole = n_whole // (N // 128) * 128
     for x, y in zip(outs[0], outs[1]):

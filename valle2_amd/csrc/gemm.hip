@@ -259,7 +259,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             f32x4 v = ld4(cr + it * 8 * LDC);
             if (EPI == EPI_PLAIN) {
                 v += e.bias4;
-                if (xbase) st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), v);   // pre-activation
+                if (a.act == VH_ACT_GELU_ERF_D) {               // GELU out, its derivative to aux (one erf for both)
+                    f32x4 dv;
+                    v = gelu_and_grad4(v, dv);
+                    st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), dv);
+                } else if (xbase) {
+                    st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), v);           // pre-activation
+                }
                 if (a.act == VH_ACT_GELU_ERF) {                 // two per instruction (packed fp32)
                     const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
                     v = f32x4{g0.x, g0.y, g1.x, g1.y};
@@ -267,6 +273,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
                 if (a.act == VH_ACT_GELU_BWD) {                 // dY through the activation: acc * gelu'(pre)
                     const f32x4 p = e.resv[it];
                     v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+                } else if (a.act == VH_ACT_MUL) {               // ... with the derivative saved by the forward
+                    v = v * e.resv[it];
                 } else {
                     v += e.resv[it];
                 }
@@ -332,13 +340,21 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             }
         } else if (ecol_full) {
             v += e.bias4;
-            if (a.aux) st4(a.aux + (int64_t)m * a.ldx + en, v);
+            if (a.act == VH_ACT_GELU_ERF_D) {
+                f32x4 dv;
+                v = gelu_and_grad4(v, dv);
+                st4(a.aux + (int64_t)m * a.ldx + en, dv);
+            } else if (a.aux) {
+                st4(a.aux + (int64_t)m * a.ldx + en, v);
+            }
             if (a.act == VH_ACT_GELU_ERF) {
                 v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
             }
             if (a.act == VH_ACT_GELU_BWD) {
                 const f32x4 p = e.resv[it];
                 v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+            } else if (a.act == VH_ACT_MUL) {
+                v = v * e.resv[it];
             } else {
                 v += e.resv[it];
             }
@@ -347,9 +363,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         } else {                                       // ragged last column group (e.g. N = 1025 logits)
             for (int j = 0; j < 4 && en + j < a.N; ++j) {
                 float sv = v[j] + (a.bias ? a.bias[en + j] : 0.f);
-                if (a.aux) a.aux[(int64_t)m * a.ldx + en + j] = sv;
+                if (a.act == VH_ACT_GELU_ERF_D) {
+                    float dv;
+                    sv = gelu_and_grad(sv, dv);
+                    a.aux[(int64_t)m * a.ldx + en + j] = dv;
+                } else if (a.aux) {
+                    a.aux[(int64_t)m * a.ldx + en + j] = sv;
+                }
                 if (a.act == VH_ACT_GELU_ERF) sv = gelu_erf(sv);
                 if (a.act == VH_ACT_GELU_BWD) sv *= gelu_grad(a.res[(int64_t)m * a.ldr + en + j]);
+                else if (a.act == VH_ACT_MUL) sv *= a.res[(int64_t)m * a.ldr + en + j];
                 else if (a.res) sv += a.res[(int64_t)m * a.ldr + en + j];
                 a.out[(int64_t)m * a.ldo + en + j] = sv;
             }
@@ -1128,13 +1151,21 @@ __global__ __launch_bounds__(256) void tile_tail_fixup_kernel(GemmArgs a, TailSp
         f32x4 v = ld4(slab + it * 8 * TN);
         for (int c = 1; c < ts.split; ++c) v += ld4(slab + (int64_t)c * TM * TN + it * 8 * TN);
         v += bias4;
-        if (a.aux) st4(a.aux + (int64_t)m * a.ldx + en, v);
+        if (a.act == VH_ACT_GELU_ERF_D) {
+            f32x4 dv;
+            v = gelu_and_grad4(v, dv);
+            st4(a.aux + (int64_t)m * a.ldx + en, dv);
+        } else if (a.aux) {
+            st4(a.aux + (int64_t)m * a.ldx + en, v);
+        }
         if (a.act == VH_ACT_GELU_ERF) {
             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
         }
         if (a.act == VH_ACT_GELU_BWD) {
             const f32x4 p = ld4(a.res + (int64_t)m * a.ldr + en);
             v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
+        } else if (a.act == VH_ACT_MUL) {
+            v = v * ld4(a.res + (int64_t)m * a.ldr + en);
         } else if (a.res) {
             v += ld4(a.res + (int64_t)m * a.ldr + en);
         }
@@ -1230,7 +1261,7 @@ template <int EPI>
 static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, float* tail_ws = nullptr,
                        size_t tail_ws_bytes = 0) {
     if (a.M == 0) return VH_OK;
-    const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act == VH_ACT_GELU_BWD;   // tile-kernel epilogues only
+    const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act >= VH_ACT_GELU_BWD;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
@@ -1358,10 +1389,12 @@ extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float
     a.colsum = dcolsum;
     VH_REQUIRE(!dcolsum || N % 128 == 0, VH_EUNSUPPORTED, "vh_linear_ex: dcolsum needs N %% 128 == 0 (N=%d)", N);
     LnFuse ln{};
-    VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF || act == VH_ACT_GELU_BWD, VH_EINVAL,
-               "vh_linear_ex: act=%d", act);
-    VH_REQUIRE(act != VH_ACT_GELU_BWD || (residual && !bias && !pre_out), VH_EINVAL,
-               "vh_linear_ex: VH_ACT_GELU_BWD takes the saved pre-activation as `residual`, no bias, no pre_out");
+    VH_REQUIRE(act >= VH_ACT_NONE && act <= VH_ACT_MUL, VH_EINVAL, "vh_linear_ex: act=%d", act);
+    VH_REQUIRE((act != VH_ACT_GELU_BWD && act != VH_ACT_MUL) || (residual && !bias && !pre_out), VH_EINVAL,
+               "vh_linear_ex: VH_ACT_GELU_BWD / VH_ACT_MUL take the saved pre-activation / derivative as `residual`, no bias, "
+               "no pre_out");
+    VH_REQUIRE(act != VH_ACT_GELU_ERF_D || (pre_out && !residual), VH_EINVAL,
+               "vh_linear_ex: VH_ACT_GELU_ERF_D stores the derivative in pre_out (required) and takes no residual");
     VH_REQUIRE(ldo >= N && (!residual || ldr >= N) && (!pre_out || (ldp >= N && ldp % 4 == 0 && vh_aligned16(pre_out))),
                VH_EINVAL, "vh_linear_ex: ldo/ldr/ldp");
     VH_REQUIRE(vh_aligned16(workspace), VH_EALIGN, "vh_linear_ex: workspace must be 16-byte aligned");

@@ -161,6 +161,22 @@ __device__ __forceinline__ float gelu_grad(float x) {
     return cdf + x * pdf;
 }
 
+// GELU and its derivative from ONE evaluation of erf (the training forward stores the derivative instead of the
+// pre-activation, so the backward's epilogue is a multiply): gelu = x Phi(x), d = Phi(x) + x phi(x).
+__device__ __forceinline__ float gelu_and_grad(float x, float& d) {
+    const float cdf = 0.5f * (1.0f + vh_erf(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    d = cdf + x * pdf;
+    return x * cdf;
+}
+
+__device__ __forceinline__ f32x4 gelu_and_grad4(f32x4 v, f32x4& d) {
+    float d0, d1, d2, d3;
+    const f32x4 g = {gelu_and_grad(v.x, d0), gelu_and_grad(v.y, d1), gelu_and_grad(v.z, d2), gelu_and_grad(v.w, d3)};
+    d = f32x4{d0, d1, d2, d3};
+    return g;
+}
+
 // LayerNorm parameters that may be fused into an operand load
 struct LnFuse {
     const float* gamma;  // (K) or nullptr → no fused LN

@@ -14,7 +14,7 @@ from . import _lib
 from ._lib import check, ptr, stream
 
 MASK_FULL, MASK_PREFIX, MASK_EXPLICIT = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_D, ACT_MUL = 0, 1, 2, 3, 4
 HEAD_DIM = 64
 
 
