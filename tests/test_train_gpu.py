@@ -120,6 +120,34 @@ def test_embedding_backward_and_colsum():
     close(td.grad, tab.grad, atol=2e-5)
 
 
+def test_embed_concat_matches_parts_and_cat():
+    """EmbedConcatFn (text | prefix frames over all codebooks | target frames over the first codebooks, one buffer, one
+    gradient per table) against F.embedding + torch.cat, forward and every table's gradient — codebook tables are read
+    by two parts."""
+    from valle2_amd import autograd as A
+    from valle2_amd.synth import sinusoid_table
+    d, B, tx, p, t, q, stage = 128, 3, 11, 7, 26, 4, 2
+    tok_tab = torch.randn(50, d, generator=g(80)).requires_grad_()
+    tabs = [torch.randn(30, d, generator=g(81 + j)).requires_grad_() for j in range(q)]
+    tokens = torch.randint(0, 50, (B, tx), generator=g(90))
+    codes = torch.randint(0, 30, (B, t, q), generator=g(91))
+    pe_t, pe_a = sinusoid_table(d, 64), sinusoid_table(d, 64)
+    dy = torch.randn(B, tx + t, d, generator=g(92))
+    ref = torch.cat([F.embedding(tokens, tok_tab) + pe_t[:tx, 0],
+                     sum(F.embedding(codes[:, :p, j], tabs[j]) for j in range(q)) + pe_a[:p, 0],
+                     sum(F.embedding(codes[:, p:, j], tabs[j]) for j in range(stage)) + pe_a[p:t, 0]], dim=1)
+    ref.backward(dy)
+    dev_tabs = [x.detach().to(DEV).requires_grad_() for x in [tok_tab] + tabs]
+    cd, td = codes.to(DEV), tokens.to(DEV)
+    spec = [(td, pe_t.to(DEV), 0, [0]), (cd[:, :p], pe_a.to(DEV), 0, list(range(1, 1 + q))),
+            (cd[:, p:], pe_a.to(DEV), p, list(range(1, 1 + stage)))]
+    out = A.EmbedConcatFn.apply(spec, *dev_tabs)
+    close(out, ref)
+    out.backward(dy.to(DEV))
+    for a, b in zip(dev_tabs, [tok_tab] + tabs):
+        close(a.grad, b.grad, atol=2e-5)
+
+
 @pytest.mark.parametrize('n,N,K_', [(5, 256, 128), (24, 1024, 512), (3, 200, 1024)])
 def test_adaproj_forward_backward(n, N, K_):
     """AdaProjFn (every AdaptiveLayerNorm project_layer of a stack in one launch each way) against nn.Linear: outputs,

@@ -277,6 +277,44 @@ class EmbedSumPeFn(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+class EmbedConcatFn(torch.autograd.Function):
+    """The model input x (B, sum T_i, d) of a training step in one buffer: part i = sum_j tables[idx][ids_i[..., j]] +
+    pe_i[pos0_i : pos0_i + T_i] is written at its row offset (what EmbedSumPeFn per part + torch.cat made with a copy
+    forward and two strided copies backward), and every table receives ONE gradient however many parts read it.
+    parts: [(ids (B, T_i) | (B, T_i, J_i), pe, pos0, [indices into `tables`, one per codebook column])]."""
+
+    @staticmethod
+    def forward(ctx, parts, *tables):
+        B = parts[0][0].shape[0]
+        d = tables[0].shape[1]
+        total = sum(p[0].shape[1] for p in parts)
+        out = torch.empty(B, total, d, device=tables[0].device, dtype=torch.float32)
+        t0, laid = 0, []
+        for ids, pe, pos0, idx in parts:
+            if ids.dim() == 2:
+                ids = ids.unsqueeze(-1)
+            kernels.embed_sum_pe(ids, [tables[j].detach() for j in idx], pe, pos0, out, out_t0=t0)
+            laid.append((ids, t0, idx))
+            t0 += ids.shape[1]
+        ctx.laid, ctx.tables = laid, tables
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        B, _, d = dout.shape
+        grads = [optim.grad_out(t, zero=True) if ctx.needs_input_grad[1 + j] else None for j, t in enumerate(ctx.tables)]
+        for ids, t0, idx in ctx.laid:
+            for col_j, j in enumerate(idx):
+                if grads[j] is None:
+                    continue
+                col = ids[..., col_j]
+                check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout), dout.stride(0), t0,
+                                              ptr(grads[j]), int(ctx.tables[j].shape[0]), B, ids.shape[1], d,
+                                              ptr(_lib.err_flag(dout.device)), stream()), 'vh_embed_bwd')
+        return (None, *grads)
+
+
 class CrossEntropyFn(torch.autograd.Function):
     """Mean cross entropy over every row of (R, V) logits against (R,) int64 targets."""
 

@@ -108,14 +108,20 @@ class ValleAR(_Base):
         codes_lens = batch['codes_lens']
         tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
         b, d = tokens.shape[0], self.config.d_model
-        xt = A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)
-        xa = A.EmbedSumPeFn.apply(codes[:, :ty], self.audio_position_emb.pe, 0, self.audio_emb.weight)
-        for mod in (self.tokens_position_emb.dropout, ):      # PE dropout p=0.1 is live in train mode (D9)
-            if mod.training and mod.p > 0:
-                xt = mod(xt)
-        if self.audio_position_emb.dropout.training and self.audio_position_emb.dropout.p > 0:
-            xa = self.audio_position_emb.dropout(xa)
-        x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
+        drops = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)   # PE dropout p=0.1 is live in train mode (D9)
+        if not any(m.training and m.p > 0 for m in drops):
+            # both embeddings written into ONE buffer (no torch.cat, no strided copies of its gradient)
+            x = A.EmbedConcatFn.apply([(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0]),
+                                       (codes[:, :ty], self.audio_position_emb.pe, 0, [1])],
+                                      self.tokens_emb.weight, self.audio_emb.weight).reshape(b * (tx + ty), d)
+        else:
+            xt = A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)
+            xa = A.EmbedSumPeFn.apply(codes[:, :ty], self.audio_position_emb.pe, 0, self.audio_emb.weight)
+            if drops[0].training and drops[0].p > 0:
+                xt = drops[0](xt)
+            if drops[1].training and drops[1].p > 0:
+                xa = drops[1](xa)
+            x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
         kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)
         spec = dict(mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
         x = A.transformer_train(self.transformer, x, b, tx + ty, spec)

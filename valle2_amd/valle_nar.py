@@ -111,16 +111,26 @@ class ValleNAR(_Base):
         b, t, q = codes.shape
         d = cfg.d_model
         p = self.prefix_len_of(t)
-        parts = [A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)]
         tabs = [e.weight for e in self.codes_embs]
-        if p:
-            parts.append(A.EmbedSumPeFn.apply(codes[:, :p], self.audio_position_emb.pe, 0, *tabs))
-        if t > p:
-            parts.append(A.EmbedSumPeFn.apply(codes[:, p:], self.audio_position_emb.pe, p,
-                                              *tabs[: max(1, min(stage, q))]))
-        drops = [self.tokens_position_emb.dropout] + [self.audio_position_emb.dropout] * (len(parts) - 1)
-        parts = [dr(x) if (dr.training and dr.p > 0) else x for dr, x in zip(drops, parts)]
-        x = torch.cat(parts, dim=1).reshape(b * (tx + t), d)
+        n_stage = max(1, min(stage, q))
+        if not any(m.training and m.p > 0 for m in (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)):
+            # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
+            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds)
+            spec = [(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0])]
+            if p:
+                spec.append((codes[:, :p], self.audio_position_emb.pe, 0, list(range(1, 1 + q))))
+            if t > p:
+                spec.append((codes[:, p:], self.audio_position_emb.pe, p, list(range(1, 1 + n_stage))))
+            x = A.EmbedConcatFn.apply(spec, self.tokens_emb.weight, *tabs).reshape(b * (tx + t), d)
+        else:
+            parts = [A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)]
+            if p:
+                parts.append(A.EmbedSumPeFn.apply(codes[:, :p], self.audio_position_emb.pe, 0, *tabs))
+            if t > p:
+                parts.append(A.EmbedSumPeFn.apply(codes[:, p:], self.audio_position_emb.pe, p, *tabs[:n_stage]))
+            drops = [self.tokens_position_emb.dropout] + [self.audio_position_emb.dropout] * (len(parts) - 1)
+            parts = [dr(x) if (dr.training and dr.p > 0) else x for dr, x in zip(drops, parts)]
+            x = torch.cat(parts, dim=1).reshape(b * (tx + t), d)
         x = A.transformer_train(self.transformer, x, b, tx + t, dict(mode=kernels.MASK_FULL),
                                 embedding=self.stage_embs[stage - 1].weight)
         z = x.view(b, tx + t, d)[:, tx + p:].reshape(b * (t - p), d)
