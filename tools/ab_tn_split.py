@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from valle2_amd import _lib, kernels as K
 dev='cuda'

@@ -1,5 +1,5 @@
 import sys, os, tempfile
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 os.chdir(tempfile.mkdtemp())
 from valle2_amd import ConfigValle, get_model_class, synth
