@@ -1,3 +1,5 @@
+"""Developer tool: the FeedForward training epilogues over M — backward gelu'(pre) against a multiply by the kept derivative,
+forward GELU + pre against GELU + derivative (profiles/r3_ab_gelu_epilogue.log).   python tools/ab_gelu_epilogue_sweep.py"""
 import sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch

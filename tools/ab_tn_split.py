@@ -1,3 +1,5 @@
+"""Developer tool: vh_gemm_tn with its contraction split aimed at 512 / 384 / 256 workgroups (knob VH_TUNE_TN_WGS) on the
+weight-gradient shapes of configs[3] (profiles/r3_ab_tn_split.log).   python tools/ab_tn_split.py"""
 import sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch

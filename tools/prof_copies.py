@@ -1,3 +1,5 @@
+"""Developer tool: which call sites of one NAR training step issue copies (torch profiler with stacks).
+python tools/prof_copies.py"""
 import sys, os, tempfile
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch

@@ -1,3 +1,5 @@
+"""Developer tool: the tile GEMM (vh_linear_ex) over M for the four (N, K) of a 12L/512d layer, with bias + residual and
+plain — TFLOP/s per shape (profiles/r3_tile_gemm_sweep_*.log).   python tools/sweep_tile_gemm.py"""
 import sys, os
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
