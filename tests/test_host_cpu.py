@@ -191,6 +191,28 @@ def test_collate_matches_reference_golden():
                               'tokens': torch.zeros(9, dtype=torch.int64)}])
 
 
+def test_workspace_plans_of_the_gemm_entry_points():
+    """Host-side plans behind the workspace queries (pure arithmetic, no GPU): the tile kernel's tail split
+    (vh_linear_ex_ws_bytes: K slices of the tiles beyond the last multiple of 256 when those fill <= half of the CUs),
+    what vh_linear_ws asks for, and the weight-gradient split over one workgroup per CU."""
+    from valle2_amd import _lib
+    L = _lib.load_library()                 # host-only entry points: no device needed
+    slab = 128 * 128 * 4
+    assert L.vh_linear_ex_ws_bytes(10240, 512, 512) == 64 * 4 * slab        # 320 tiles: 64 tail tiles x 4 K slices
+    assert L.vh_linear_ex_ws_bytes(10240, 512, 2048) == 64 * 4 * slab
+    assert L.vh_linear_ex_ws_bytes(8800, 512, 512) == 20 * 4 * slab          # 276 tiles: K / 8 would be < 128 -> 4 slices
+    assert L.vh_linear_ex_ws_bytes(8800, 512, 2048) == 20 * 8 * slab
+    assert L.vh_linear_ex_ws_bytes(16384, 512, 512) == 0                     # 512 tiles: no tail
+    assert L.vh_linear_ex_ws_bytes(12800, 512, 512) == 0                     # 400 tiles: the tail fills more than half
+    assert L.vh_linear_ex_ws_bytes(1000, 512, 2048) == 0                     # fewer than 256 tiles: split-K territory
+    assert L.vh_linear_ex_ws_bytes(10240, 1025, 512) == 0                    # ragged N: never split
+    assert L.vh_linear_ws_bytes(10240, 512, 512) == 64 * 4 * slab            # vh_linear_ws hands its workspace on
+    assert L.vh_linear_ws_bytes(1000, 512, 2048) > 0 and L.vh_linear_ws_bytes(32, 512, 2048) > 0   # split-K plans
+    assert L.vh_linear_ws_bytes(32, 512, 512) == 0
+    # dW (512, 2048) over 16 320 tokens: 64 tiles -> 4 slices (one workgroup per CU), 4 slabs of the weight's size
+    assert L.vh_gemm_tn_ws_bytes(16320, 512, 2048) == 4 * 512 * 2048 * 4
+
+
 def test_flat_adamw_refuses_cpu_parameters():
     from valle2_amd._lib import VhError
     from valle2_amd.optim import FlatAdamW
