@@ -110,7 +110,9 @@ class ValleAR(_Base):
         b, d = tokens.shape[0], self.config.d_model
         drops = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)   # PE dropout p=0.1 is live in train mode (D9)
         if not any(m.training and m.p > 0 for m in drops):
-            # both embeddings written into ONE buffer (no torch.cat, no strided copies of its gradient)
+            # both embeddings written into ONE buffer (no torch.cat, no strided copies of its gradient).  The reference's
+            # PositionalEncoding keeps p = 0.1 whatever config.dropout says (D9), so in train mode the branch below runs;
+            # this one serves models whose PE dropout was switched off and gradient runs in eval mode
             x = A.EmbedConcatFn.apply([(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0]),
                                        (codes[:, :ty], self.audio_position_emb.pe, 0, [1])],
                                       self.tokens_emb.weight, self.audio_emb.weight).reshape(b * (tx + ty), d)

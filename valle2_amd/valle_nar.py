@@ -115,7 +115,8 @@ class ValleNAR(_Base):
         n_stage = max(1, min(stage, q))
         if not any(m.training and m.p > 0 for m in (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)):
             # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
-            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds)
+            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds).  As in
+            # the AR model, the reference's PE dropout (p = 0.1, D9) is live in train mode and takes the branch below
             spec = [(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0])]
             if p:
                 spec.append((codes[:, :p], self.audio_position_emb.pe, 0, list(range(1, 1 + q))))
