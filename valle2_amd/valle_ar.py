@@ -108,20 +108,25 @@ class ValleAR(_Base):
         codes_lens = batch['codes_lens']
         tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
         b, d = tokens.shape[0], self.config.d_model
-        drops = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)   # PE dropout p=0.1 is live in train mode (D9)
-        if not any(m.training and m.p > 0 for m in drops):
-            # both embeddings written into ONE buffer (no torch.cat, no strided copies of its gradient).  The reference's
-            # PositionalEncoding keeps p = 0.1 whatever config.dropout says (D9), so in train mode the branch below runs;
-            # this one serves models whose PE dropout was switched off and gradient runs in eval mode
+        # PE dropout p = 0.1 is live in train mode whatever config.dropout says (D9).  Both streams' embeddings are written
+        # into ONE buffer (no torch.cat, no strided copies of its gradient); when the two Dropout modules agree (both off,
+        # or both training with one p) a single elementwise dropout over that buffer draws the same Bernoulli field the
+        # reference draws in two calls — only the order of the draws from torch's generator differs
+        drops = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)
+        live = [m.training and m.p > 0 for m in drops]
+        if live[0] == live[1] and (not live[0] or drops[0].p == drops[1].p):
             x = A.EmbedConcatFn.apply([(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0]),
                                        (codes[:, :ty], self.audio_position_emb.pe, 0, [1])],
-                                      self.tokens_emb.weight, self.audio_emb.weight).reshape(b * (tx + ty), d)
+                                      self.tokens_emb.weight, self.audio_emb.weight)
+            if live[0]:
+                x = torch.nn.functional.dropout(x, drops[0].p, True)
+            x = x.reshape(b * (tx + ty), d)
         else:
             xt = A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)
             xa = A.EmbedSumPeFn.apply(codes[:, :ty], self.audio_position_emb.pe, 0, self.audio_emb.weight)
-            if drops[0].training and drops[0].p > 0:
+            if live[0]:
                 xt = drops[0](xt)
-            if drops[1].training and drops[1].p > 0:
+            if live[1]:
                 xa = drops[1](xa)
             x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
         kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)

@@ -113,16 +113,22 @@ class ValleNAR(_Base):
         p = self.prefix_len_of(t)
         tabs = [e.weight for e in self.codes_embs]
         n_stage = max(1, min(stage, q))
-        if not any(m.training and m.p > 0 for m in (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)):
+        drops2 = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)
+        live = [m.training and m.p > 0 for m in drops2]
+        if live[0] == live[1] and (not live[0] or drops2[0].p == drops2[1].p):
             # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
-            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds).  As in
-            # the AR model, the reference's PE dropout (p = 0.1, D9) is live in train mode and takes the branch below
+            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds); the PE
+            # dropout (p = 0.1 in train mode, D9) as ONE elementwise dropout over that buffer — the same Bernoulli field
+            # as the reference's per-part calls, drawn in a different order
             spec = [(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0])]
             if p:
                 spec.append((codes[:, :p], self.audio_position_emb.pe, 0, list(range(1, 1 + q))))
             if t > p:
                 spec.append((codes[:, p:], self.audio_position_emb.pe, p, list(range(1, 1 + n_stage))))
-            x = A.EmbedConcatFn.apply(spec, self.tokens_emb.weight, *tabs).reshape(b * (tx + t), d)
+            x = A.EmbedConcatFn.apply(spec, self.tokens_emb.weight, *tabs)
+            if live[0]:
+                x = torch.nn.functional.dropout(x, drops2[0].p, True)
+            x = x.reshape(b * (tx + t), d)
         else:
             parts = [A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)]
             if p:
