@@ -95,6 +95,11 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, (dy if ctx.has_res else None)
 
 
+# FeedForward's activation pair: the forward keeps gelu'(pre) where it would keep pre (one erf for GELU and derivative),
+# the backward's epilogue multiplies by it.  (tools/ab_train_step.py flips this to (ACT_GELU, ACT_GELU_BWD) for the A/B.)
+_FFN_FWD_ACT = [kernels.ACT_GELU_D, kernels.ACT_MUL]
+
+
 class FfnFn(torch.autograd.Function):
     """out = linear_2(gelu(linear_1(xn))) + residual  (modules.py:215-221,278) with dropout off.
     Forward: linear_1's epilogue stores the GELU and its DERIVATIVE (one erf for both) in one pass.  Backward: the
@@ -106,7 +111,7 @@ class FfnFn(torch.autograd.Function):
         m, dff = xn.shape[0], w1.shape[0]
         pre = torch.empty(m, dff, device=xn.device, dtype=torch.float32)
         hid = torch.empty_like(pre)
-        kernels.linear_ex(xn, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU_D)   # pre := gelu'
+        kernels.linear_ex(xn, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=_FFN_FWD_ACT[0])   # pre := gelu'
         out = torch.empty(m, w2.shape[0], device=xn.device, dtype=torch.float32)
         kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=residual, out=out)
         ctx.save_for_backward(xn, w1, w2, pre, hid, b1, b2)
@@ -121,7 +126,7 @@ class FfnFn(torch.autograd.Function):
         dw2 = optim.grad_out(w2)
         kernels.gemm_tn(dy, hid, out=dw2)                                   # dW2 = dY^T . hid
         db2 = _colsum(dy, b2)
-        dpre = _dx(dy, w2, kernels.pad32(d), residual=pre, act=kernels.ACT_MUL)   # (dY . W2) * gelu'(pre)
+        dpre = _dx(dy, w2, kernels.pad32(d), residual=pre, act=_FFN_FWD_ACT[1])   # (dY . W2) * gelu'(pre)
         dw1 = optim.grad_out(w1)
         kernels.gemm_tn(dpre, xn, out=dw1)
         db1 = _colsum(dpre, b1)
@@ -431,7 +436,7 @@ class EncoderLayerFn(torch.autograd.Function):
         xn2 = kernels.layernorm(xm, g2.detach(), be2.detach(), ada_scale=det(s2), ada_shift=det(t2), eps=eps)
         pre = torch.empty(B * T, w1.shape[0], device=dev, dtype=torch.float32)
         hid = torch.empty_like(pre)
-        kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=kernels.ACT_GELU_D)  # pre := gelu'
+        kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=_FFN_FWD_ACT[0])  # pre := gelu'
         y = torch.empty_like(x)
         kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=xm, out=y)
         ctx.save_for_backward(x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2)
@@ -458,7 +463,7 @@ class EncoderLayerFn(torch.autograd.Function):
         dpre = torch.empty_like(pre)                                       # (dY . W2) * gelu'(pre), + its column sums = db1
         fold = pre.shape[1] % 128 == 0                                     # (whole 128-column tiles)
         db1 = optim.grad_out(b1, zero=True) if fold else None
-        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=kernels.ACT_MUL, K=w2_t.shape[1], colsum=db1)
+        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=_FFN_FWD_ACT[1], K=w2_t.shape[1], colsum=db1)
         if not fold:
             db1 = _colsum(dpre, b1)
         dw1 = optim.grad_out(w1)
