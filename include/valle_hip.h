@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 100            /* 0.1.0 */
+#define VH_VERSION 110            /* 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -83,6 +83,27 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_COUNT = 12 };
 int vh_set_tuning(int knob, int value);
 
+/* ---- dropout field of the training path -------------------------------------------------------------
+ * replaces nn.Dropout at its four call sites of a training step: PositionalEncoding (valle/models/modules.py:56-58,
+ * 78-80: p = 0.1 whatever config.dropout says), FeedForward (:219), EncoderLayer.dropout1 / dropout2 (:277-278, p =
+ * config.dropout, default 0.1 valle/config.py:26) and TokenEmbedding (:35).  The field is never stored: it is a pure
+ * function of (seed, site, row, column) that every kernel regenerates where it needs it — forward epilogue and
+ * backward alike — so a training step with dropout reads and writes no mask tensors.
+ *   keep(row, col) = philox4x32_7(key = (seed lo, seed hi), counter = (col / 4, row, site lo, site hi))[col % 4]
+ *                    >= round(p * 2^32)                                   (Philox: Salmon et al., SC'11; 7 rounds)
+ *   dropped value  = keep ? value / (1 - p) : 0                           (torch.nn.functional.dropout's scaling)
+ * `row` / `col` index the logical (rows, cols) matrix the site covers (cols % 4 == 0); `site` tells the fields of one
+ * step apart (layer, call site), `seed` the steps.  A NULL spec or p == 0 means "no dropout" everywhere below; p must
+ * be < 1.  The stream differs from torch's generators: parity with the reference is through the exported mask
+ * (vh_dropout_mask) handed to the oracle, and distributional. */
+typedef struct { uint64_t seed; uint64_t site; float p; } vh_dropout_spec;
+/* out[r][c] = keep(r, c) ? x[r][c] / (1 - p) : 0 for a (rows, cols) matrix (row strides ldx / ldo, multiples of 4);
+ * out may be x.  Forward and backward of a free-standing nn.Dropout are this same call. */
+int vh_dropout(const float* x, int ldx, float* out, int ldo, int64_t rows, int cols, const vh_dropout_spec* spec,
+               void* stream);
+/* keep[r * cols + c] = 1 / 0: the field itself, for tests and for handing the very same mask to a CPU oracle */
+int vh_dropout_mask(uint8_t* keep, int64_t rows, int cols, const vh_dropout_spec* spec, void* stream);
+
 /* ---- K1/K2: embedding gather (sum over n_tables codebooks) + sinusoidal position add --------
  * replaces TokenEmbedding.forward + PositionalEncoding.forward (valle/models/modules.py:33-37,
  * 78-80) and the 8-codebook sum of ValleNAR._prepare_audio_codes (valle/models/valle_nar.py:
@@ -95,13 +116,16 @@ int vh_set_tuning(int knob, int value);
  * ORs VH_DEVERR_EMBED_ID into *err_flag (device int32, may be NULL); the reference's nn.Embedding raises
  * IndexError there — the host side turns the flag into that exception at its next synchronisation.
  * row_pos0 / row_t0 (device int32 (B), each may be NULL): per-row overrides of pos0 / out_t0 — a ragged batch whose
- * rows sit at different offsets (text | prompt | target per utterance) is embedded by one launch. */
+ * rows sit at different offsets (text | prompt | target per utterance) is embedded by one launch.
+ * drop (NULL: none): the dropout that follows the position add (modules.py:80) applied to the sum before it is stored;
+ * the field's row index is the row's offset in `out` / d (= b * (out_bstride / d) + out_t0 + t; out_bstride % d == 0
+ * then), its column the column — what vh_embed_bwd regenerates from the same spec. */
 enum { VH_DEVERR_EMBED_ID = 1, VH_DEVERR_TARGET = 2 };
 int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
                     int64_t ids_jstride, const float* const* tables, const int32_t* vocab, int n_tables,
                     const float* pe, int pos0, const int32_t* lens, float* out,
                     int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
-                    const int32_t* row_pos0, const int32_t* row_t0, void* stream);
+                    const int32_t* row_pos0, const int32_t* row_t0, const vh_dropout_spec* drop, void* stream);
 
 /* ---- K3/K4: LayerNorm (eps) with optional adaptive scale/shift ------------------------------
  * replaces nn.LayerNorm (valle/models/modules.py:284) and AdaptiveLayerNorm.forward (:93-99):
@@ -340,10 +364,14 @@ int vh_ar_decoder_profile_attn(vh_ar_decoder* dec, int n_steps, void* stream, fl
  * dres (rows, d) | NULL: added to dx — the gradient of the pre-norm block's residual branch, which bypasses the norm
  * (x feeds norm AND residual add, modules.py:271-279): no separate elementwise add.  dx must not alias dres.
  * dcolsum (d) | NULL: += the column sums of the rows written to dx — the bias gradient of the Linear whose output x
- * was (out-projection / linear_2), without a column-sum launch. */
+ * was (out-projection / linear_2), without a column-sum launch.
+ * dx_drop (rows, d) + drop (both or neither): x = residual + dropout(branch) (modules.py:277-278): the gradient of the
+ * BRANCH is the dropped dx.  It is written to dx_drop in the same pass (field row = row, column = column) and dcolsum
+ * then sums dx_drop — the branch's Linear bias sits under the dropout — while dx stays the residual stream's gradient. */
 int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta, const float* ada_scale,
                      const float* dy, float* dx, float* dgamma, float* dbeta, float* dscale,
-                     float* dshift, const float* dres, float* dcolsum, int rows, int d, float eps, void* stream);
+                     float* dshift, const float* dres, float* dcolsum, float* dx_drop, const vh_dropout_spec* drop,
+                     int rows, int d, float eps, void* stream);
 /* exact-erf GELU on a saved pre-activation: dh == NULL → out = gelu(pre); else out = dh*gelu'(pre) */
 int vh_gelu(const float* pre, const float* dh, float* out, int64_t n, void* stream);
 /* P = softmax(S*scale + mask) in place over rows of (B,h,Tq,Tk) with row stride ld >= Tk; same mask
@@ -361,10 +389,11 @@ int vh_softmax_bwd(const float* P, float* dP, int ld, int64_t rows, int Tk, floa
 int vh_cross_entropy(const float* logits, int ld, int V, const int64_t* target, float* loss,
                      float* dlogits, int ldd, int rows, int32_t* err_flag, void* stream);
 /* embedding backward: dtable[ids[b,t], :] += dout[b, out_t0 + t, :]; ids outside [0, vocab) are skipped
- * (and flagged as in vh_embed_sum_pe) */
+ * (and flagged as in vh_embed_sum_pe).  drop (NULL: none): the forward's vh_embed_sum_pe dropout — dout is multiplied
+ * by the regenerated field on the way in (dout_bstride % d == 0 then). */
 int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride, const float* dout,
                  int64_t dout_bstride, int out_t0, float* dtable, int vocab, int B, int T, int d,
-                 int32_t* err_flag, void* stream);
+                 int32_t* err_flag, const vh_dropout_spec* drop, void* stream);
 /* bias gradient: out[c] += sum_r x[r, c] */
 int vh_colsum(const float* x, int ld, float* out, int rows, int cols, void* stream);
 
@@ -439,10 +468,15 @@ int vh_adamw_flat(float* param, float* grad, float* exp_avg, float* exp_avg_sq, 
  *                     launch adds the slices in slice order and applies the epilogue: deterministic, but those tiles'
  *                     sums are associated differently from an unsplit run.  vh_linear_ex_ws_bytes returns 0 for a
  *                     shape that is not split (<= 16 MiB otherwise); NULL or a smaller workspace = never split. */
+/*   drop (NULL: none; act NONE / GELU_ERF / GELU_ERF_D, N % 4 == 0, K % 32 == 0): out = dropout(act(acc + bias)) +
+ *                     residual with the field indexed by (m, n) — dropout1 / dropout2 inside the out-projection's /
+ *                     linear_2's epilogue (modules.py:277-278) and FeedForward's dropout inside linear_1's (:219).
+ *                     With VH_ACT_GELU_ERF_D the stored derivative is multiplied by the same keep / (1 - p) factor, so
+ *                     the backward's VH_ACT_MUL epilogue already yields the gradient through dropout AND GELU. */
 size_t vh_linear_ex_ws_bytes(int M, int N, int K);
 int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual, int ldr,
                  float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K, int act,
-                 void* workspace, size_t workspace_bytes, void* stream);
+                 const vh_dropout_spec* drop, void* workspace, size_t workspace_bytes, void* stream);
 
 /* out (cols, ldo) = in (rows, cols)^T; out rows are zero-filled from `rows` up to ldo. */
 int vh_transpose(const float* in, int ldi, int rows, int cols, float* out, int ldo, void* stream);

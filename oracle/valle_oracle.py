@@ -42,15 +42,51 @@ def positional_table(d_model: int, max_len: int = 5000) -> torch.Tensor:
     return pe.unsqueeze(0).transpose(0, 1)
 
 
+class Dropout:
+    """Train-mode dropout of the path (valle/models/modules.py:56-58,80 PositionalEncoding p = 0.1 always;
+    :219 FeedForward, :277-278 EncoderLayer.dropout1/2 with p = config.dropout, valle/config.py:26), in two modes:
+
+      Dropout(p_layers, p_pe)             the reference's own arithmetic: every site calls F.dropout in the reference's
+                                          order, so under one torch.manual_seed the draws — and hence the results — are
+                                          the reference's bit for bit.  The multiplier tensors (0 or 1/(1-p)) each site
+                                          used are kept in `.used[name]` (drawn as F.dropout(ones): same generator
+                                          consumption, and x * F.dropout(ones) is exactly what F.dropout(x) computes on
+                                          the CPU: noise = bernoulli(1-p) / (1-p), out = x * noise).
+      Dropout(..., masks={name: keep})    the SAME sites with GIVEN keep fields (uint8/bool, (rows..., cols) in the
+                                          layout of the tensor they multiply): how the HIP path's counter-based fields
+                                          (vh_dropout_mask) are replayed on the CPU.
+
+    Site names: 'tokens_position_emb.dropout', 'audio_position_emb.dropout', 'layer{i}.dropout1',
+    'layer{i}.ffn.dropout', 'layer{i}.dropout2'."""
+
+    def __init__(self, p_layers: float, p_pe: float = 0.1, masks=None):
+        self.p_layers, self.p_pe, self.masks, self.used = p_layers, p_pe, masks, {}
+
+    def __call__(self, name: str, x: torch.Tensor, p: float) -> torch.Tensor:
+        if p == 0:
+            return x                                         # F.dropout(p=0) returns its input and draws nothing
+        if self.masks is not None:
+            noise = self.masks[name].reshape(x.shape).to(x.dtype) * (1.0 / (1.0 - p))
+        else:
+            noise = F.dropout(torch.ones_like(x), p, True)          # (same strides as x: same draw order)
+        self.used[name] = noise
+        return x * noise
+
+
 def embed(table: torch.Tensor, ids: torch.Tensor) -> torch.Tensor:
-    """valle/models/modules.py:33-37 — row gather (dropout p=0 is the identity in eval)."""
+    """valle/models/modules.py:33-37 — row gather (TokenEmbedding's dropout has p = 0: the identity, no draw)."""
     return F.embedding(ids, table)
 
 
-def add_position(x: torch.Tensor, pe: torch.Tensor) -> torch.Tensor:
-    """valle/models/modules.py:78-80 — x (B,T,d) + pe[:T] broadcast over batch; eval mode."""
+def add_position(x: torch.Tensor, pe: torch.Tensor, drop: Dropout | None = None, name: str = '') -> torch.Tensor:
+    """valle/models/modules.py:78-80 — x (B,T,d) + pe[:T] broadcast over batch, then dropout (train mode) on the
+    (T,B,d) tensor; a given keep field is in (B,T,d) layout."""
     xt = x.permute(1, 0, 2)
     xt = xt + pe[: xt.size(0), :]
+    if drop is not None:
+        if drop.masks is not None and drop.p_pe:
+            drop = Dropout(drop.p_layers, drop.p_pe, {name: drop.masks[name].reshape(x.shape).permute(1, 0, 2)})
+        xt = drop(name, xt, drop.p_pe)
     return xt.permute(1, 0, 2)
 
 
@@ -132,25 +168,33 @@ def multi_head_attention(sd, p, x, n_heads, attn_mask=None, padding_mask=None, k
     return F.linear(out, sd[p + 'out.weight'], sd[p + 'out.bias']), kv
 
 
-def feed_forward(sd, p, x):
-    """valle/models/modules.py:215-221 — Linear → exact-erf GELU → (dropout) → Linear."""
+def feed_forward(sd, p, x, drop=None, site=''):
+    """valle/models/modules.py:215-221 — Linear → exact-erf GELU → dropout → Linear."""
     hidden = F.gelu(F.linear(x, sd[p + 'linear_1.weight'], sd[p + 'linear_1.bias']))
+    if drop is not None:
+        hidden = drop(site + 'ffn.dropout', hidden, drop.p_layers)
     return F.linear(hidden, sd[p + 'linear_2.weight'], sd[p + 'linear_2.bias'])
 
 
 def encoder_layer(sd, p, x, cfg, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
-                  use_cache=False):
-    """valle/models/modules.py:240-280 — pre-norm residual block."""
+                  use_cache=False, drop=None, site=''):
+    """valle/models/modules.py:240-280 — pre-norm residual block; `drop` (train mode): dropout1 on the attention
+    branch, FeedForward's dropout, dropout2 on the FeedForward branch (:219, :277-278)."""
     a, kv = multi_head_attention(sd, p + 'self_attn.', _norm(sd, p + 'norm1.', x, cfg.norm, embedding),
                                  cfg.n_heads, attn_mask=attn_mask, padding_mask=padding_mask,
                                  kv_cache=kv_cache, use_cache=use_cache)
+    if drop is not None:
+        a = drop(site + 'dropout1', a, drop.p_layers)
     x = x + a
-    x = x + feed_forward(sd, p + 'ffn.', _norm(sd, p + 'norm2.', x, cfg.norm, embedding))
+    f = feed_forward(sd, p + 'ffn.', _norm(sd, p + 'norm2.', x, cfg.norm, embedding), drop, site)
+    if drop is not None:
+        f = drop(site + 'dropout2', f, drop.p_layers)
+    x = x + f
     return x, kv
 
 
 def transformer(sd, p, x, cfg, padding_mask=None, attn_mask=None, embedding=None, kv_cache=None,
-                use_cache=False):
+                use_cache=False, drop=None):
     """valle/models/modules.py:305-352 — L layers; with a cache keep the last row and drop the
     mask; collect the per-layer (k,v) tuple when use_cache."""
     new_kv = ()
@@ -162,7 +206,7 @@ def transformer(sd, p, x, cfg, padding_mask=None, attn_mask=None, embedding=None
     for i in range(cfg.num_layers):
         x, kv = encoder_layer(sd, f'{p}layers.{i}.', x, cfg, padding_mask=padding_mask,
                               attn_mask=attn_mask, embedding=embedding, kv_cache=kv_cache[i],
-                              use_cache=use_cache)
+                              use_cache=use_cache, drop=drop, site=f'layer{i}.')
         if use_cache:
             new_kv = new_kv + (kv,)
     return x, new_kv
@@ -210,24 +254,25 @@ def get_best_beam(x, sum_logprobs, stop_token, length_penalty=1.0):
 # --------------------------------------------------------------------------------------------
 # ValleAR (valle/models/valle_ar.py)
 # --------------------------------------------------------------------------------------------
-def ar_logits(sd, cfg, batch):
-    """valle/models/valle_ar.py:54-83 — teacher-forced forward; returns logits (B, V_a+1, Ty)."""
+def ar_logits(sd, cfg, batch, drop=None):
+    """valle/models/valle_ar.py:54-83 — teacher-forced forward; returns logits (B, V_a+1, Ty).  `drop`: a Dropout
+    (train mode); None = eval."""
     tokens_lens, codes_lens = batch['tokens_lens'], batch['codes_lens']
     tx, ty = int(max(tokens_lens)), int(max(codes_lens))
     tokens = add_position(embed(sd['tokens_emb.word_embeddings.weight'], batch['tokens']),
-                          sd['tokens_position_emb.pe'])
+                          sd['tokens_position_emb.pe'], drop, 'tokens_position_emb.dropout')
     codes = add_position(embed(sd['audio_emb.word_embeddings.weight'], batch['codes']),
-                         sd['audio_position_emb.pe'])
+                         sd['audio_position_emb.pe'], drop, 'audio_position_emb.dropout')
     padding_mask = F.pad(build_pad_mask(codes_lens), (tx, 0), value=False)
     attn_mask = build_attn_mask(tx, ty)
     out, _ = transformer(sd, 'transformer.', torch.cat((tokens, codes), dim=1), cfg,
-                         padding_mask=padding_mask, attn_mask=attn_mask)
+                         padding_mask=padding_mask, attn_mask=attn_mask, drop=drop)
     return F.linear(out[:, tx:], sd['proj.weight']).permute(0, 2, 1)
 
 
-def ar_training_loss(sd, cfg, batch):
+def ar_training_loss(sd, cfg, batch, drop=None):
     """valle/models/valle_ar.py:86 — mean CE over ALL (B,Ty) positions, pads included."""
-    return F.cross_entropy(ar_logits(sd, cfg, batch), batch['target'])
+    return F.cross_entropy(ar_logits(sd, cfg, batch, drop), batch['target'])
 
 
 def ar_generate(sd, cfg, prompt_tokens, prompt_codes, target_tokens=None, trace=None):
@@ -295,25 +340,25 @@ def nar_prepare_audio_codes(sd, cfg, codes, nar_stage):
     return torch.concat((prompt, rest), dim=1), prefix_len
 
 
-def nar_stage_logits(sd, cfg, batch, stage):
+def nar_stage_logits(sd, cfg, batch, stage, drop=None):
     """Intended forward of valle/models/valle_nar.py:71-100 for a given stage (1..Q-1): logits
     (B, T-prefix, V_a) for codebook `stage` of the non-prefix frames.  Key padding is NOT applied
     (attn_mask is None → defect D6 drops it), matching what the reference's Transformer does."""
     tx = int(batch['tokens_lens'].max())
     tokens = add_position(embed(sd['tokens_emb.word_embeddings.weight'], batch['tokens']),
-                          sd['tokens_position_emb.pe'])
+                          sd['tokens_position_emb.pe'], drop, 'tokens_position_emb.dropout')
     y, prefix_len = nar_prepare_audio_codes(sd, cfg, batch['codes'], stage)
-    y = add_position(y, sd['audio_position_emb.pe'])
+    y = add_position(y, sd['audio_position_emb.pe'], drop, 'audio_position_emb.dropout')
     pad = F.pad(build_pad_mask(batch['codes_lens']), (tx, 0), value=False)
     z, _ = transformer(sd, 'transformer.', torch.cat([tokens, y], dim=1), cfg, padding_mask=pad,
-                       embedding=sd[f'stage_embs.{stage - 1}.word_embeddings.weight'])
+                       embedding=sd[f'stage_embs.{stage - 1}.word_embeddings.weight'], drop=drop)
     return F.linear(z[:, tx + prefix_len:], sd[f'proj_layers.{stage - 1}.weight']), prefix_len
 
 
-def nar_training_loss(sd, cfg, batch, stage):
+def nar_training_loss(sd, cfg, batch, stage, drop=None):
     """Intended loss (valle_nar.py:81,103): CE of stage logits vs raw ids codes[:, prefix:, stage],
     mean over all positions (same convention as the AR loss)."""
-    logits, prefix_len = nar_stage_logits(sd, cfg, batch, stage)
+    logits, prefix_len = nar_stage_logits(sd, cfg, batch, stage, drop)
     return F.cross_entropy(logits.permute(0, 2, 1), batch['codes'][:, prefix_len:, stage])
 
 

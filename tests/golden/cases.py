@@ -241,6 +241,46 @@ def _ref_ar_train(ref):
     return {'loss': loss.detach(), 'grad_norms': torch.stack([grads[n] for n in names]).detach()}
 
 
+DROPOUT_SEED = 4242        # torch.manual_seed right before the train-mode forward, on both sides
+AR_TINY_DROPOUT = dict(AR_TINY, dropout=0.1)        # the reference's default p (valle/config.py:26)
+
+
+def _ref_ar_train_dropout(ref):
+    """ValleAR.training_step in TRAIN mode (dropout1/2 + FeedForward dropout p = 0.1, PositionalEncoding dropout 0.1):
+    loss, per-parameter gradient norms and the logits under torch.manual_seed(DROPOUT_SEED).  The oracle must draw the
+    same Bernoulli fields from the same generator state — this pins WHERE it applies dropout."""
+    _, sd, batch = ar_train_inputs()
+    with torch.enable_grad():
+        cfg = cfg_of(AR_TINY_DROPOUT, ref['config'].ConfigValle)
+        m = ref['ar'].ValleAR(cfg).train()
+        m.load_state_dict(sd)
+        rows = []
+        hook = m.proj.register_forward_hook(lambda mod, i, o: rows.append(o.detach().clone()))
+        torch.manual_seed(DROPOUT_SEED)
+        loss = m.training_step({k: v.clone() for k, v in batch.items()})
+        hook.remove()
+        loss.backward()
+        grads = {n: p.grad.norm() for n, p in m.named_parameters()}
+    names = sorted(grads)
+    return {'loss': loss.detach(), 'grad_norms': torch.stack([grads[n] for n in names]).detach(), 'logits': rows[0]}
+
+
+def _ref_transformer_dropout(ref):
+    """Transformer.forward in TRAIN mode, both norms (AdaLN = the NAR stack, whose training_step raises in the reference)."""
+    out = {}
+    for norm in ('LayerNorm', 'AdaptiveLayerNorm'):
+        kw, sd, x, xl, yl, pad, emb = transformer_inputs(norm)
+        cfg = cfg_of(dict(kw, dropout=0.1), ref['config'].ConfigValle)
+        m = ref['modules'].Transformer(cfg).train()
+        m.load_state_dict(sd)
+        mask = ref['utils'].build_attn_mask(xl, yl, device='cpu')
+        e = emb if norm != 'LayerNorm' else None
+        torch.manual_seed(DROPOUT_SEED)
+        y, _ = m(x, padding_mask=pad, attn_mask=mask, embedding=e)
+        out[f'{norm}_y'] = y
+    return out
+
+
 def _ref_generate(ref, which):
     kw, sd, utt = ar_generate_inputs(which)
     cfg = cfg_of(kw, ref['config'].ConfigValle)
@@ -413,6 +453,8 @@ REFERENCE_RUNNERS = {
     'mha': _ref_mha,
     'transformer': _ref_transformer,
     'ar_train': _ref_ar_train,
+    'ar_train_dropout': _ref_ar_train_dropout,
+    'transformer_dropout': _ref_transformer_dropout,
     'ar_generate_tiny': lambda ref: _ref_generate(ref, 'tiny'),
     'ar_generate_mid': lambda ref: _ref_generate(ref, 'mid'),
     'ar_generate_eos': _ref_generate_eos,

@@ -69,6 +69,32 @@ def ar_train():
             'grad_norms': torch.stack([params[n].grad.norm() for n in names])}
 
 
+def ar_train_dropout():
+    _, sd, batch = C.ar_train_inputs()
+    cfg = C.cfg_of(C.AR_TINY_DROPOUT)
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    with torch.enable_grad():
+        torch.manual_seed(C.DROPOUT_SEED)
+        logits = O.ar_logits(params, cfg, batch, O.Dropout(cfg.dropout))
+        loss = torch.nn.functional.cross_entropy(logits, batch['target'])
+        loss.backward()
+    names = sorted(k for k in params if not k.endswith('.pe'))
+    return {'loss': loss.detach(), 'grad_norms': torch.stack([params[n].grad.norm() for n in names]),
+            'logits': logits.detach().permute(0, 2, 1).contiguous()}
+
+
+def transformer_dropout():
+    out = {}
+    for norm in ('LayerNorm', 'AdaptiveLayerNorm'):
+        kw, sd, x, xl, yl, pad, emb = C.transformer_inputs(norm)
+        cfg = C.cfg_of(dict(kw, dropout=0.1))
+        torch.manual_seed(C.DROPOUT_SEED)
+        y, _ = O.transformer(sd, '', x, cfg, padding_mask=pad, attn_mask=O.build_attn_mask(xl, yl),
+                             embedding=emb if norm != 'LayerNorm' else None, drop=O.Dropout(cfg.dropout))
+        out[f'{norm}_y'] = y
+    return out
+
+
 def _generate(kw, sd, utt):
     cfg = C.cfg_of(kw)
     trace = {}
@@ -200,6 +226,7 @@ ORACLE_RUNNERS = {
     'nar_full': nar_full,
     'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
     'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
+    'ar_train_dropout': ar_train_dropout, 'transformer_dropout': transformer_dropout,
     'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,
     'ar_generate_eos': ar_generate_eos, 'nar': nar, 'sampling': sampling,
 }

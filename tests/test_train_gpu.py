@@ -97,7 +97,7 @@ def test_embedding_backward_and_colsum():
     ref = sum(F.embedding(ids[..., j], tabs[j]) for j in range(3)) + pe[:9, 0]
     ref.backward(dy)
     dt = [t.detach().to(DEV).requires_grad_() for t in tabs]
-    out = A.EmbedSumPeFn.apply(ids.to(DEV), pe.to(DEV), 0, *dt)
+    out = A.EmbedSumPeFn.apply(ids.to(DEV), pe.to(DEV), 0, None, *dt)
     close(out, ref)
     out.backward(dy.to(DEV))
     for a, b in zip(dt, tabs):
@@ -114,7 +114,7 @@ def test_embedding_backward_and_colsum():
     ref = F.embedding(ids[..., 0], tab) + pe[:T, 0]
     ref.backward(dy)
     td = tab.detach().to(DEV).requires_grad_()
-    out = A.EmbedSumPeFn.apply(ids.to(DEV), pe.to(DEV), 0, td)
+    out = A.EmbedSumPeFn.apply(ids.to(DEV), pe.to(DEV), 0, None, td)
     close(out, ref)
     out.backward(dy.to(DEV))
     close(td.grad, tab.grad, atol=2e-5)
@@ -139,8 +139,8 @@ def test_embed_concat_matches_parts_and_cat():
     ref.backward(dy)
     dev_tabs = [x.detach().to(DEV).requires_grad_() for x in [tok_tab] + tabs]
     cd, td = codes.to(DEV), tokens.to(DEV)
-    spec = [(td, pe_t.to(DEV), 0, [0]), (cd[:, :p], pe_a.to(DEV), 0, list(range(1, 1 + q))),
-            (cd[:, p:], pe_a.to(DEV), p, list(range(1, 1 + stage)))]
+    spec = [(td, pe_t.to(DEV), 0, [0], None), (cd[:, :p], pe_a.to(DEV), 0, list(range(1, 1 + q)), None),
+            (cd[:, p:], pe_a.to(DEV), p, list(range(1, 1 + stage)), None)]
     out = A.EmbedConcatFn.apply(spec, *dev_tabs)
     close(out, ref)
     out.backward(dy.to(DEV))

@@ -24,6 +24,14 @@ class VhError(RuntimeError):
     pass
 
 
+class VhDropoutSpec(C.Structure):
+    """include/valle_hip.h vh_dropout_spec: (seed, site, p) of one dropout field."""
+    _fields_ = [('seed', C.c_uint64), ('site', C.c_uint64), ('p', C.c_float)]
+
+
+c_dropp = C.POINTER(VhDropoutSpec)
+
+
 class VhLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'ln1_g', 'ln1_b', 'wqkv', 'wo', 'bo', 'ln2_g', 'ln2_b', 'w1', 'b1', 'w2', 'b2',
@@ -66,7 +74,9 @@ SIGNATURES = {
     'vh_set_tuning': (C.c_int, [C.c_int, C.c_int]),
     'vh_embed_sum_pe': (C.c_int, [c_i64p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p),
                                   C.POINTER(C.c_int32), C.c_int, c_f32p, C.c_int, c_i32p, c_f32p, C.c_int64,
-                                  C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+                                  C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_i32p, c_dropp, C.c_void_p]),
+    'vh_dropout': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int, c_dropp, C.c_void_p]),
+    'vh_dropout_mask': (C.c_int, [c_u8p, C.c_int64, C.c_int, c_dropp, C.c_void_p]),
     'vh_layernorm': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                C.c_float, C.c_void_p]),
     'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
@@ -125,7 +135,7 @@ SIGNATURES = {
     'vh_ar_decoder_profile_attn': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p,
                                              C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     'vh_layernorm_bwd': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
-                                   c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+                                   c_f32p, c_f32p, c_f32p, c_f32p, c_dropp, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     'vh_gelu': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int64, C.c_void_p]),
     'vh_softmax_rows': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
                                   C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
@@ -133,10 +143,10 @@ SIGNATURES = {
     'vh_cross_entropy': (C.c_int, [c_f32p, C.c_int, C.c_int, c_i64p, c_f32p, c_f32p, C.c_int, C.c_int,
                                    c_i32p, C.c_void_p]),
     'vh_embed_bwd': (C.c_int, [c_i64p, C.c_int64, C.c_int64, c_f32p, C.c_int64, C.c_int, c_f32p, C.c_int,
-                               C.c_int, C.c_int, C.c_int, c_i32p, C.c_void_p]),
+                               C.c_int, C.c_int, C.c_int, c_i32p, c_dropp, C.c_void_p]),
     'vh_colsum': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     'vh_linear_ex': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p, C.c_int,
-                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+                               c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_dropp, C.c_void_p, C.c_size_t, C.c_void_p]),
     'vh_linear_ex_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'vh_transpose': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     'vh_transpose_many': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

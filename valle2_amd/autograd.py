@@ -13,7 +13,9 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib, kernels, optim
+import ctypes as C
+
+from . import _lib, dropout, kernels, optim
 from ._lib import check, ptr, stream
 
 HEAD_DIM = kernels.HEAD_DIM
@@ -178,8 +180,8 @@ class LayerNormFn(torch.autograd.Function):
             s = s.contiguous()
             ds, dt = torch.zeros(d, device=x.device), torch.zeros(d, device=x.device)
         check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy),
-                                          ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(dt), None, None, rows, d, ctx.eps,
-                                          stream()), 'vh_layernorm_bwd')
+                                          ptr(dx), ptr(dg), ptr(db), ptr(ds), ptr(dt), None, None, None, None, rows, d,
+                                          ctx.eps, stream()), 'vh_layernorm_bwd')
         if ds is not None:
             ds, dt = ds.view_as(s), dt.view_as(s)
         return dx, dg, db, ds, dt, None
@@ -249,18 +251,23 @@ class QkvAttentionFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+def _drop_ref(sp):
+    return None if sp is None else C.byref(sp)
+
+
 class EmbedSumPeFn(torch.autograd.Function):
-    """x[:, t0:t0+T] = sum_j tables[j][ids[..., j]] + pe[pos0:pos0+T]  written into a fresh (B,T,d)."""
+    """x[:, t0:t0+T] = dropout(sum_j tables[j][ids[..., j]] + pe[pos0:pos0+T])  written into a fresh (B,T,d);
+    drop: a dropout.spec or None (modules.py:35,80)."""
 
     @staticmethod
-    def forward(ctx, ids, pe, pos0, *tables):
+    def forward(ctx, ids, pe, pos0, drop, *tables):
         if ids.dim() == 2:
             ids = ids.unsqueeze(-1)
         B, T, _ = ids.shape
         d = tables[0].shape[1]
         out = torch.empty(B, T, d, device=ids.device, dtype=torch.float32)
-        kernels.embed_sum_pe(ids, [t.detach() for t in tables], pe, pos0, out)
-        ctx.ids, ctx.shapes, ctx.tables = ids, [t.shape for t in tables], tables
+        kernels.embed_sum_pe(ids, [t.detach() for t in tables], pe, pos0, out, drop=drop)
+        ctx.ids, ctx.shapes, ctx.tables, ctx.drop = ids, [t.shape for t in tables], tables, drop
         return out
 
     @staticmethod
@@ -270,23 +277,25 @@ class EmbedSumPeFn(torch.autograd.Function):
         B, T, d = dout.shape
         grads = []
         for j, shp in enumerate(ctx.shapes):
-            if not ctx.needs_input_grad[3 + j]:
+            if not ctx.needs_input_grad[4 + j]:
                 grads.append(None)
                 continue
             g = optim.grad_out(ctx.tables[j], zero=True)
             col = ids[..., j]
             check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout),
                                           dout.stride(0), 0, ptr(g), int(shp[0]), B, T, d,
-                                          ptr(_lib.err_flag(dout.device)), stream()), 'vh_embed_bwd')
+                                          ptr(_lib.err_flag(dout.device)), _drop_ref(ctx.drop), stream()), 'vh_embed_bwd')
             grads.append(g)
-        return (None, None, None, *grads)
+        return (None, None, None, None, *grads)
 
 
 class EmbedConcatFn(torch.autograd.Function):
     """The model input x (B, sum T_i, d) of a training step in one buffer: part i = sum_j tables[idx][ids_i[..., j]] +
     pe_i[pos0_i : pos0_i + T_i] is written at its row offset (what EmbedSumPeFn per part + torch.cat made with a copy
     forward and two strided copies backward), and every table receives ONE gradient however many parts read it.
-    parts: [(ids (B, T_i) | (B, T_i, J_i), pe, pos0, [indices into `tables`, one per codebook column])]."""
+    parts: [(ids (B, T_i) | (B, T_i, J_i), pe, pos0, [indices into `tables`, one per codebook column], drop)] —
+    drop: the dropout.spec of the part's PositionalEncoding dropout (modules.py:80) or None; its field is indexed by the
+    row of the joint buffer, so parts never share an element whatever their specs."""
 
     @staticmethod
     def forward(ctx, parts, *tables):
@@ -295,11 +304,11 @@ class EmbedConcatFn(torch.autograd.Function):
         total = sum(p[0].shape[1] for p in parts)
         out = torch.empty(B, total, d, device=tables[0].device, dtype=torch.float32)
         t0, laid = 0, []
-        for ids, pe, pos0, idx in parts:
+        for ids, pe, pos0, idx, drop in parts:
             if ids.dim() == 2:
                 ids = ids.unsqueeze(-1)
-            kernels.embed_sum_pe(ids, [tables[j].detach() for j in idx], pe, pos0, out, out_t0=t0)
-            laid.append((ids, t0, idx))
+            kernels.embed_sum_pe(ids, [tables[j].detach() for j in idx], pe, pos0, out, out_t0=t0, drop=drop)
+            laid.append((ids, t0, idx, drop))
             t0 += ids.shape[1]
         ctx.laid, ctx.tables = laid, tables
         return out
@@ -309,14 +318,14 @@ class EmbedConcatFn(torch.autograd.Function):
         dout = dout.contiguous()
         B, _, d = dout.shape
         grads = [optim.grad_out(t, zero=True) if ctx.needs_input_grad[1 + j] else None for j, t in enumerate(ctx.tables)]
-        for ids, t0, idx in ctx.laid:
+        for ids, t0, idx, drop in ctx.laid:
             for col_j, j in enumerate(idx):
                 if grads[j] is None:
                     continue
                 col = ids[..., col_j]
                 check(_lib.lib().vh_embed_bwd(col.data_ptr(), col.stride(0), col.stride(1), ptr(dout), dout.stride(0), t0,
                                               ptr(grads[j]), int(ctx.tables[j].shape[0]), B, ids.shape[1], d,
-                                              ptr(_lib.err_flag(dout.device)), stream()), 'vh_embed_bwd')
+                                              ptr(_lib.err_flag(dout.device)), _drop_ref(drop), stream()), 'vh_embed_bwd')
         return (None, *grads)
 
 
@@ -342,20 +351,22 @@ class CrossEntropyFn(torch.autograd.Function):
         return dl * g, None
 
 
-def _ln_bwd(x, gamma, beta, s, dy, dres, dcol, eps, dst=None):
+def _ln_bwd(x, gamma, beta, s, dy, dres, dcol, eps, dst=None, drop=None):
     """LayerNorm / AdaLN backward with the residual-branch gradient added in the same pass and (optionally) the column
     sums of the result accumulated into `dcol`.  `dst` (2, d), zero on entry: where the AdaLN scale / shift gradients
-    are accumulated.  Returns (dx, dgamma, dbeta)."""
+    are accumulated.  drop (a dropout.spec): x was residual + dropout(branch) — the branch's gradient, dx under that
+    dropout's field, is written as well and `dcol` sums IT.  Returns (dx, dgamma, dbeta, dx_dropped | None)."""
     d = x.shape[-1]
     dx = torch.empty_like(x)
+    dxd = torch.empty_like(x) if drop is not None else None
     dg, db = optim.grad_out(gamma, zero=True), optim.grad_out(beta, zero=True)
     ds = dt = None
     if s is not None:
         ds, dt = dst[0], dst[1]
     check(_lib.lib().vh_layernorm_bwd(ptr(x), ptr(gamma.detach()), ptr(beta.detach()), ptr(s), ptr(dy), ptr(dx),
-                                      ptr(dg), ptr(db), ptr(ds), ptr(dt), ptr(dres), ptr(dcol), x.numel() // d, d,
-                                      eps, stream()), 'vh_layernorm_bwd')
-    return dx, dg, db
+                                      ptr(dg), ptr(db), ptr(ds), ptr(dt), ptr(dres), ptr(dcol), ptr(dxd), _drop_ref(drop),
+                                      x.numel() // d, d, eps, stream()), 'vh_layernorm_bwd')
+    return dx, dg, db, dxd
 
 
 class AdaProjFn(torch.autograd.Function):
@@ -398,16 +409,28 @@ class AdaProjFn(torch.autograd.Function):
         return (None if demb is None else demb.view(1, K), *grads)
 
 
-# bias gradients produced ahead of their layer's backward: layer l+1's LayerNorm backward writes dx — the gradient of
-# layer l's output — and accumulates its column sums, which ARE the gradient of layer l's linear_2 bias, into that
-# bias' gradient slot; layer l's backward picks the tensor up here instead of launching a column-sum kernel.
-# id(bias parameter) -> gradient tensor; filled and consumed inside one backward pass (cleared at every forward).
-_BIAS_GRAD_AHEAD = {}
+class _StackPass:
+    """What the layers of ONE transformer_train call hand each other during its backward (a fresh object per forward,
+    carried in every layer's `meta`: nothing outlives the pass it belongs to).
+      bias_ahead[l]  layer l+1's norm1 backward writes dx — the gradient of layer l's output — and accumulates its column
+                     sums, which ARE the gradient of layer l's linear_2 bias, into that bias' gradient slot; layer l's
+                     backward picks the tensor up here instead of launching a column-sum kernel.
+      dy_drop[l]     (dx, dx under layer l's dropout2 field) from the same launch: layer l's backward uses the dropped
+                     copy for the products of its FeedForward branch when the gradient it receives IS that dx."""
+
+    def __init__(self, drops):
+        self.drops = drops                 # dropout.StackDropout
+        self.bias_ahead = {}
+        self.dy_drop = {}
 
 
 class EncoderLayerFn(torch.autograd.Function):
-    """One pre-norm block (modules.py:240-280, dropout off) as ONE autograd node:
-        xm = x + out(attn(qkv(norm1(x))));  y = xm + linear_2(gelu(linear_1(norm2(xm)))).
+    """One pre-norm block (modules.py:240-280) as ONE autograd node, dropout included:
+        xm = x + drop1(out(attn(qkv(norm1(x)))));  y = xm + drop2(linear_2(dropf(gelu(linear_1(norm2(xm)))))).
+    The three dropouts are fields regenerated in the epilogues (dropout.py): drop1 / drop2 inside the out-projection's /
+    linear_2's bias + residual epilogue, dropf inside linear_1's GELU epilogue, which also multiplies the stored GELU
+    derivative by the field — so the backward's (dY . W2) * saved epilogue needs nothing new.  The gradients of the two
+    residual branches are the dropped copies the LayerNorm backward launches write next to the residual stream's.
     The forward is the kernel sequence of the separate Functions; the backward runs the whole block in one Python
     call with the residual-gradient adds folded into the two LayerNorm backward launches, the out-projection's bias
     gradient (and the linear_2 bias gradient of the layer BELOW) taken from those launches' column sums, and the
@@ -418,8 +441,9 @@ class EncoderLayerFn(torch.autograd.Function):
         # AdaLN: meta carries this layer's (scale, shift) pairs as views of the stack's projections (ada_all, made by
         # AdaProjFn) and the slices of the ONE gradient buffer every layer accumulates into; only the first layer
         # receives ada_all as a differentiable input and hands that buffer back as its gradient (it runs last)
-        B, T, n_heads, spec, eps, wts, below_b2, ada, ada_grad = meta
+        B, T, n_heads, spec, eps, wts, below_b2, ada, ada_grad, sp, idx = meta
         s1, t1, s2, t2 = ada if ada is not None else (None, None, None, None)
+        dr1, drf, dr2 = sp.drops.layer(idx)
         x = x.contiguous()
         dev, d = x.device, x.shape[1]
         det = lambda p: None if p is None else p.detach().contiguous()   # noqa: E731
@@ -432,13 +456,19 @@ class EncoderLayerFn(torch.autograd.Function):
         lse2 = torch.empty(B, n_heads, T, device=dev, dtype=torch.float32)
         kernels.attn_rows(q, k, v, a, B, n_heads, T, T, lse2=lse2, **spec)
         xm = torch.empty_like(x)
-        kernels.linear_ex(a, wo.detach(), bias=bo.detach(), residual=x, out=xm)    # (tile kernel with the tail split)
+        kernels.linear_ex(a, wo.detach(), bias=bo.detach(), residual=x, out=xm, drop=dr1)    # (tile kernel with the tail split)
         xn2 = kernels.layernorm(xm, g2.detach(), be2.detach(), ada_scale=det(s2), ada_shift=det(t2), eps=eps)
         pre = torch.empty(B * T, w1.shape[0], device=dev, dtype=torch.float32)
         hid = torch.empty_like(pre)
-        kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=_FFN_FWD_ACT[0])  # pre := gelu'
+        if drf is not None and _FFN_FWD_ACT[0] != kernels.ACT_GELU_D:
+            raise _lib.VhError('FeedForward dropout rides on the (ACT_GELU_D, ACT_MUL) activation pair')
+        kernels.linear_ex(xn2, w1.detach(), bias=b1.detach(), out=hid, pre_out=pre, act=_FFN_FWD_ACT[0], drop=drf)  # pre := gelu' (x field)
         y = torch.empty_like(x)
-        kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=xm, out=y)
+        kernels.linear_ex(hid, w2.detach(), bias=b2.detach(), residual=xm, out=y, drop=dr2)
+        M = B * T
+        dropout.record(f'layer{idx}.dropout1', dr1, M, d)
+        dropout.record(f'layer{idx}.ffn.dropout', drf, M, w1.shape[0])
+        dropout.record(f'layer{idx}.dropout2', dr2, M, d)
         ctx.save_for_backward(x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2)
         ctx.meta = meta
         ctx.returns_ada = ada_all is not None
@@ -447,23 +477,34 @@ class EncoderLayerFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, xn1, q, k, v, a, lse2, xm, xn2, pre, hid, wqkv, wo, bo, g1, be1, g2, be2, w1, b1, w2, b2 = ctx.saved_tensors
-        B, T, h, spec, eps, wts, below_b2, ada, ada_grad = ctx.meta
+        B, T, h, spec, eps, wts, below_b2, ada, ada_grad, sp, idx = ctx.meta
         s1, _, s2, _ = ada if ada is not None else (None, None, None, None)
         dst1, dst2, ada_grads = ada_grad if ada_grad is not None else (None, None, None)
+        dr1, _, dr2 = sp.drops.layer(idx)
+        below_dr2 = sp.drops.layer(idx - 1)[2] if idx > 0 else None
         d = x.shape[1]
         dy = dy.contiguous()
         wqkv_t, wo_t, w1_t, w2_t = wts
         det = lambda p: None if p is None else p.detach().contiguous()   # noqa: E731
-        # ---- FeedForward
+        # ---- FeedForward: its branch sits under dropout2, so its products read dY under that field (written by the layer
+        # above's norm1 backward next to dY itself; the top layer — or a dY autograd re-made — gets it from one launch here)
+        ahead_dy = sp.dy_drop.pop(idx, None)
+        db2 = sp.bias_ahead.pop(idx, None)                                 # the layer above summed (dropped) dY's columns already
+        dyd = dy
+        if dr2 is not None:
+            if ahead_dy is not None and ahead_dy[0].data_ptr() == dy.data_ptr():
+                dyd = ahead_dy[1]
+            else:
+                dyd = dropout.apply_raw(dy, dr2)
+                db2 = None
         dw2 = optim.grad_out(w2)
-        kernels.gemm_tn(dy, hid, out=dw2)                                  # dW2 = dY^T . hid
-        db2 = _BIAS_GRAD_AHEAD.pop(id(b2), None)                           # the layer above summed dY's columns already
+        kernels.gemm_tn(dyd, hid, out=dw2)                                 # dW2 = dY^T . hid
         if db2 is None:
-            db2 = _colsum(dy, b2)
+            db2 = _colsum(dyd, b2)
         dpre = torch.empty_like(pre)                                       # (dY . W2) * gelu'(pre), + its column sums = db1
         fold = pre.shape[1] % 128 == 0                                     # (whole 128-column tiles)
         db1 = optim.grad_out(b1, zero=True) if fold else None
-        kernels.linear_ex(dy, w2_t, residual=pre, out=dpre, act=_FFN_FWD_ACT[1], K=w2_t.shape[1], colsum=db1)
+        kernels.linear_ex(dyd, w2_t, residual=pre, out=dpre, act=_FFN_FWD_ACT[1], K=w2_t.shape[1], colsum=db1)
         if not fold:
             db1 = _colsum(dpre, b1)
         dw1 = optim.grad_out(w1)
@@ -472,12 +513,13 @@ class EncoderLayerFn(torch.autograd.Function):
         kernels.linear_ex(dpre, w1_t, out=dxn2, K=w1_t.shape[1])
         # ---- norm2 (+ the residual branch's dY, + the out-projection's bias gradient = column sums of the result)
         dbo = optim.grad_out(bo, zero=True)
-        dxm, dg2, dbe2 = _ln_bwd(xm, g2, be2, det(s2), dxn2, dy, dbo, eps, dst2)
-        # ---- out-projection
+        dxm, dg2, dbe2, dxm_d = _ln_bwd(xm, g2, be2, det(s2), dxn2, dy, dbo, eps, dst2, drop=dr1)
+        # ---- out-projection (under dropout1: the dropped copy of the same launch)
+        dbr = dxm if dxm_d is None else dxm_d
         dwo = optim.grad_out(wo)
-        kernels.gemm_tn(dxm, a, out=dwo)
+        kernels.gemm_tn(dbr, a, out=dwo)
         da = torch.empty_like(x)
-        kernels.linear_ex(dxm, wo_t, out=da, K=wo_t.shape[1])
+        kernels.linear_ex(dbr, wo_t, out=da, K=wo_t.shape[1])
         # ---- attention core + QKV projection
         dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
         kernels.attn_rows_bwd(q, k, v, a, da, lse2, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, T, **spec)
@@ -487,9 +529,11 @@ class EncoderLayerFn(torch.autograd.Function):
         kernels.linear_ex(dqkv, wqkv_t, out=dxn1, K=wqkv_t.shape[1])
         # ---- norm1 (+ the residual branch's gradient; + the bias gradient of the layer below's linear_2)
         ahead = optim.grad_out(below_b2, zero=True) if below_b2 is not None else None
-        dx, dg1, dbe1 = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps, dst1)
+        dx, dg1, dbe1, dx_d = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps, dst1, drop=below_dr2)
         if ahead is not None:
-            _BIAS_GRAD_AHEAD[id(below_b2)] = ahead
+            sp.bias_ahead[idx - 1] = ahead
+        if dx_d is not None:
+            sp.dy_drop[idx - 1] = (dx, dx_d)
         dada = ada_grads if ctx.returns_ada else None            # the whole stack's buffer, complete once layer 0 is done
         return (dx, None, dwqkv, dwo, dbo, dg1, dbe1, dg2, dbe2, dw1, db1, dw2, db2, dada)
 
@@ -503,8 +547,9 @@ def layer_norm(x, gamma, beta, s=None, t=None, eps=1e-5):
 
 
 def encoder_layer_train(layer, x, B, T, spec, embedding=None):
-    """One pre-norm block on x (B*T, d) with a full autograd graph (modules.py:240-280).
-    Dropout (training mode, p > 0) uses torch's device RNG, as the reference does."""
+    """One pre-norm block on x (B*T, d) with a full autograd graph of separate nodes (modules.py:240-280): the form the
+    shapes the fused node does not serve take (and the 'materialized' attention backward).  Dropout (training mode,
+    p > 0): free-standing fields through vh_dropout (dropout.apply)."""
     cfg = layer.config
     at, ff = layer.self_attn, layer.ffn
 
@@ -517,7 +562,7 @@ def encoder_layer_train(layer, x, B, T, spec, embedding=None):
     a = QkvAttentionFn.apply(norm(layer.norm1, x), at.qkv.weight, B, T, at.n_heads, spec)
     d1, d2 = layer.dropout1, layer.dropout2
     if d1.training and d1.p > 0:
-        x = x + d1(linear(a, at.out.weight, at.out.bias))
+        x = x + dropout.apply(d1, linear(a, at.out.weight, at.out.bias))
     else:
         x = linear(a, at.out.weight, at.out.bias, residual=x)
     ffn_drop = ff.dropout.training and ff.dropout.p > 0
@@ -527,9 +572,9 @@ def encoder_layer_train(layer, x, B, T, spec, embedding=None):
                            ff.linear_2.bias, x)
     hid = GeluFn.apply(linear(norm(layer.norm2, x), ff.linear_1.weight, ff.linear_1.bias))
     if ffn_drop:
-        hid = ff.dropout(hid)
+        hid = dropout.apply(ff.dropout, hid)
     if res_drop:
-        x = x + d2(linear(hid, ff.linear_2.weight, ff.linear_2.bias))
+        x = x + dropout.apply(d2, linear(hid, ff.linear_2.weight, ff.linear_2.bias))
     else:
         x = linear(hid, ff.linear_2.weight, ff.linear_2.bias, residual=x)
     return x
@@ -559,13 +604,12 @@ def _stack_transposes(transformer):
 def transformer_train(transformer, x, B, T, spec, embedding=None):
     layers = list(transformer.layers)
     cfg = transformer.hparams
-    fused = (ATTENTION_BACKWARD == 'flash' and cfg.dim_feedforward % 32 == 0 and cfg.d_model % 32 == 0
-             and not any(m.training and m.p > 0 for l in layers for m in (l.dropout1, l.dropout2, l.ffn.dropout)))
+    fused = ATTENTION_BACKWARD == 'flash' and cfg.dim_feedforward % 32 == 0 and cfg.d_model % 32 == 0
     if not fused:
         for layer in layers:
             x = encoder_layer_train(layer, x, B, T, spec, embedding)
         return x
-    _BIAS_GRAD_AHEAD.clear()
+    sp = _StackPass(dropout.StackDropout(layers))           # one seed draw per forward; the fields of every layer
     wts = _stack_transposes(transformer)
     ada_all = ada_vals = ada_grads = None
     d = cfg.d_model
@@ -586,7 +630,7 @@ def transformer_train(transformer, x, B, T, spec, embedding=None):
             av, gv = ada_vals[2 * i:2 * i + 2].view(2, 2, d), ada_grads[2 * i:2 * i + 2].view(2, 2, d)
             ada = (av[0, 0], av[0, 1], av[1, 0], av[1, 1])              # (scale, shift) of norm1, of norm2
             ada_grad = (gv[0], gv[1], ada_grads)
-        meta = (B, T, at.n_heads, spec, layer.norm1.eps, wts[i], below_b2, ada, ada_grad)
+        meta = (B, T, at.n_heads, spec, layer.norm1.eps, wts[i], below_b2, ada, ada_grad, sp, i)
         x = EncoderLayerFn.apply(x, meta, at.qkv.weight, at.out.weight, at.out.bias, n1.weight, n1.bias, n2.weight,
                                  n2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias,
                                  ada_all if i == 0 else None)

@@ -15,7 +15,7 @@ __global__ __launch_bounds__(256) void embed_sum_pe_kernel(
     const int64_t* __restrict__ ids, int64_t ids_bs, int64_t ids_ts, int64_t ids_js, TablePtrs tabs,
     int n_tables, const float* __restrict__ pe, int pos0, const int32_t* __restrict__ lens,
     float* __restrict__ out, int64_t out_bs, int out_t0, int T, int d, int32_t* __restrict__ err_flag,
-    const int32_t* __restrict__ row_pos0, const int32_t* __restrict__ row_t0) {
+    const int32_t* __restrict__ row_pos0, const int32_t* __restrict__ row_t0, DropArgs drop) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
@@ -37,13 +37,17 @@ __global__ __launch_bounds__(256) void embed_sum_pe_kernel(
     if (bad && err_flag && lane == 0) atomicOr(err_flag, VH_DEVERR_EMBED_ID);
     float* orow = out + b * out_bs + (int64_t)(out_t0 + t) * d;
     const float* prow = pe ? pe + (int64_t)(pos0 + t) * d : nullptr;
+    // dropout after the position add (modules.py:80): the field's row is this row's index in `out`
+    const uint32_t frow = (uint32_t)((b * out_bs) / d + out_t0 + t);
     for (int c = lane * 4; c < d; c += 256) {
         f32x4 acc = prow ? ld4(prow + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 e = ld4(tabs.t[0] + row[0] * d + c);
         // sum the codebooks first, then add the position row: same order as the reference
         // (emb0 + emb1 + ... then + pe), so fp32 rounding matches op for op.
         for (int j = 1; j < n_tables; ++j) e += ld4(tabs.t[j] + row[j] * d + c);
-        st4(orow + c, e + acc);
+        e += acc;
+        if (drop.thresh) e = e * vh_dropmul4(drop, frow, (uint32_t)c >> 2);
+        st4(orow + c, e);
     }
 }
 
@@ -51,7 +55,8 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
                                int64_t ids_jstride, const float* const* tables, const int32_t* vocab,
                                int n_tables, const float* pe, int pos0, const int32_t* lens, float* out,
                                int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
-                               const int32_t* row_pos0, const int32_t* row_t0, void* stream) {
+                               const int32_t* row_pos0, const int32_t* row_t0, const vh_dropout_spec* drop,
+                               void* stream) {
     VH_REQUIRE(ids && tables && vocab && out, VH_EINVAL, "vh_embed_sum_pe: null pointer");
     VH_REQUIRE(n_tables >= 1 && n_tables <= VH_MAX_TABLES, VH_EINVAL,
                "vh_embed_sum_pe: n_tables=%d not in 1..%d", n_tables, VH_MAX_TABLES);
@@ -59,6 +64,11 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
                "vh_embed_sum_pe: bad dims B=%d T=%d d=%d (d must be a multiple of 4)", B, T, d);
     VH_REQUIRE(vh_aligned16(out) && (!pe || vh_aligned16(pe)) && out_bstride % 4 == 0, VH_EALIGN,
                "vh_embed_sum_pe: out/pe must be 16-byte aligned");
+    DropArgs da;
+    VH_REQUIRE(VH_DROP_OK(drop), VH_EINVAL, "vh_embed_sum_pe: dropout p must be in [0, 1)");
+    if (vh_drop_args(drop, &da))
+        VH_REQUIRE(out_bstride % d == 0 && (int64_t)B * (out_bstride / d) < (1ll << 32), VH_EINVAL,
+                   "vh_embed_sum_pe: dropout needs out_bstride %% d == 0");
     if (B == 0 || T == 0) return VH_OK;
     TablePtrs tp{};
     for (int j = 0; j < n_tables; ++j) {
@@ -71,8 +81,77 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
     dim3 grid((T + 3) / 4, B);
     hipLaunchKernelGGL(embed_sum_pe_kernel, grid, dim3(256), 0, (hipStream_t)stream, ids,
                        ids_bstride, ids_tstride, ids_jstride, tp, n_tables, pe, pos0, lens, out,
-                       out_bstride, out_t0, T, d, err_flag, row_pos0, row_t0);
+                       out_bstride, out_t0, T, d, err_flag, row_pos0, row_t0, da);
     VH_CHECK_LAUNCH("vh_embed_sum_pe");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Free-standing dropout (a module-level nn.Dropout outside the fused training step) and the field itself.
+// One float4 per thread and Philox call; rows x cols/4 work items.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out,
+                                                      int ldo, uint8_t* __restrict__ keep, int64_t rows, int c4n,
+                                                      DropArgs drop) {
+    const int64_t n = rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c4n;
+        const int c4 = (int)(i - r * c4n);
+        const f32x4 m = vh_dropmul4(drop, (uint32_t)r, (uint32_t)c4);
+        if (keep) {
+            *reinterpret_cast<uint32_t*>(keep + i * 4) = (m.x != 0.f ? 1u : 0u) | (m.y != 0.f ? 0x100u : 0u) |
+                                                         (m.z != 0.f ? 0x10000u : 0u) | (m.w != 0.f ? 0x1000000u : 0u);
+        } else {
+            st4(out + r * ldo + 4 * c4, ld4(x + r * ldx + 4 * c4) * m);
+        }
+    }
+}
+
+extern "C" int vh_dropout(const float* x, int ldx, float* out, int ldo, int64_t rows, int cols,
+                          const vh_dropout_spec* spec, void* stream) {
+    VH_REQUIRE(x && out && rows >= 0 && rows < (1ll << 32) && cols > 0 && cols % 4 == 0 && ldx >= cols && ldo >= cols &&
+                   ldx % 4 == 0 && ldo % 4 == 0,
+               VH_EINVAL, "vh_dropout: bad dims rows=%lld cols=%d (cols and strides multiples of 4)", (long long)rows, cols);
+    VH_REQUIRE(vh_aligned16(x) && vh_aligned16(out), VH_EALIGN, "vh_dropout: pointers must be 16-byte aligned");
+    VH_REQUIRE(VH_DROP_OK(spec), VH_EINVAL, "vh_dropout: p must be in [0, 1)");
+    if (rows == 0) return VH_OK;
+    DropArgs da;
+    hipStream_t st = (hipStream_t)stream;
+    if (!vh_drop_args(spec, &da)) {                      // p == 0: the identity
+        if (x != out && hipMemcpy2DAsync(out, (size_t)ldo * 4, x, (size_t)ldx * 4, (size_t)cols * 4, (size_t)rows,
+                                         hipMemcpyDeviceToDevice, st) != hipSuccess) {
+            vh_set_error("vh_dropout: copy failed");
+            return VH_ELAUNCH;
+        }
+        return VH_OK;
+    }
+    const int64_t n = rows * (cols / 4);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, st, x, ldx, out, ldo, (uint8_t*)nullptr, rows, cols / 4, da);
+    VH_CHECK_LAUNCH("vh_dropout");
+    return VH_OK;
+}
+
+extern "C" int vh_dropout_mask(uint8_t* keep, int64_t rows, int cols, const vh_dropout_spec* spec, void* stream) {
+    VH_REQUIRE(keep && rows >= 0 && rows < (1ll << 32) && cols > 0 && cols % 4 == 0, VH_EINVAL,
+               "vh_dropout_mask: bad dims rows=%lld cols=%d", (long long)rows, cols);
+    VH_REQUIRE((reinterpret_cast<uintptr_t>(keep) & 3u) == 0, VH_EALIGN, "vh_dropout_mask: keep must be 4-byte aligned");
+    VH_REQUIRE(VH_DROP_OK(spec), VH_EINVAL, "vh_dropout_mask: p must be in [0, 1)");
+    if (rows == 0) return VH_OK;
+    DropArgs da;
+    hipStream_t st = (hipStream_t)stream;
+    if (!vh_drop_args(spec, &da)) {
+        if (hipMemsetAsync(keep, 1, (size_t)rows * cols, st) != hipSuccess) {
+            vh_set_error("vh_dropout_mask: memset failed");
+            return VH_ELAUNCH;
+        }
+        return VH_OK;
+    }
+    const int64_t n = rows * (cols / 4);
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(dropout_kernel, dim3(blocks), dim3(256), 0, st, (const float*)nullptr, 0, (float*)nullptr, 0, keep,
+                       rows, cols / 4, da);
+    VH_CHECK_LAUNCH("vh_dropout_mask");
     return VH_OK;
 }
 

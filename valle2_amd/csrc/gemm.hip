@@ -44,6 +44,7 @@ struct GemmArgs {
     float* colsum;  // training backward (EPI_PLAIN, tile kernels): += column sums of the stored output (a bias gradient)
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
+    DropArgs drop;  // training forward (EPI_PLAIN, LDS-DMA tile kernel): out = dropout(act(acc + bias)) + residual
 #ifdef VH_STAMPS
     long long* dbg;  // diagnostic build only (tools/probe_skinny.hip): per-wave phase stamps
 #endif
@@ -226,7 +227,9 @@ __device__ __forceinline__ void tile_colsum(const GemmArgs& a, float* ct, f32x4 
 
 // ct: 128 x 132 floats of LDS, free (the main loop ended on a barrier).  D reg e of tile (mt,nt) holds row
 // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
-template <int EPI>
+// DROP (EPI_PLAIN, act NONE / GELU_ERF / GELU_ERF_D): the dropout field of a.drop multiplies act(acc + bias) — and the
+// stored GELU derivative — before the residual is added.  A template parameter: the dropout-off kernels stay as they were.
+template <int EPI, bool DROP = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&acc)[2][2], float* ct, int m0, int n0,
                                               int tid, const TileEpi& e) {
     constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
@@ -259,9 +262,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             f32x4 v = ld4(cr + it * 8 * LDC);
             if (EPI == EPI_PLAIN) {
                 v += e.bias4;
+                f32x4 dm;
+                if (DROP) dm = vh_dropmul4(a.drop, (uint32_t)(m0 + erow + 8 * it), (uint32_t)(en >> 2));
                 if (a.act == VH_ACT_GELU_ERF_D) {               // GELU out, its derivative to aux (one erf for both)
                     f32x4 dv;
                     v = gelu_and_grad4(v, dv);
+                    if (DROP) dv = dv * dm;
                     st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), dv);
                 } else if (xbase) {
                     st4((float*)(xbase + (int64_t)it * 8 * a.ldx * 4 + xoff), v);           // pre-activation
@@ -270,6 +276,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
                     const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
                     v = f32x4{g0.x, g0.y, g1.x, g1.y};
                 }
+                if (DROP) v = v * dm;
                 if (a.act == VH_ACT_GELU_BWD) {                 // dY through the activation: acc * gelu'(pre)
                     const f32x4 p = e.resv[it];
                     v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
@@ -340,9 +347,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             }
         } else if (ecol_full) {
             v += e.bias4;
+            f32x4 dm;
+            if (DROP) dm = vh_dropmul4(a.drop, (uint32_t)m, (uint32_t)(en >> 2));
             if (a.act == VH_ACT_GELU_ERF_D) {
                 f32x4 dv;
                 v = gelu_and_grad4(v, dv);
+                if (DROP) dv = dv * dm;
                 st4(a.aux + (int64_t)m * a.ldx + en, dv);
             } else if (a.aux) {
                 st4(a.aux + (int64_t)m * a.ldx + en, v);
@@ -350,6 +360,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             if (a.act == VH_ACT_GELU_ERF) {
                 v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
             }
+            if (DROP) v = v * dm;
             if (a.act == VH_ACT_GELU_BWD) {
                 const f32x4 p = e.resv[it];
                 v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
@@ -524,7 +535,7 @@ struct TailSplit {
     float* ws;
 };
 
-template <int EPI>
+template <int EPI, bool DROP = false>
 __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int tiles_m, int tiles_n, TailSplit ts) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];  // [buf][A|W][row][32] (+ slack for the epilogue)
     // Outside the main loop the wave runs at raised priority: its scalar/vector bookkeeping competes for issue slots
@@ -705,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
         p.out = ts.ws + (int64_t)unit * TM * TN - ((int64_t)m0 * TN + n0);
         tile_epilogue<EPI_PARTIAL>(p, acc, &lds[0][0][0], m0, n0, tid, epi);
     } else {
-        tile_epilogue<EPI>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
+        tile_epilogue<EPI, DROP>(a, acc, &lds[0][0][0], m0, n0, tid, epi);
     }
 #ifdef VH_TILE_PROBE
     if ((tid & 63) == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + (tid >> 6)) * 200 + 197] = clock64();
@@ -1151,16 +1162,19 @@ __global__ __launch_bounds__(256) void tile_tail_fixup_kernel(GemmArgs a, TailSp
         f32x4 v = ld4(slab + it * 8 * TN);
         for (int c = 1; c < ts.split; ++c) v += ld4(slab + (int64_t)c * TM * TN + it * 8 * TN);
         v += bias4;
+        f32x4 dm = {1.f, 1.f, 1.f, 1.f};
+        if (a.drop.thresh) dm = vh_dropmul4(a.drop, (uint32_t)m, (uint32_t)(en >> 2));
         if (a.act == VH_ACT_GELU_ERF_D) {
             f32x4 dv;
             v = gelu_and_grad4(v, dv);
-            st4(a.aux + (int64_t)m * a.ldx + en, dv);
+            st4(a.aux + (int64_t)m * a.ldx + en, dv * dm);
         } else if (a.aux) {
             st4(a.aux + (int64_t)m * a.ldx + en, v);
         }
         if (a.act == VH_ACT_GELU_ERF) {
             v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
         }
+        if (a.drop.thresh) v = v * dm;
         if (a.act == VH_ACT_GELU_BWD) {
             const f32x4 p = ld4(a.res + (int64_t)m * a.ldr + en);
             v = f32x4{v.x * gelu_grad(p.x), v.y * gelu_grad(p.y), v.z * gelu_grad(p.z), v.w * gelu_grad(p.w)};
@@ -1261,7 +1275,7 @@ template <int EPI>
 static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hipStream_t s, float* tail_ws = nullptr,
                        size_t tail_ws_bytes = 0) {
     if (a.M == 0) return VH_OK;
-    const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act >= VH_ACT_GELU_BWD;   // tile-kernel epilogues only
+    const bool train_epi = a.aux != nullptr || a.colsum != nullptr || a.act >= VH_ACT_GELU_BWD || a.drop.thresh != 0;   // tile-kernel epilogues only
     if (a.M <= 64 && !train_epi) {
         const int mt = (a.M + 15) / 16;
         dim3 grid((a.N + 15) / 16);
@@ -1354,8 +1368,12 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
                     ts = TailSplit{n_whole, split, a.K / split, tail_ws};
             }
             const int tail = tm * tn - ts.n_whole;
-            hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(ts.n_whole + tail * ts.split), dim3(256), 0, s, a, tm, tn,
-                               ts);
+            if (EPI == EPI_PLAIN && a.drop.thresh)
+                hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI, EPI == EPI_PLAIN>), dim3(ts.n_whole + tail * ts.split), dim3(256), 0,
+                                   s, a, tm, tn, ts);
+            else
+                hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI>), dim3(ts.n_whole + tail * ts.split), dim3(256), 0, s, a, tm, tn,
+                                   ts);
             if (tail) hipLaunchKernelGGL(tile_tail_fixup_kernel, dim3(tail * 4), dim3(256), 0, s, a, ts, tn);
         } else {
             hipLaunchKernelGGL((gemm_tile_kernel<EPI>), dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
@@ -1382,12 +1400,19 @@ extern "C" int vh_linear(const float* A, int lda, const float* W, const float* b
 
 extern "C" int vh_linear_ex(const float* A, int lda, const float* W, const float* bias, const float* residual,
                             int ldr, float* out, int ldo, float* pre_out, int ldp, float* dcolsum, int M, int N, int K,
-                            int act, void* workspace, size_t workspace_bytes, void* stream) {
+                            int act, const vh_dropout_spec* drop, void* workspace, size_t workspace_bytes, void* stream) {
     GemmArgs a{};
     a.A = A; a.lda = lda; a.W = W; a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
     a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = act; a.k_len = K; a.aux = pre_out; a.ldx = ldp;
     a.colsum = dcolsum;
     VH_REQUIRE(!dcolsum || N % 128 == 0, VH_EUNSUPPORTED, "vh_linear_ex: dcolsum needs N %% 128 == 0 (N=%d)", N);
+    VH_REQUIRE(VH_DROP_OK(drop), VH_EINVAL, "vh_linear_ex: dropout p must be in [0, 1)");
+    if (vh_drop_args(drop, &a.drop)) {
+        VH_REQUIRE(act == VH_ACT_NONE || act == VH_ACT_GELU_ERF || act == VH_ACT_GELU_ERF_D, VH_EINVAL,
+                   "vh_linear_ex: dropout goes with act NONE / GELU_ERF / GELU_ERF_D (act=%d)", act);
+        VH_REQUIRE(N % 4 == 0 && K % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1, VH_EUNSUPPORTED,
+                   "vh_linear_ex: dropout needs N %% 4 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+    }
     LnFuse ln{};
     VH_REQUIRE(act >= VH_ACT_NONE && act <= VH_ACT_MUL, VH_EINVAL, "vh_linear_ex: act=%d", act);
     VH_REQUIRE((act != VH_ACT_GELU_BWD && act != VH_ACT_MUL) || (residual && !bias && !pre_out), VH_EINVAL,
@@ -1532,7 +1557,7 @@ extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float
                             int act, void* workspace, size_t workspace_bytes, void* stream) {
     const int splits = splitk_plan(M, N, K);
     if (!splits && workspace && M > 64 && vh_linear_ex_ws_bytes(M, N, K))   // many tiles with a short tail: split the tail
-        return vh_linear_ex(A, lda, W, bias, residual, ldr, out, ldo, nullptr, 0, nullptr, M, N, K, act, workspace,
+        return vh_linear_ex(A, lda, W, bias, residual, ldr, out, ldo, nullptr, 0, nullptr, M, N, K, act, nullptr, workspace,
                             workspace_bytes, stream);
     if (!splits || !workspace)
         return vh_linear(A, lda, W, bias, residual, ldr, out, ldo, M, N, K, act, nullptr, nullptr,

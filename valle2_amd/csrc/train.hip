@@ -20,12 +20,15 @@ __device__ __forceinline__ float hsum4(f32x4 v) { return (v.x + v.y) + (v.z + v.
 // column per WORKGROUP at the end.
 // ---------------------------------------------------------------------------------------------
 #define LNB_WAVES 8
-template <int NV>
+// DROP: the dropped copy of dx (the gradient of the branch under dropout1 / dropout2, modules.py:277-278) leaves in the
+// same pass and the column sums are taken of IT; a template parameter so that the dropout-off kernel keeps its registers.
+template <int NV, bool DROP>
 __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ s, const float* __restrict__ dy, float* __restrict__ dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ds,
-    float* __restrict__ dt, const float* __restrict__ dres, float* __restrict__ dcol, int rows, int d, float eps) {
+    float* __restrict__ dt, const float* __restrict__ dres, float* __restrict__ dcol, int rows, int d, float eps,
+    float* __restrict__ dx_drop, DropArgs drop) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * LNB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * LNB_WAVES;
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -107,7 +110,13 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(
                 // by a separate elementwise launch (x feeds the norm AND the residual add, modules.py:271-279)
                 const f32x4 o = (g[i] - m1 - v[i] * m2) * rstd + r[i];
                 st4(dx + (int64_t)row * d + c, o);
-                if (dcol) ac[i] += o;
+                if (DROP) {
+                    const f32x4 od = o * vh_dropmul4(drop, (uint32_t)row, (uint32_t)(lane + 64 * i));
+                    st4(dx_drop + (int64_t)row * d + c, od);
+                    if (dcol) ac[i] += od;
+                } else if (dcol) {
+                    ac[i] += o;
+                }
             }
         }
     }
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(LNB_WAVES * 64) void layernorm_bwd_kernel(
 extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float* beta,
                                 const float* ada_scale, const float* dy, float* dx, float* dgamma,
                                 float* dbeta, float* dscale, float* dshift, const float* dres, float* dcolsum,
-                                int rows, int d, float eps, void* stream) {
+                                float* dx_drop, const vh_dropout_spec* drop, int rows, int d, float eps, void* stream) {
     VH_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, VH_EINVAL, "vh_layernorm_bwd: null pointer");
     VH_REQUIRE(!ada_scale || (beta && dscale && dshift), VH_EINVAL,
                "vh_layernorm_bwd: adaptive form needs beta, dscale, dshift");
@@ -149,12 +158,24 @@ extern "C" int vh_layernorm_bwd(const float* x, const float* gamma, const float*
     VH_REQUIRE(vh_aligned16(x) && vh_aligned16(dy) && vh_aligned16(dx) && vh_aligned16(gamma) &&
                    vh_aligned16(beta) && vh_aligned16(ada_scale) && vh_aligned16(dres),
                VH_EALIGN, "vh_layernorm_bwd: pointers must be 16-byte aligned");
+    VH_REQUIRE(VH_DROP_OK(drop) && vh_aligned16(dx_drop), VH_EINVAL, "vh_layernorm_bwd: dropout p in [0, 1), dx_drop aligned");
+    DropArgs da;
+    const bool dropped = vh_drop_args(drop, &da);
+    VH_REQUIRE(dropped == (dx_drop != nullptr), VH_EINVAL, "vh_layernorm_bwd: dx_drop and a dropout spec with p > 0 go together");
     if (rows == 0) return VH_OK;
     const int blocks = rows < LNB_WAVES * 256 ? (rows + LNB_WAVES - 1) / LNB_WAVES : 256;
     hipStream_t st = (hipStream_t)stream;
-#define LNB(NV)                                                                                    \
-    hipLaunchKernelGGL(layernorm_bwd_kernel<NV>, dim3(blocks), dim3(LNB_WAVES * 64), 0, st, x, gamma, beta,   \
-                       ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, dres, dcolsum, rows, d, eps)
+#define LNB(NV)                                                                                                        \
+    do {                                                                                                               \
+        if (dropped)                                                                                                   \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, true>), dim3(blocks), dim3(LNB_WAVES * 64), 0, st, x, gamma,  \
+                               beta, ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, dres, dcolsum, rows, d, eps,    \
+                               dx_drop, da);                                                                           \
+        else                                                                                                           \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<NV, false>), dim3(blocks), dim3(LNB_WAVES * 64), 0, st, x, gamma, \
+                               beta, ada_scale, dy, dx, dgamma, dbeta, dscale, dshift, dres, dcolsum, rows, d, eps,    \
+                               dx_drop, da);                                                                           \
+    } while (0)
     if (d <= 256) LNB(1);
     else if (d <= 512) LNB(2);
     else if (d <= 1024) LNB(4);
@@ -350,7 +371,7 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
                                                         int64_t ids_ts, const float* __restrict__ dout,
                                                         int64_t dout_bs, int t0, float* __restrict__ dtable,
                                                         int vocab, int T, int d,
-                                                        int32_t* __restrict__ err_flag) {
+                                                        int32_t* __restrict__ err_flag, DropArgs drop) {
     __shared__ int sid[EMB_RUN];                                     // the run's table rows, -1 = skip (bad id / beyond T)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int t_begin = blockIdx.x * EMB_RUN;
@@ -368,10 +389,15 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
     }
     __syncthreads();
     const float* src = dout + b * dout_bs + (int64_t)(t0 + t_begin) * d;
+    const uint32_t frow0 = (uint32_t)((b * dout_bs) / d + t0 + t_begin);     // the forward's dropout field: row = row of dout
     for (int c = tid; c < d; c += 256) {
         float v[EMB_RUN];
 #pragma unroll
         for (int i = 0; i < EMB_RUN; ++i) v[i] = sid[i] >= 0 ? src[(int64_t)i * d + c] : 0.f;   // all in flight at once
+        if (drop.thresh) {                               // (a thread owns a column: one of the four words of a Philox call)
+#pragma unroll
+            for (int i = 0; i < EMB_RUN; ++i) v[i] *= vh_dropmul4(drop, frow0 + i, (uint32_t)c >> 2)[c & 3];
+        }
         int cur = -1;
         float acc = 0.f;
 #pragma unroll
@@ -391,12 +417,16 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
 
 extern "C" int vh_embed_bwd(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride,
                             const float* dout, int64_t dout_bstride, int out_t0, float* dtable, int vocab,
-                            int B, int T, int d, int32_t* err_flag, void* stream) {
+                            int B, int T, int d, int32_t* err_flag, const vh_dropout_spec* drop, void* stream) {
     VH_REQUIRE(ids && dout && dtable && vocab > 0 && B >= 0 && T >= 0 && d > 0, VH_EINVAL,
                "vh_embed_bwd: bad args");
+    DropArgs da;
+    VH_REQUIRE(VH_DROP_OK(drop), VH_EINVAL, "vh_embed_bwd: dropout p must be in [0, 1)");
+    if (vh_drop_args(drop, &da))
+        VH_REQUIRE(dout_bstride % d == 0 && d % 4 == 0, VH_EINVAL, "vh_embed_bwd: dropout needs dout_bstride %% d == 0");
     if (B == 0 || T == 0) return VH_OK;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3((T + EMB_RUN - 1) / EMB_RUN, B), dim3(256), 0, (hipStream_t)stream, ids,
-                       ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, vocab, T, d, err_flag);
+                       ids_bstride, ids_tstride, dout, dout_bstride, out_t0, dtable, vocab, T, d, err_flag, da);
     VH_CHECK_LAUNCH("vh_embed_bwd");
     return VH_OK;
 }

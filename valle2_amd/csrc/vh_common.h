@@ -177,6 +177,65 @@ __device__ __forceinline__ f32x4 gelu_and_grad4(f32x4 v, f32x4& d) {
     return g;
 }
 
+// ---- dropout field (include/valle_hip.h, vh_dropout_spec) ---------------------------------------------------------
+// Philox4x32 with 7 rounds (the fewest that pass BigCrush in Salmon et al., SC'11 table 2; 10 is the library default
+// with its safety margin — a dropout mask needs neither cryptographic nor Monte-Carlo-grade streams, and every round is
+// two 32x32->64 multiplies in epilogues that share their issue port with the other workgroup's MFMA stream).
+// One call covers 4 consecutive columns of one row: exactly the float4 a lane of the tile epilogue / the row kernels
+// owns, so no lane ever computes bits it throws away.
+struct DropArgs {
+    uint32_t k0, k1;      // key   = seed
+    uint32_t s0, s1;      // counter words 2, 3 = site
+    uint32_t thresh;      // keep iff bits >= thresh (= round(p * 2^32)); 0 = dropout off
+    float scale;          // 1 / (1 - p)
+};
+
+__device__ __forceinline__ void vh_philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0,
+                                                uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (uint32_t)p1;
+    c3 = (uint32_t)p0;
+    c0 = n0;
+    c2 = n2;
+}
+// (written out round by round: a loop here, even a fully unrollable one, kept the 16-row epilogue loop around it from
+// being unrolled, and the epilogue's per-row registers went to scratch)
+__device__ __forceinline__ void vh_philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                                uint32_t k1, uint32_t (&o)[4]) {
+    constexpr uint32_t W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    vh_philox_round(c0, c1, c2, c3, k0, k1);
+    vh_philox_round(c0, c1, c2, c3, k0 + W0, k1 + W1);
+    vh_philox_round(c0, c1, c2, c3, k0 + 2 * W0, k1 + 2 * W1);
+    vh_philox_round(c0, c1, c2, c3, k0 + 3 * W0, k1 + 3 * W1);
+    vh_philox_round(c0, c1, c2, c3, k0 + 4 * W0, k1 + 4 * W1);
+    vh_philox_round(c0, c1, c2, c3, k0 + 5 * W0, k1 + 5 * W1);
+    vh_philox_round(c0, c1, c2, c3, k0 + 6 * W0, k1 + 6 * W1);
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+
+// keep / (1 - p) factors of columns 4 c4 .. 4 c4 + 3 of row `row`
+__device__ __forceinline__ f32x4 vh_dropmul4(const DropArgs& d, uint32_t row, uint32_t c4) {
+    uint32_t b[4];
+    vh_philox4x32_7(c4, row, d.s0, d.s1, d.k0, d.k1, b);
+    return f32x4{b[0] >= d.thresh ? d.scale : 0.f, b[1] >= d.thresh ? d.scale : 0.f,
+                 b[2] >= d.thresh ? d.scale : 0.f, b[3] >= d.thresh ? d.scale : 0.f};
+}
+
+// host: spec -> kernel arguments; returns false (and leaves `a` off) for a NULL spec or p == 0
+static inline bool vh_drop_args(const vh_dropout_spec* spec, DropArgs* a) {
+    *a = DropArgs{0, 0, 0, 0, 0, 1.0f};
+    if (!spec || !(spec->p > 0.f)) return false;
+    a->k0 = (uint32_t)spec->seed; a->k1 = (uint32_t)(spec->seed >> 32);
+    a->s0 = (uint32_t)spec->site; a->s1 = (uint32_t)(spec->site >> 32);
+    double t = (double)spec->p * 4294967296.0 + 0.5;
+    a->thresh = t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+    if (a->thresh == 0) a->thresh = 1;               // a p below 2^-33 still drops something rather than turning off
+    a->scale = (float)(1.0 / (1.0 - (double)spec->p));
+    return true;
+}
+#define VH_DROP_OK(spec) (!(spec) || ((spec)->p >= 0.f && (spec)->p < 1.f))
+
 // LayerNorm parameters that may be fused into an operand load
 struct LnFuse {
     const float* gamma;  // (K) or nullptr → no fused LN

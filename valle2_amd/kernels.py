@@ -24,12 +24,17 @@ def _f32(t, name):
     return t
 
 
-def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None, row_pos0=None, row_t0=None, max_pos=None):
+def _drop_ref(drop):
+    return None if drop is None else C.byref(drop)
+
+
+def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None, row_pos0=None, row_t0=None, max_pos=None, drop=None):
     """out[b, out_t0+t] = sum_j tables[j][ids[b,t,j]] + pe[pos0+t].  ids (B,T) or (B,T,J) int64
     (any strides); tables: list of (vocab,d); pe (P,1,d)|(P,d)|None; out (B,T_out,d).
     lens / row_pos0 / row_t0: device int32 (B) — valid ids per row and per-row overrides of pos0 / out_t0 (a ragged
     batch in one launch); with them the caller vouches, through `max_pos` (largest position + 1 any row reaches) and
-    its own layout, that positions stay inside the table and rows inside `out`."""
+    its own layout, that positions stay inside the table and rows inside `out`.
+    drop: a dropout.spec — the dropout after the position add (modules.py:80), field row = the row's index in `out`."""
     if ids.dtype != torch.int64:
         raise _lib.VhError('ids must be int64')
     if ids.dim() == 2:
@@ -60,7 +65,8 @@ def embed_sum_pe(ids, tables, pe, pos0, out, out_t0=0, lens=None, row_pos0=None,
     check(_lib.lib().vh_embed_sum_pe(
         ids.data_ptr(), ids.stride(0), ids.stride(1), ids.stride(2), arr, vocab, n,
         ptr(_f32(pe, 'pe')), pos0, ptr(lens), ptr(_f32(out, 'out')), out.stride(0), out_t0,
-        B, T, d, ptr(_lib.err_flag(out.device)), ptr(row_pos0), ptr(row_t0), stream()), 'vh_embed_sum_pe')
+        B, T, d, ptr(_lib.err_flag(out.device)), ptr(row_pos0), ptr(row_t0), _drop_ref(drop), stream()),
+        'vh_embed_sum_pe')
     return out
 
 
@@ -375,11 +381,12 @@ def _tail_ws(device, stream_handle, M, N, K):
     return ws
 
 
-def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None, colsum=None):
+def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NONE, K=None, colsum=None, drop=None):
     """vh_linear_ex: out = act(a @ w.T + bias) + residual on the tile kernels whatever M is, with the training
     epilogues (pre_out: also store the pre-activation; ACT_GELU_BWD: out = (a @ w.T) * gelu'(residual)).
     `K` overrides the contraction width (operands whose rows are zero-padded to a multiple of 32).
-    colsum (N,) fp32, N % 128 == 0: += the column sums of `out` (a bias gradient) in the same launch."""
+    colsum (N,) fp32, N % 128 == 0: += the column sums of `out` (a bias gradient) in the same launch.
+    drop: a dropout.spec — out = dropout(act(a @ w.T + bias)) + residual, field indexed by (row, column) of `out`."""
     M = a.shape[0]
     N = w.shape[0]
     K = K or a.shape[1]
@@ -399,7 +406,7 @@ def linear_ex(a, w, bias=None, residual=None, out=None, pre_out=None, act=ACT_NO
         _dev_f32(residual, 'residual') if residual is not None else None,
         residual.stride(0) if residual is not None else 0, _dev_f32(out, 'out'), out.stride(0),
         _dev_f32(pre_out, 'pre_out') if pre_out is not None else None,
-        pre_out.stride(0) if pre_out is not None else 0, ptr(colsum), M, N, K, act, ptr(ws),
+        pre_out.stride(0) if pre_out is not None else 0, ptr(colsum), M, N, K, act, _drop_ref(drop), ptr(ws),
         ws.numel() * 4 if ws is not None else 0, st), 'vh_linear_ex')
     return out
 

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 from einops import rearrange, repeat
 
-from . import _lib, kernels
+from . import _lib, dropout, kernels
 from .engine import KVCache, transformer_forward
 from .synth import sinusoid_table
 from .utils import pad_lens_for_kernel
@@ -123,8 +123,8 @@ def _on_device(forward):
 
 
 def _drop(module: nn.Dropout, x):
-    # dropout is the identity in eval mode / p=0; in training mode it is torch's device RNG
-    return module(x) if (module.training and module.p > 0) else x
+    # the identity in eval mode / p = 0; in training mode a counter-based field through vh_dropout (dropout.py)
+    return dropout.apply(module, x)
 
 
 class TokenEmbedding(nn.Module):
@@ -388,9 +388,9 @@ class EncoderLayer(nn.Module):
                                          kv_cache=kv_cache, use_cache=use_cache,
                                          _ln=self._ln_args(self.norm1, embedding),
                                          _residual=x if fuse1 else None)
-        x = x_attn if fuse1 else x + self.dropout1(x_attn)
+        x = x_attn if fuse1 else x + _drop(self.dropout1, x_attn)
         y = self.ffn(x, _ln=self._ln_args(self.norm2, embedding), _residual=x if fuse2 else None)
-        x = y if fuse2 else x + self.dropout2(y)
+        x = y if fuse2 else x + _drop(self.dropout2, y)
         return x, next_kv
 
     def _get_norm(self):

@@ -20,7 +20,7 @@ from pathlib import Path
 
 import torch
 
-from . import dp, synth
+from . import dp, dropout, synth
 from .config import ConfigValle
 
 
@@ -45,6 +45,8 @@ def train(hparams_fp: Path, model_name: str, batches=None, device=None, log=prin
     torch.manual_seed(config.seed)                       # identical initial weights on every rank
     random.seed(config.seed)                             # and the same NAR stage draw (valle_nar.py:76) on every rank:
     #                                                      the reference calls seed_everything (train_model.py:15)
+    dropout.set_rank(rank)                               # ...but every rank its own dropout fields (the rank is part of a
+    #                                                      field's site id): same seeds, different masks per shard
     model = get_model_class(model_name)(config).to(device).train()
     opt = model.configure_optimizers()                   # FlatAdamW + CosineAnnealingWarmRestarts
     optimizer, scheduler = opt['optimizer'], opt['lr_scheduler']

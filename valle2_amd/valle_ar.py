@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 from torch import optim
 
-from . import _lib, kernels
+from . import _lib, dropout, kernels
 from .engine import ArDecoder, ForwardScratch, KVCache, transformer_forward
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device, device_mirror
 from .utils import get_best_beam
@@ -109,26 +109,17 @@ class ValleAR(_Base):
         tx, ty = int(max(batch['tokens_lens'])), int(max(codes_lens))
         b, d = tokens.shape[0], self.config.d_model
         # PE dropout p = 0.1 is live in train mode whatever config.dropout says (D9).  Both streams' embeddings are written
-        # into ONE buffer (no torch.cat, no strided copies of its gradient); when the two Dropout modules agree (both off,
-        # or both training with one p) a single elementwise dropout over that buffer draws the same Bernoulli field the
-        # reference draws in two calls — only the order of the draws from torch's generator differs
-        drops = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)
-        live = [m.training and m.p > 0 for m in drops]
-        if live[0] == live[1] and (not live[0] or drops[0].p == drops[1].p):
-            x = A.EmbedConcatFn.apply([(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0]),
-                                       (codes[:, :ty], self.audio_position_emb.pe, 0, [1])],
-                                      self.tokens_emb.weight, self.audio_emb.weight)
-            if live[0]:
-                x = torch.nn.functional.dropout(x, drops[0].p, True)
-            x = x.reshape(b * (tx + ty), d)
-        else:
-            xt = A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)
-            xa = A.EmbedSumPeFn.apply(codes[:, :ty], self.audio_position_emb.pe, 0, self.audio_emb.weight)
-            if live[0]:
-                xt = drops[0](xt)
-            if live[1]:
-                xa = drops[1](xa)
-            x = torch.cat((xt, xa), dim=1).reshape(b * (tx + ty), d)
+        # into ONE buffer (no torch.cat, no strided copies of its gradient) and each part's dropout is a field applied by
+        # the gather kernel itself before it stores the row (dropout.py) — the backward regenerates it in the scatter
+        seed = dropout.draw_seed()
+        dr_t = dropout.spec(seed, dropout.site(dropout.PE_TEXT), dropout.live(self.tokens_position_emb.dropout))
+        dr_a = dropout.spec(seed, dropout.site(dropout.PE_AUDIO), dropout.live(self.audio_position_emb.dropout))
+        dropout.record('tokens_position_emb.dropout', dr_t, b * (tx + ty), d)
+        dropout.record('audio_position_emb.dropout', dr_a, b * (tx + ty), d)
+        x = A.EmbedConcatFn.apply([(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0], dr_t),
+                                   (codes[:, :ty], self.audio_position_emb.pe, 0, [1], dr_a)],
+                                  self.tokens_emb.weight, self.audio_emb.weight)
+        x = x.reshape(b * (tx + ty), d)
         kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)
         spec = dict(mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
         x = A.transformer_train(self.transformer, x, b, tx + ty, spec)

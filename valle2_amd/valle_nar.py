@@ -13,7 +13,7 @@ import random
 import torch
 import torch.nn as nn
 
-from . import _lib, kernels
+from . import _lib, dropout, kernels
 from .engine import ForwardScratch, KVCache, transformer_forward
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device
 from .valle_ar import _Base
@@ -113,31 +113,20 @@ class ValleNAR(_Base):
         p = self.prefix_len_of(t)
         tabs = [e.weight for e in self.codes_embs]
         n_stage = max(1, min(stage, q))
-        drops2 = (self.tokens_position_emb.dropout, self.audio_position_emb.dropout)
-        live = [m.training and m.p > 0 for m in drops2]
-        if live[0] == live[1] and (not live[0] or drops2[0].p == drops2[1].p):
-            # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
-            # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds); the PE
-            # dropout (p = 0.1 in train mode, D9) as ONE elementwise dropout over that buffer — the same Bernoulli field
-            # as the reference's per-part calls, drawn in a different order
-            spec = [(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0])]
-            if p:
-                spec.append((codes[:, :p], self.audio_position_emb.pe, 0, list(range(1, 1 + q))))
-            if t > p:
-                spec.append((codes[:, p:], self.audio_position_emb.pe, p, list(range(1, 1 + n_stage))))
-            x = A.EmbedConcatFn.apply(spec, self.tokens_emb.weight, *tabs)
-            if live[0]:
-                x = torch.nn.functional.dropout(x, drops2[0].p, True)
-            x = x.reshape(b * (tx + t), d)
-        else:
-            parts = [A.EmbedSumPeFn.apply(tokens[:, :tx], self.tokens_position_emb.pe, 0, self.tokens_emb.weight)]
-            if p:
-                parts.append(A.EmbedSumPeFn.apply(codes[:, :p], self.audio_position_emb.pe, 0, *tabs))
-            if t > p:
-                parts.append(A.EmbedSumPeFn.apply(codes[:, p:], self.audio_position_emb.pe, p, *tabs[:n_stage]))
-            drops = [self.tokens_position_emb.dropout] + [self.audio_position_emb.dropout] * (len(parts) - 1)
-            parts = [dr(x) if (dr.training and dr.p > 0) else x for dr, x in zip(drops, parts)]
-            x = torch.cat(parts, dim=1).reshape(b * (tx + t), d)
+        # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
+        # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds); the PE
+        # dropouts (p = 0.1 in train mode, D9) are fields applied by the gather kernel before it stores a row
+        seed = dropout.draw_seed()
+        dr_t = dropout.spec(seed, dropout.site(dropout.PE_TEXT), dropout.live(self.tokens_position_emb.dropout))
+        dr_a = dropout.spec(seed, dropout.site(dropout.PE_AUDIO), dropout.live(self.audio_position_emb.dropout))
+        dropout.record('tokens_position_emb.dropout', dr_t, b * (tx + t), d)
+        dropout.record('audio_position_emb.dropout', dr_a, b * (tx + t), d)
+        spec = [(tokens[:, :tx], self.tokens_position_emb.pe, 0, [0], dr_t)]
+        if p:
+            spec.append((codes[:, :p], self.audio_position_emb.pe, 0, list(range(1, 1 + q)), dr_a))
+        if t > p:
+            spec.append((codes[:, p:], self.audio_position_emb.pe, p, list(range(1, 1 + n_stage)), dr_a))
+        x = A.EmbedConcatFn.apply(spec, self.tokens_emb.weight, *tabs).reshape(b * (tx + t), d)
         x = A.transformer_train(self.transformer, x, b, tx + t, dict(mode=kernels.MASK_FULL),
                                 embedding=self.stage_embs[stage - 1].weight)
         z = x.view(b, tx + t, d)[:, tx + p:].reshape(b * (t - p), d)
