@@ -362,8 +362,13 @@ def train_leg(dev, world, rank, small):
     kw = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, batch_size=16)
     if small:
         kw.update(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, batch_size=4)
+    out['dropout_rule'] = ('*_ms_per_step: config.dropout = 0 (PositionalEncoding dropout 0.1 still live in train mode, D9); '
+                           '*_ms_per_step_dropout: the reference default config.dropout = 0.1 (valle/config.py:26) — dropout1 / '
+                           'dropout2 / FeedForward dropout as fields regenerated in the GEMM epilogues and the LayerNorm '
+                           'backward (valle2_amd/dropout.py), same batches')
     for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
-        cfg = ConfigValle(**kw, norm=norm)
+      for p_drop in (0.0, 0.1):
+        cfg = ConfigValle(**dict(kw, dropout=p_drop), norm=norm)
         torch.manual_seed(0)
         model = get_model_class(name)(cfg).to(dev).train()
         opt = model.configure_optimizers()['optimizer']
@@ -395,15 +400,20 @@ def train_leg(dev, world, rank, small):
         torch.cuda.synchronize()
         dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
         key = 'ar' if name == 'ValleAR' else 'nar'
-        out[f'{key}_ms_per_step'] = dt / timed * 1e3
-        out[f'{key}_positions_per_s'] = world * rows / dt          # rank 0's rows x world (shapes are seeded per rank)
-        out[f'{key}_allreduce_bytes'] = 4 * opt.numel if world > 1 else 0
-        # this rank's algorithmic FLOP per step (real positions, 3 x forward) against the fp32 MFMA peak of ONE GPU
-        out[f'{key}_flop_per_step'] = flop / timed
-        out[f'{key}_tflops'] = flop / dt / 1e12
-        out[f'{key}_frac'] = flop / dt / 1e12 / MFMA_F32_PEAK_TF
-        out[f'{key}_frac_padded_positions'] = flop_pad / dt / 1e12 / MFMA_F32_PEAK_TF   # the work the step really runs
-        out[f'{key}_loss'] = float(loss.detach())
+        if p_drop:
+            out[f'{key}_ms_per_step_dropout'] = dt / timed * 1e3
+            out[f'{key}_dropout_over_plain'] = (dt / timed * 1e3) / out[f'{key}_ms_per_step']
+            out[f'{key}_loss_dropout'] = float(loss.detach())
+        else:
+            out[f'{key}_ms_per_step'] = dt / timed * 1e3
+            out[f'{key}_positions_per_s'] = world * rows / dt          # rank 0's rows x world (shapes are seeded per rank)
+            out[f'{key}_allreduce_bytes'] = 4 * opt.numel if world > 1 else 0
+            # this rank's algorithmic FLOP per step (real positions, 3 x forward) against the fp32 MFMA peak of ONE GPU
+            out[f'{key}_flop_per_step'] = flop / timed
+            out[f'{key}_tflops'] = flop / dt / 1e12
+            out[f'{key}_frac'] = flop / dt / 1e12 / MFMA_F32_PEAK_TF
+            out[f'{key}_frac_padded_positions'] = flop_pad / dt / 1e12 / MFMA_F32_PEAK_TF   # the work the step really runs
+            out[f'{key}_loss'] = float(loss.detach())
         reducer.remove()
         del model, opt, reducer
         torch.cuda.empty_cache()

@@ -1,7 +1,8 @@
 """Training-step timing at BASELINE.json configs[3]: 12L/512d AR and NAR forward+backward, per-GPU
 batch 16, LibriTTS-shaped synthetic batches (tokens 40..120, codes 225..900), fp32.  Developer tool
 (the graded bench is bench.py); under torch.distributed.run it averages gradients over RCCL.
-usage: python tools/bench_train.py [steps=5]"""
+usage: python tools/bench_train.py [steps=5] [dropout=0.1]   (dropout = config.dropout: dropout1 / dropout2 / FeedForward
+dropout; the PositionalEncoding dropout 0.1 is live in train mode either way, D9)"""
 import os
 import sys
 import tempfile
@@ -14,14 +15,14 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from valle2_amd import ConfigValle, dp, get_model_class, synth  # noqa: E402
 
 
-def main(steps=5):
+def main(steps=5, dropout=0.0):
     os.chdir(tempfile.mkdtemp())
     rank, local, world = dp.env_world()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dp.init_distributed('nccl', dev)
     for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
-        cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm=norm,
+        cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=dropout, norm=norm,
                           batch_size=16)
         torch.manual_seed(0)
         model = get_model_class(name)(cfg).to(dev).train()
@@ -52,10 +53,11 @@ def main(steps=5):
         if rank == 0:
             f, b, o = (sum(p[k] for p in phases) / len(phases) * 1e3 for k in range(3))
             rows = batch['codes'].shape[0] * (batch['codes'].shape[1] + batch['tokens'].shape[1])
-            print(f'{name}: {sum(times) / len(times) * 1e3:.1f} ms/step (fwd {f:.1f}, bwd {b:.1f}, '
+            print(f'{name} (dropout {dropout}): {sum(times) / len(times) * 1e3:.1f} ms/step (fwd {f:.1f}, bwd {b:.1f}, '
                   f'allreduce tail + clip + AdamW {o:.1f}) world={world} last batch rows={rows} loss={float(loss.detach()):.3f} '
                   f'peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
 
 
 if __name__ == '__main__':
-    main(*[int(a.split('=')[1]) for a in sys.argv[1:]])
+    kv = dict(a.split('=') for a in sys.argv[1:])
+    main(int(kv.get('steps', 5)), float(kv.get('dropout', 0.0)))

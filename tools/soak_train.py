@@ -1,7 +1,7 @@
 """Soak of the training step (developer tool): N steps of configs[3] AR then NAR with a DIFFERENT batch shape every step
 (ragged lengths drawn per seed -> a different row count, tile count and tail split each step), every loss finite, the
 loss of one repeated batch going down, device error flags clean, allocator footprint flat.
-usage: python tools/soak_train.py [steps=150]"""
+usage: python tools/soak_train.py [steps=150] [dropout=0.0]   (dropout = config.dropout; 0.1 = the reference default)"""
 import os
 import sys
 import tempfile
@@ -15,10 +15,10 @@ os.chdir(tempfile.mkdtemp())
 from valle2_amd import ConfigValle, _lib, get_model_class, synth  # noqa: E402
 
 
-def main(steps=150):
+def main(steps=150, dropout=0.0):
     dev = torch.device('cuda:0')
     for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
-        cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm=norm, batch_size=16)
+        cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=dropout, norm=norm, batch_size=16)
         torch.manual_seed(0)
         model = get_model_class(name)(cfg).to(dev).train()
         opt = model.configure_optimizers()['optimizer']
@@ -53,7 +53,7 @@ def main(steps=150):
         opt.check_errors()
         grow = (torch.cuda.memory_reserved(dev) - peak0) / 2 ** 20
         assert probe[-1] < probe[0], f'{name}: the repeated batch did not improve ({probe[0]:.3f} -> {probe[-1]:.3f})'
-        print(f'{name}: {steps} steps over {len(shapes)} batch shapes, all losses finite; repeated batch {probe[0]:.3f} -> '
+        print(f'{name} (dropout {dropout}): {steps} steps over {len(shapes)} batch shapes, all losses finite; repeated batch {probe[0]:.3f} -> '
               f'{probe[-1]:.3f}; step min {min(times):.1f} median {sorted(times)[len(times) // 2]:.1f} max {max(times[5:]):.1f} ms; '
               f'reserved memory since step 20: {grow:+.0f} MiB ({torch.cuda.memory_reserved(dev) / 2 ** 30:.1f} GiB)', flush=True)
         del model, opt
@@ -61,4 +61,4 @@ def main(steps=150):
 
 
 if __name__ == '__main__':
-    main(*[int(a) for a in sys.argv[1:]])
+    main(*([int(sys.argv[1])] if len(sys.argv) > 1 else []), *([float(sys.argv[2])] if len(sys.argv) > 2 else []))
