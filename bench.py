@@ -400,6 +400,20 @@ def train_leg(dev, world, rank, small):
         torch.cuda.synchronize()
         dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
         key = 'ar' if name == 'ValleAR' else 'nar'
+        if not p_drop:
+            # the exchange by itself (nothing to overlap with): every bucket launched back to back on the zeroed flat
+            # gradient, as finish() does for a step whose hooks launched nothing — what the step would pay without overlap
+            out[f'{key}_exchange'] = {'algorithm': reducer.algorithm, 'bucket_mb': reducer.bucket_bytes / 2 ** 20,
+                                      'buckets': len(reducer.buckets), 'launches_per_step': reducer.launches_per_step,
+                                      'bytes_sent_per_rank': reducer.bytes_per_step(world), 'alone_ms': None}
+            if world > 1 and reducer.active:
+                reducer.finish()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    reducer.finish()
+                torch.cuda.synchronize()
+                out[f'{key}_exchange']['alone_ms'] = dp.max_over_ranks(time.perf_counter() - t1, dev) / 5 * 1e3
         if p_drop:
             out[f'{key}_ms_per_step_dropout'] = dt / timed * 1e3
             out[f'{key}_dropout_over_plain'] = (dt / timed * 1e3) / out[f'{key}_ms_per_step']

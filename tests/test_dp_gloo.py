@@ -37,11 +37,11 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _reducer_worker(rank, world, port, out):
+def _reducer_worker(rank, world, port, out, algo='ring'):
     """GradReducer on a toy model: flat gradient views, hooks firing during backward, two buckets,
     gradient accumulation with the exchange on the last micro-batch only."""
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VALLE2_ALLREDUCE=algo)
     dp.init_distributed('gloo')
     from valle2_amd.optim import flat_layout
     torch.manual_seed(0)                                   # same weights on both ranks
@@ -53,6 +53,7 @@ def _reducer_worker(rank, world, port, out):
     for p, off, n in slots:
         p.grad = flat[off:off + n].view_as(p)
     red = dp.GradReducer(flat, slots, bucket_bytes=160)    # 40 floats per bucket → several buckets
+    assert red.algorithm == algo and all((e - s) % 64 == 0 for s, e, _ in red.buckets)
     g = torch.Generator().manual_seed(100 + rank)
     xs = [torch.randn(4, 6, generator=g) for _ in range(2)]
     for i, x in enumerate(xs):                             # 2 micro-batches, exchange on the last
@@ -112,11 +113,42 @@ def _branch_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def _spawn(target, world):
+def _ab_worker(rank, world, port, out):
+    """The two forms of the exchange on the SAME flat gradient (several buckets, a knob-sized bucket): ring all_reduce and
+    reduce-scatter + all-gather must leave the same numbers in every element on every rank, and an AdamW-shaped update
+    from them the same parameters."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), VALLE2_BUCKET_MB='0.002')     # ~2 KiB buckets
+    dp.init_distributed('gloo')
+    from valle2_amd.optim import flat_layout
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.randn(*shp)) for shp in ((33, 17), (100,), (7, 9, 3), (64, 64), (5,), (1025, 3))]
+    slots, total = flat_layout(params)
+    g = torch.Generator().manual_seed(500 + rank)
+    mine = torch.randn(total, generator=g)
+    res = {}
+    for algo in ('ring', 'rs_ag'):
+        os.environ['VALLE2_ALLREDUCE'] = algo
+        flat = mine.clone()
+        red = dp.GradReducer(flat, slots)
+        assert red.algorithm == algo and len(red.buckets) >= 3 and red.bucket_bytes == int(0.002 * (1 << 20))
+        assert red.launches_per_step == len(red.buckets) * (2 if algo == 'rs_ag' else 1)
+        assert red.bytes_per_step(world) == int(2 * (world - 1) / world * total * 4)
+        red.finish()                                        # nothing arrived through hooks: every bucket leaves here, in order
+        red.remove()
+        res[algo] = flat
+    flatp = torch.cat([p.detach().reshape(-1) for p in params])
+    upd = {a: flatp[:64] - 1e-3 * (f[:64] / world) / ((f[:64] / world).abs().sqrt() + 1e-8) for a, f in res.items()}
+    out.put((rank, res['ring'].tolist(), res['rs_ag'].tolist(), mine.tolist(), torch.equal(upd['ring'], upd['rs_ag'])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, *extra):
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q, *extra)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=240) for _ in range(world))
@@ -136,8 +168,23 @@ def test_grad_reducer_launches_buckets_in_index_order_when_ranks_train_different
 
 
 @pytest.mark.parametrize('world', [2, 4, 8])
-def test_grad_reducer_overlapped_buckets(world):
-    res = _spawn(_reducer_worker, world)
+def test_ring_and_reduce_scatter_all_gather_agree(world):
+    """VALLE2_ALLREDUCE = ring | rs_ag (and VALLE2_BUCKET_MB) on one flat gradient: the same sums, bit for bit, in every
+    element on every rank — gloo adds the ranks' contributions in rank order in both collectives — and therefore the
+    same parameters after the update."""
+    res = _spawn(_ab_worker, world)
+    total = sum(torch.tensor(r[3], dtype=torch.float64) for r in res)
+    for rank, ring, rs_ag, _, same_update in res:
+        ring, rs_ag = torch.tensor(ring), torch.tensor(rs_ag)
+        assert torch.allclose(ring.double(), total, atol=1e-5) and torch.allclose(rs_ag.double(), total, atol=1e-5)
+        assert torch.equal(ring, torch.tensor(res[0][1])) and torch.equal(rs_ag, torch.tensor(res[0][2])), rank   # replicas agree
+        assert torch.equal(ring, rs_ag) and same_update, f'rank {rank}: the two forms differ'
+
+
+@pytest.mark.parametrize('algo', ['ring', 'rs_ag'])
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_grad_reducer_overlapped_buckets(world, algo):
+    res = _spawn(_reducer_worker, world, algo)
     assert len({r[1] for r in res}) == 1 and res[0][1] >= 2 and all(r[5] for r in res)
     assert all(r[2] >= 1 for r in res)                   # at least one bucket left during backward on every rank
     n_params = len(res[0][3])

@@ -8,7 +8,9 @@ need minutes per case there):
   configs[2]  12L/512d NAR, 64 x 1024: stage logits are batch-invariant (row i of 64 == row i alone)
               and invariant to right-padding the batch with extra frames' worth of rows.
   configs[4]  24L/1024d, 16 heads (B*h = 128 → split-KV decode + combine kernel): oracle parity on a
-              short prompt, then graph == eager on a long one (2.3 k context).
+              short prompt, then graph == eager over the config's whole 2250 new tokens (context 626 → 2876); the NAR
+              stack at the bench's batch of 8: row 0 == the B = 1 golden of the real reference; and the joint pipeline
+              AR generate_batch → NAR generate_batch on 8 utterances, its stages re-derived by stage_logits.
 """
 import pytest
 import torch
@@ -104,8 +106,70 @@ def test_config5_shape_24_layers_1024d():
     n = min(len(out), len(ref))
     bad = (out[:n] != ref[:n]).nonzero()
     assert len(out) == len(ref) and (bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4)
-    # long context: 400 text + 226 prompt frames + 1700 new → S up to 2.3 k (PE table 5000)
+    # configs[4] as worded: 400 text + BOS + 225 prompt frames + 2250 new tokens → context 626 → 2876 (PE table 5000)
     texts, firsts = utterances(cfg, 8, 400, 225, 8000)
-    g = m.generate_batch(texts, firsts, max_new=1700)
-    e = m.generate_batch(texts, firsts, max_new=1700, use_graph=False)
-    assert g.shape == (8, 226 + 1700) and torch.equal(g, e)
+    g = m.generate_batch(texts, firsts, max_new=2250)
+    assert m.last_generate_stats['tokens_appended'] == 2250
+    e = m.generate_batch(texts, firsts, max_new=2250, use_graph=False)
+    assert g.shape == (8, 226 + 2250) and torch.equal(g, e)
+    assert int((g[:, 226:] == cfg.eos_token).sum()) == 0            # (EOS silenced: every row decodes all 2250)
+    assert len({tuple(r.tolist()) for r in g[:, 226:].cpu()}) == 8
+
+
+def test_config5_nar_batch_of_8_row0_matches_the_b1_golden():
+    """configs[4]'s NAR leg at the shape bench.py runs it (B = 8 x 2875 positions, 24L/1024d): row 0 of the batch is
+    the utterance of the real reference's B = 1 golden (nar_big.npz), 7 other utterances beside it — batch invariance
+    ties the bench shape to the golden (logits atol 1e-3, rtol 1e-4 as the B = 1 test)."""
+    from tests.oracle_runners import load_golden
+    from valle2_amd import get_model_class, synth
+    gold = load_golden('nar_big')
+    kw, sd, one = C.nar_big_inputs()
+    cfg = C.cfg_of(kw)
+    others = synth.synth_nar_batch(cfg, 7, n_tokens=C.NAR_BIG_TEXT, n_frames=C.NAR_BIG_FRAMES, seed=999)
+    batch = {k: torch.cat([one[k], others[k]]) for k in one}
+    assert batch['codes'].shape == (8, C.NAR_BIG_FRAMES, 8) and batch['tokens'].shape == (8, C.NAR_BIG_TEXT)
+    m = get_model_class('ValleNAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    for stage in (2, 7):
+        with torch.no_grad():
+            logits, p = m.stage_logits(batch, stage)
+        assert p == int(gold[f'prefix_{stage}']) and logits.shape[0] == 8
+        torch.testing.assert_close(logits[:1, ::C.NAR_BIG_STRIDE].cpu(), gold[f'logits_{stage}'], atol=1e-3, rtol=1e-4)
+        assert float((logits[1] - logits[0]).abs().max()) > 1e-2     # the other rows are other utterances
+
+
+def test_config5_joint_ar_then_nar_pipeline():
+    """configs[4] end to end on 8 utterances: ValleAR.generate_batch (2250 first-codebook tokens per row) feeds
+    ValleNAR.generate_batch (greedy) → (2250, 8) codes per row whose column 0 IS the AR output.  Every NAR stage is then
+    re-derived by `stage_logits` on the finished codes: with a 150-frame prompt the training-shaped forward's prefix
+    (min(T // 3, 3 x 50) = 150 frames, all codebooks) is exactly the acoustic prompt, so stage n's arg-max over the
+    target frames must be codebook n of the result (near-ties < 1e-3 excepted: ragged-batch vs dense kernels)."""
+    big = dict(d_model=1024, n_heads=16, dim_feedforward=4096, num_layers=24, dropout=0.0, top_k=1)
+    ar, cfg, _ = build('ValleAR', dict(big, norm='LayerNorm', num_beams=8, max_audio_len=2250), seed=3, std=0.03)
+    nar, ncfg, _ = build('ValleNAR', dict(big, norm='AdaptiveLayerNorm'), seed=4, std=0.03)
+    from valle2_amd import synth
+    B, n_text, n_prompt, n_new = 8, 400, 150, 2250
+    us = [synth.synth_utterance(cfg, n_text // 2, n_text // 2, n_prompt, seed=8100 + i) for i in range(B)]
+    texts = [torch.cat([u[0], u[2]]).to(DEV) for u in us]
+    prompts = [u[1].to(DEV) for u in us]                              # (150, 8) codes
+    rows = ar.generate_batch(texts, [p[:, 0] for p in prompts], max_new=n_new)
+    assert rows.shape == (B, 1 + n_prompt + n_new) and ar.last_generate_stats['tokens_appended'] == n_new
+    firsts = [rows[b, 1 + n_prompt:] for b in range(B)]
+    assert all(int((f >= ncfg.num_audio_tokens).sum()) == 0 for f in firsts)
+    out = nar.generate_batch(texts, prompts, firsts, greedy=True)
+    assert len(out) == B and all(tuple(o.shape) == (n_new, 8) for o in out)
+    assert all(torch.equal(o[:, 0], f) for o, f in zip(out, firsts))
+    codes = torch.stack([torch.cat([p, o]) for p, o in zip(prompts, out)])          # (B, 150 + 2250, 8)
+    batch = {'tokens': torch.stack(texts), 'tokens_lens': torch.full((B,), n_text), 'codes': codes,
+             'codes_lens': torch.full((B,), n_prompt + n_new)}
+    for stage in (1, 7):
+        with torch.no_grad():
+            logits, p = nar.stage_logits(batch, stage)
+        assert p == n_prompt and tuple(logits.shape) == (B, n_new, ncfg.num_audio_tokens)
+        top2 = logits.topk(2, dim=-1)
+        got = torch.stack([o[:, stage] for o in out])
+        off = top2.indices[..., 0] != got
+        margin = (top2.values[..., 0] - top2.values[..., 1])[off]
+        assert off.float().mean().item() < 1e-3 and (margin.numel() == 0 or float(margin.max()) < 1e-3), \
+            (stage, int(off.sum()), float(margin.max()) if margin.numel() else 0.0)

@@ -92,6 +92,23 @@ def allreduce_mean_(tensors, bucket_bytes: int = 64 << 20):
     flush()
 
 
+def exchange_knobs():
+    """(algorithm, bucket bytes) of the gradient exchange from the environment:
+      VALLE2_ALLREDUCE = ring  (default) one in-place all_reduce per bucket — RCCL picks its own algorithm, a ring at these
+                               sizes: 2 (N-1)/N of the bucket over ONE link pair per GPU;
+                       = rs_ag reduce_scatter_tensor + all_gather_into_tensor on the same slice, both in place (rank r owns
+                               chunk r of the bucket): the all-links form SURVEY.md section 5 asks to compare — every GPU
+                               sends 1/N of the bucket to each of its N-1 peers over that peer's own xGMI link, twice;
+      VALLE2_BUCKET_MB = 64    (default) bucket size in MiB."""
+    algo = os.environ.get('VALLE2_ALLREDUCE', 'ring').strip().lower()
+    if algo not in ('ring', 'rs_ag'):
+        raise ValueError(f"VALLE2_ALLREDUCE={algo!r}: expected 'ring' or 'rs_ag'")
+    mb = float(os.environ.get('VALLE2_BUCKET_MB', '64'))
+    if not mb > 0:
+        raise ValueError(f'VALLE2_BUCKET_MB={mb}: must be positive')
+    return algo, int(mb * (1 << 20))
+
+
 class GradReducer:
     """Sum-all-reduce of a flat gradient buffer, overlapped with backward.
 
@@ -106,9 +123,20 @@ class GradReducer:
     waits, and returns; the 1/world mean is left to the optimizer kernel (`grad_scale`).
     Few large messages: xGMI is point-to-point, 7 links per GPU, so a bucket is sized per link
     (64 MB default ≈ 3 buckets for the 156 MB AR model), not for a switch.
+    `algorithm` / `bucket_bytes` default to the environment's knobs (`exchange_knobs`): 'ring' = one all_reduce per
+    bucket, 'rs_ag' = reduce-scatter + all-gather of the same slice.  Both leave the SUM over ranks in every element of
+    the bucket; a bucket whose length the world size does not divide (slots are padded to 64 floats, so only world
+    sizes that do not divide 64) falls back to all_reduce.  `bytes_per_step` / `launches_per_step`: what one exchange
+    of the whole buffer moves per rank (for the bench line).
     """
 
-    def __init__(self, flat_grad: torch.Tensor, slots, bucket_bytes: int = 64 << 20):
+    def __init__(self, flat_grad: torch.Tensor, slots, bucket_bytes: int | None = None, algorithm: str | None = None):
+        env_algo, env_bytes = exchange_knobs()
+        self.algorithm = algorithm or env_algo
+        if self.algorithm not in ('ring', 'rs_ag'):
+            raise ValueError(f'GradReducer: unknown algorithm {self.algorithm!r}')
+        bucket_bytes = env_bytes if bucket_bytes is None else bucket_bytes
+        self.bucket_bytes = bucket_bytes
         self.flat = flat_grad
         self.enabled = True
         self.buckets = []          # (start, end, n_params)
@@ -116,10 +144,12 @@ class GradReducer:
         self.view_of = {id(p): flat_grad[off:off + n].view_as(p) for p, off, n in slots}
         start, count = 0, 0
         end = 0
-        for p, off, n in slots:
+        for i, (p, off, n) in enumerate(slots):
             self.bucket_of[id(p)] = len(self.buckets)
             count += 1
-            end = off + n
+            # a bucket ends where the next slot begins (slots are padded — optim.ALIGN = 64 floats — so bucket lengths
+            # are multiples of 64 and every power-of-two world size divides them: what rs_ag's equal chunks need)
+            end = slots[i + 1][1] if i + 1 < len(slots) else flat_grad.numel()
             if (end - start) * flat_grad.element_size() >= bucket_bytes:
                 self.buckets.append((start, end, count))
                 start, count = end, 0
@@ -139,7 +169,30 @@ class GradReducer:
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
-        self._work[b] = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        buf = self.flat[s:e]
+        world = dist.get_world_size()
+        if self.algorithm == 'rs_ag' and (e - s) % world == 0:
+            # in place on the bucket: rank r reduces chunk r (its slice of the send buffer IS its receive buffer), then
+            # every rank gathers the N reduced chunks back into the same bucket.  The two collectives of a bucket — and
+            # the buckets among themselves — run in issue order on the communicator's stream (RCCL); gloo's worker
+            # threads give no such order, so there the scatter is waited for before the gather is issued.
+            chunk = (e - s) // world
+            mine = buf[dist.get_rank() * chunk:(dist.get_rank() + 1) * chunk]
+            rs = dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, async_op=True)
+            if dist.get_backend() != 'nccl':
+                rs.wait()
+            self._work[b] = dist.all_gather_into_tensor(buf, mine, async_op=True)
+        else:
+            self._work[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    @property
+    def launches_per_step(self):
+        return len(self.buckets) * (2 if self.algorithm == 'rs_ag' else 1)
+
+    def bytes_per_step(self, world: int) -> int:
+        """Bytes one rank SENDS for one exchange of the whole buffer: 2 (N-1)/N of it either way — a ring pushes them
+        through one link, rs_ag spreads them over the N-1 links."""
+        return int(2 * (world - 1) / max(world, 1) * self.flat.numel() * self.flat.element_size())
 
     def _on_grad(self, p):
         if not self.active:

@@ -120,17 +120,46 @@ def layer_table(transformer, cache: KVCache, folded=None):
 
 
 def adaln_table(transformer, embedding):
-    """(L, 2, 2, d) [layer][norm1|norm2][scale|shift] = project_layer(embedding) for every
-    AdaptiveLayerNorm (valle/models/modules.py:94-98); one (1,d)x(d,2d) GEMV each."""
+    """(L, 2, 2, d) [layer][norm1|norm2][scale|shift] = project_layer(embedding) for every AdaptiveLayerNorm of the
+    stack (valle/models/modules.py:94-98) in ONE launch (`vh_adaproj_fwd`, the training path's kernel: a wave per 8
+    output rows of one of the 2 L Linears), instead of 2 L single-row GEMV launches from Python.
+
+    The table of a stage depends on the stage embedding and the projection weights only, so it is kept per embedding
+    TENSOR OBJECT (a weak reference: a parameter such as stage_embs[n].weight lives as long as the model; an ad-hoc
+    tensor's entry dies with it, and a recycled address can never alias a live entry) and reused while neither that
+    tensor's version, nor any projection parameter's, nor the weights epoch (flat optimizer steps) has moved — the 7
+    stages of ValleNAR.generate_batch build 7 tables once, not 7 per call."""
+    import weakref
+
+    import numpy as np
     layers = list(transformer.layers)
     d = embedding.shape[-1]
-    emb = embedding.reshape(1, d).contiguous()
-    out = torch.empty(len(layers), 2, 2 * d, device=emb.device, dtype=torch.float32)
-    for i, layer in enumerate(layers):
-        for j, norm in enumerate((layer.norm1, layer.norm2)):
-            kernels.linear(emb, norm.project_layer.weight.detach(), norm.project_layer.bias.detach(),
-                           out=out[i, j].view(1, 2 * d))
-    return out.view(len(layers), 2, 2, d)
+    projs = [(n.project_layer.weight, n.project_layer.bias) for l in layers for n in (l.norm1, l.norm2)]
+    n = len(projs)
+    state = transformer.__dict__.setdefault('_vh_ada', {'items': None, 'tables': []})
+    pkey = (_WEIGHTS_EPOCH,) + tuple(x for w, b in projs for x in (w.data_ptr(), w._version, b.data_ptr(), b._version))
+    for ref, ver, key, table in state['tables']:
+        if ref() is embedding and ver == embedding._version and key == pkey and table.device == embedding.device:
+            return table
+    state['tables'] = [e for e in state['tables'] if e[0]() is not None and e[0]() is not embedding][-15:]
+    if any(tuple(w.shape) != (2 * d, d) or not w.is_contiguous() or w.dtype != torch.float32 for w, _ in projs):
+        raise _lib.VhError('adaln_table: project_layer weights must be contiguous fp32 (2 d, d)')
+    ptrs = tuple(x for w, b in projs for x in (w.data_ptr(), b.data_ptr()))
+    if state['items'] is None or state['items'][0] != ptrs or state['items'][1].device != embedding.device:
+        rec = np.zeros(n, dtype=[('w', 'u8'), ('b', 'u8'), ('dw', 'u8'), ('db', 'u8')])
+        for i, (w, b) in enumerate(projs):
+            rec[i] = (w.data_ptr(), b.data_ptr(), 0, 0)
+        state['items'] = (ptrs, _lib.to_device_async(torch.from_numpy(rec.view(np.uint8).copy()), embedding.device))
+    emb = embedding.detach().reshape(-1).contiguous()
+    with torch.inference_mode(False):            # a normal tensor: the cached table outlives an inference_mode() caller
+        out = torch.empty(n, 2 * d, device=emb.device, dtype=torch.float32)
+    check(_lib.lib().vh_adaproj_fwd(ptr(state['items'][1]), n, ptr(emb), ptr(out), 2 * d, d, stream()), 'vh_adaproj_fwd')
+    table = out.view(len(layers), 2, 2, d)
+    try:
+        state['tables'].append((weakref.ref(embedding), embedding._version, pkey, table))
+    except TypeError:
+        pass
+    return table
 
 
 class ForwardScratch:

@@ -178,18 +178,30 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def sync_touched(self):
         """Data parallel: a slot is updated iff SOME rank produced a gradient for it (its all-reduced gradient is
-        then the same everywhere), so every rank takes the same decision and the replicas stay identical."""
+        then the same everywhere), so every rank takes the same decision and the replicas stay identical.
+
+        The device error flag travels with the flags, and the decision it carries is taken HERE, collectively: the MAX
+        over ranks is read on the host in this call (the flags are read anyway), so when any rank's kernels saw a bad id
+        during this step's forward / backward — the range-checking kernels all run before this point — EVERY rank drops
+        the step in this very call: gradients cleared, flag cleared, host counters untouched (step() has not run), and
+        the IndexError raised on all ranks together.  No rank can run ahead into the next bucket's collective while a
+        peer raises, and no stale flag is left to be re-raised from a peer at the next step."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
-        # the device error flag travels with the flags: a rank whose kernels saw a bad id skips its update (the launch
-        # is guarded by the flag) — every rank must skip it then, and raise together, or the replicas diverge and the
-        # faulty rank leaves the others hanging in the next collective
         flag = _lib.err_flag(self.flat_param.device)
         t = torch.cat([torch.tensor(self._touched, dtype=torch.int32, device=self.flat_param.device), flag])
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        flag.copy_(t[-1:])
-        self._touched = [bool(v) for v in t[:-1].tolist()]
+        vals = t.tolist()                                  # (host synchronisation: once per optimizer step, world > 1 only)
+        self._touched = [bool(v) for v in vals[:-1]]
+        code = int(vals[-1])
+        if code:
+            flag.zero_()
+            self.flat_grad.zero_()
+            self._clean = [True] * len(self.slots)
+            self._touched = [False] * len(self.slots)
+            self._release_grads()
+            _lib.raise_device_errors(self.flat_param.device, code=code)
 
     # ---- gradient views -------------------------------------------------------------------------
     def grad_view(self, slot):

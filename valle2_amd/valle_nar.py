@@ -95,7 +95,7 @@ class ValleNAR(_Base):
         p = self._embed_audio(codes, stage, x, tx, self.audio_position_emb.pe)
         cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev)
         transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL,
-                            embedding=self.stage_embs[stage - 1].weight.detach())
+                            embedding=self.stage_embs[stage - 1].weight)      # (the parameter itself: adaln_table keys on it)
         z = x[:, tx + p:].reshape(b * (t - p), d)
         logits = kernels.linear(z, self.proj_layers[stage - 1].weight.detach())
         return logits.reshape(b, t - p, -1), p
@@ -230,7 +230,7 @@ class ValleNAR(_Base):
             kernels.embed_sum_pe(out, self._tables(n), pe_a, 0, x, lens=ty_d, row_pos0=tc_d, row_t0=t0_target,
                                  max_pos=max(tc + ty for tc, ty in zip(tcs, tys)))
             transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
-                                embedding=self.stage_embs[n - 1].weight.detach(), scratch=scratch)
+                                embedding=self.stage_embs[n - 1].weight, scratch=scratch)    # (cached AdaLN table per stage)
             z = x.view(B * total, d).index_select(0, idx)                      # target frames of every row
             logits = kernels.linear(z, self.proj_layers[n - 1].weight.detach())
             kernels.categorical_rows(logits, toks, temperature=cfg.temperature, greedy=greedy, seed=seed,
