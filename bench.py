@@ -72,6 +72,7 @@ def parse():
     ap.add_argument('--no-config5', action='store_true')
     ap.add_argument('--no-perf-mode', action='store_true')
     ap.add_argument('--no-rows64', action='store_true')
+    ap.add_argument('--no-default-generate', action='store_true')
     ap.add_argument('--no-traffic', action='store_true', help='do not start the rocprofv3 --pmc child processes')
     ap.add_argument('--traffic-child', action='store_true', help=argparse.SUPPRESS)   # one generate, nothing else
     ap.add_argument('--extras-deadline', type=float, default=600.0,
@@ -345,6 +346,44 @@ def spawn_ranks(n):
                 for q in procs:
                     q.terminate()
     return rc
+
+
+def default_generate_leg(dev, sd, utt):
+    import torch
+
+    from valle2_amd import ConfigValle, get_model_class
+    cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm='LayerNorm')
+    assert (cfg.num_beams, cfg.top_k, cfg.tok_p, cfg.temperature, cfg.max_audio_len) == (4, 50, 1.0, 1.0, 1024)
+    model = get_model_class('ValleAR')(cfg)
+    model.load_state_dict(sd)                       # the headline's weights (EOS row zeroed: logit 0 never reaches the top 50)
+    model = model.to(dev).eval()
+    utt = [u.to(dev) for u in utt]
+    torch.manual_seed(0)
+    model.generate(*utt)
+    torch.cuda.synchronize()
+    reps, t0 = 3, time.perf_counter()
+    for _ in range(reps):
+        toks = model.generate(*utt)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    st = model.last_generate_stats
+    steps = st['steps_run']
+    per_layer = 2 + (2 if st['n_split'] > 1 else 1) + (2 if st['ffn_fused'] else 3)
+    out = {'metric': 'generate(prompt_tokens, prompt_codes, target_tokens) at the reference generation defaults '
+                     '(num_beams=4, top_k=50, tok_p=1.0, temperature=1.0, max_audio_len=1024), 12L/512d, '
+                     f'{utt[0].numel() + utt[2].numel()} text + {utt[1].shape[0]} prompt frames',
+           'value': cfg.num_beams * steps / dt, 'unit': 'tokens/s (all 4 beams)',
+           'utterance_tokens_per_s': steps / dt, 'ms_per_generate': dt * 1e3, 'steps': steps,
+           'tokens_returned': int(toks.numel()), 'prefill_ms': st['prefill_ms'],
+           'decode_us_per_step': st['decode_ms'] / max(1, steps - 1) * 1e3, 'n_split': st['n_split'],
+           'launches_per_step': cfg.num_layers * per_layer + 2,
+           'launches': f'per layer: QKV, decode attention x{st["n_split"]} key splits'
+                       + (' + combine' if st['n_split'] > 1 else '') + ', out-projection, FeedForward '
+                       + ('(one split launch + slab reduce)' if st['ffn_fused'] else '(linear_1, split-K linear_2, reduce)')
+                       + '; + head + sample step'}
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def train_leg(dev, world, rank, small):
@@ -644,6 +683,14 @@ def main():
                            'tokens_returned': int(toks.numel()), 'decode_ms': st_b['decode_ms'],
                            'prefill_ms': st_b['prefill_ms'],
                            'vs_distinct_rows': (rows * new / dtb) / (value / world)}
+
+    if rank == 0 and world == 1 and not args.no_default_generate and not args.small:
+        # what a user of the reference calls: generate() with the reference's OWN generation defaults (valle/config.py:
+        # num_beams = 4, top_k = 50, tok_p = 1, temperature = 1, max_audio_len = 1024) on the 12L/512d model — one utterance,
+        # 4 sampled beams, 1024 steps.  B x heads = 32 (row, head) streams: the decode attention splits the keys 8 ways
+        # (+ a combine launch), the GEMMs see 4 rows: a launch-floor-bound step, reported as such
+        log('default_generate: generate() with the reference generation defaults')
+        result['default_generate'] = default_generate_leg(dev, sd, utts[0])
 
     if rank == 0 and world == 1 and not args.no_perf_mode:
         # SURVEY section 7's perf mode, a LABELLED SECONDARY line (narrower storage than the reference: never the headline,
