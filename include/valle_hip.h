@@ -80,7 +80,10 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_TAIL_SPLIT = 10,     /* vh_linear_ex with a workspace: 0 (default) = the tiles beyond the last multiple of 256 are
                                        computed as K slices + a fix-up launch when they would fill <= half of the CUs, 1 = never */
        VH_TUNE_TN_WGS = 11,         /* vh_gemm_tn: workgroups the contraction split aims at, 0 (default) = 256 (one per CU) */
-       VH_TUNE_COUNT = 12 };
+       VH_TUNE_DECODE_COMBINE = 12, /* decode attention with key splits: 0 (default) = a second launch adds the split records,
+                                       1 = the last workgroup of a (b, head) to arrive does, in the same launch (same bits:
+                                       split order either way; measured 13 us per decode step slower at 4 beams x 8 splits) */
+       VH_TUNE_COUNT = 13 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- dropout field of the training path -------------------------------------------------------------
@@ -247,7 +250,11 @@ int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* 
  * q (B, ldq); keys 0 .. cache_len[b] + len_bias - 1 of row b are attended (len_bias = 1 when the
  * new K/V row was just appended by vh_linear_qkv and cache_len is not yet incremented).
  * n_split >= 1 splits the key range of one (b,head) over n_split workgroups; then `partial`
- * must hold vh_attn_decode_ws_bytes(B, n_heads, n_split) bytes. out (B, ldo). */
+ * must hold vh_attn_decode_ws_bytes(B, n_heads, n_split) bytes: the split records followed by one ticket word per
+ * (b, head).  The records are combined in split order by a second launch (default) or, with VH_TUNE_DECODE_COMBINE = 1,
+ * inside the same launch by whichever workgroup finishes last; for that form the TICKET WORDS (the last B * n_heads * 4
+ * bytes, rounded up to 16) MUST BE ZERO before the first call on a workspace; every call leaves them zero (calls on one
+ * workspace must be stream-ordered).  out (B, ldo). */
 size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
 int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
                    int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,

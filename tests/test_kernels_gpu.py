@@ -508,6 +508,41 @@ def test_attn_decode(K, B, h, S, n_split):
     close(out, ref, atol=3e-5)
 
 
+@pytest.mark.parametrize('B,h,n_split', [(4, 8, 8), (8, 16, 2), (3, 2, 16), (1, 8, 5)])
+def test_attn_decode_split_combine_in_launch_equals_the_second_launch(K, B, h, n_split):
+    """Key splits combined by the last workgroup to arrive (VH_TUNE_DECODE_COMBINE = 1) against the separate combine launch
+    (default): the records are added in split order either way, so the results are the same BITS; the ticket words
+    re-arm themselves — 25 launches on one workspace — and end at zero."""
+    from valle2_amd import _lib
+    d, S = 64 * h, 700
+    gen = g(90 + n_split)
+    q = torch.randn(B, d, generator=gen).to(DEV)
+    k = torch.randn(B, h, S, 64, generator=gen).to(DEV)
+    v = torch.randn(B, h, S, 64, generator=gen).to(DEV)
+    lens = torch.tensor([max(1, S - 37 * i) for i in range(B)], dtype=torch.int32).to(DEV)
+    ws = K.attn_decode_ws(B, h, n_split, DEV)
+    lib = _lib.lib()
+    outs = {}
+    try:
+        for knob in (0, 1):
+            lib.vh_set_tuning(12, knob)
+            out = torch.empty(B, d, device=DEV)
+            for _ in range(25 if knob == 1 else 1):
+                out.fill_(float('nan'))
+                K.attn_decode(q, k, v, out, lens - 1, 1, n_split, ws)
+            outs[knob] = out.clone()
+    finally:
+        lib.vh_set_tuning(12, 0)
+    assert torch.equal(outs[0], outs[1])
+    tickets = ws.view(torch.int32)[B * h * n_split * 72:][: B * h]
+    assert int(tickets.abs().sum()) == 0
+    ref = torch.empty(B, d)
+    for b in range(B):
+        L = int(lens[b])
+        ref[b] = _sdpa_ref(q[b].cpu().view(1, h, 1, 64), k[b:b + 1, :, :L].cpu(), v[b:b + 1, :, :L].cpu(), None).reshape(d)
+    close(outs[0], ref, atol=3e-5)
+
+
 @pytest.mark.parametrize('variant', [0, 1])        # the ring kernel (default at 256 (row, head) pairs) and the burst kernel
 @pytest.mark.parametrize('S_max', [40, 300, 1100])
 def test_attn_decode_ring_kernels_short_and_ragged_rows(K, variant, S_max):

@@ -31,9 +31,10 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
     const float* __restrict__ q, int ldq, const float* __restrict__ kc,
     const float* __restrict__ vc, float* __restrict__ out, int ldo,
     const int32_t* __restrict__ cache_len, int len_bias, int n_heads, int S_max, int n_split,
-    float* __restrict__ partial) {
+    float* __restrict__ partial, unsigned* __restrict__ arrived) {
     __shared__ float s_m[NW], s_l[NW];
     __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
+    __shared__ int s_last;
     const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
     const int split = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -112,11 +113,52 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_kernel(
         }
         if (n_split == 1) {
             out[(int64_t)b * ldo + head * HD + tid] = O / L;
-        } else {
+        } else if (arrived == nullptr) {                     // two-launch form: plain stores, the next launch reads them
             float* pr = partial + ((int64_t)bh * n_split + split) * PART_LD;
             pr[tid] = O;
             if (tid == 0) { pr[HD] = M; pr[HD + 1] = L; }
+        } else {                                             // handed to another workgroup of THIS launch: write-through
+            float* pr = partial + ((int64_t)bh * n_split + split) * PART_LD;
+            __hip_atomic_store(pr + tid, O, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(pr + HD, M, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pr + HD + 1, L, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
+    }
+    // Key splits, combined by the LAST workgroup of the (b, head) to arrive instead of by a second launch (opt-in,
+    // VH_TUNE_DECODE_COMBINE = 1: measured slower than the launch it removes, see vh_attn_decode).  The 8 XCDs have
+    // private L2s, so the record leaves as agent-scope (sc1, write-through) stores that the storing wave drains before
+    // one lane takes a ticket with a relaxed agent-scope add — no release fence: an agent-scope release writes back the
+    // whole L2 and made this form 240 us per step SLOWER than the second launch it replaces
+    // (cdna_hip_programming.md Guideline 16, recipe R1).  The workgroup that draws the last ticket reads every record with
+    // agent-scope loads (they bypass its L1: no acquire either) and adds them IN SPLIT ORDER — the result does not depend
+    // on who came last — then re-arms the ticket word for the next launch of the stream (words start at zero:
+    // vh_attn_decode_ws_bytes).
+    if (arrived == nullptr) return;                          // (uniform: n_split == 1, or the two-launch form)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every storing wave: its record has left
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned ticket = __hip_atomic_fetch_add(arrived + bh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == (unsigned)(n_split - 1);
+        if (s_last) __hip_atomic_store(arrived + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");   // (no instruction: keeps the loads below the ticket)
+    if (tid < HD) {
+        const float* pr = partial + (int64_t)bh * n_split * PART_LD;
+        auto ldg = [](const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+        float M = NEG_INF;
+        for (int k = 0; k < n_split; ++k) M = fmaxf(M, ldg(pr + k * PART_LD + HD));
+        float L = 0.f, O = 0.f;
+        for (int k = 0; k < n_split; ++k) {
+            const float ms = ldg(pr + k * PART_LD + HD);
+            const float wgt = ms == NEG_INF ? 0.f : vh_exp2(ms - M);
+            L += ldg(pr + k * PART_LD + HD + 1) * wgt;
+            O += ldg(pr + k * PART_LD + tid) * wgt;
+        }
+        out[(int64_t)b * ldo + head * HD + tid] = O / L;
     }
 }
 
@@ -443,9 +485,13 @@ extern "C" int vh_attn_decode_kv16(const float* q, int ldq, const uint16_t* kcac
     return VH_OK;
 }
 
+// workspace of a key-split launch: [B h][n_split] partial records, then B h ticket words (one per (b, head), padded to 16 B)
+static size_t decode_records_bytes(int B, int n_heads, int n_split) {
+    return (size_t)B * n_heads * n_split * PART_LD * sizeof(float);
+}
 extern "C" size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split) {
     if (n_split <= 1) return 0;
-    return (size_t)B * n_heads * n_split * PART_LD * sizeof(float);
+    return decode_records_bytes(B, n_heads, n_split) + ((size_t)B * n_heads * sizeof(unsigned) + 15) / 16 * 16;
 }
 
 
@@ -469,23 +515,31 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
     // packet (hipExtLaunchKernelGGL), i.e. the kernel's begin/end timestamps rather than a marker bracket.
 #define AD(KERN, ...)                                                                              \
     hipExtLaunchKernelGGL((KERN<__VA_ARGS__>), grid, dim3(waves * 64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, q, ldq, \
-                          kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial)
+                          kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial, arrived)
     // default: one (b, head) per CU and no key split -> the ring kernel (8 waves x 2 register sets of 32 keys, speculative
     // start: 605.9 vs 615.2 us per decode step, profiles/r2_ab_decode_ring.log); otherwise — key splits, more (b, head)
     // pairs than CUs — the burst kernel.  VH_TUNE_DECODE_VARIANT = 1 forces the burst kernel (A/B); the other ring
     // shapes round 2 measured (8x3, 16x1, 12x2, 16x2x16-key, 8x4x16-key; profiles/r2_attn_ab.log) were slower and are gone.
     const int variant = vh_tuning(VH_TUNE_DECODE_VARIANT);
     const int nw = vh_tuning(VH_TUNE_DECODE_WAVES);
+    // key splits: combined by a second launch (default) or by the last workgroup to arrive (VH_TUNE_DECODE_COMBINE = 1).
+    // Measured on generate() at the reference defaults (4 beams, 8 splits, 12L/512d; profiles/r4_ab_default_generate_combine.log):
+    // second launch 364.6 us per step; in-launch with an agent-scope release + acquire 609.7 (the release writes back the
+    // L2); in-launch with write-through stores and agent-scope loads, no fences, 377.6 — the hand-off (drain, ticket,
+    // dependent loads from beyond the L2) still costs 1 us per layer more than the 1.75 us dependent-launch floor it saves.
+    const bool fused_combine = n_split > 1 && vh_tuning(VH_TUNE_DECODE_COMBINE) == 1;
+    unsigned* arrived = fused_combine ? (unsigned*)((char*)partial + decode_records_bytes(B, n_heads, n_split)) : nullptr;
     if (variant != 1 && big && n_split == 1 && nw == 0) {
         const int waves = 8;
-        AD(attn_decode_ring_kernel, 8, 2);
+        hipExtLaunchKernelGGL((attn_decode_ring_kernel<8, 2>), grid, dim3(waves * 64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, q,
+                              ldq, kcache, vcache, out, ldo, cache_len, len_bias, n_heads, S_max, n_split, (float*)partial);
     } else {
         const int waves = nw ? nw : (big ? 16 : 4);
         if (waves == 16) AD(attn_decode_kernel, 16, true); else if (waves == 8) AD(attn_decode_kernel, 8, true);
         else AD(attn_decode_kernel, 4, true);
     }
 #undef AD
-    if (n_split > 1)
+    if (n_split > 1 && !fused_combine)
         hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(B * n_heads), dim3(64), 0, s,
                            (const float*)partial, out, ldo, n_heads, n_split);
     VH_CHECK_LAUNCH("vh_attn_decode");

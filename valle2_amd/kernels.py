@@ -294,8 +294,10 @@ def attn_rows_bwd(q, kcache, vcache, out, dout, lse2, dq, dk, dv, B, n_heads, T,
 
 
 def attn_decode_ws(B, n_heads, n_split, device):
+    """Workspace of a key-split decode attention: split records + the per-(b, head) ticket words, which must start at
+    zero (the kernel re-arms them itself) — hence zeros, not empty."""
     n = _lib.lib().vh_attn_decode_ws_bytes(B, n_heads, n_split)
-    return torch.empty(max(n, 16) // 4, device=device, dtype=torch.float32) if n else None
+    return torch.zeros(max(n, 16) // 4, device=device, dtype=torch.float32) if n else None
 
 
 def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=None):
