@@ -155,7 +155,39 @@ def cpu_baseline(cfg_kw, sd, utt, rows, new, gpu_tokens=None):
                       f'({t_step * 1e3:.1f} ms/step at S~{TEXT + FRAMES + 1}), extrapolated to {new} tokens'}
 
 
-def measure_attn_traffic(rows, new):
+_CHILDREN = []      # Popen handles of profiler children in flight: the extras watchdog ends them (by PID) before it exits
+
+
+def _run_child(cmd, timeout, **kw):
+    """subprocess.run(check=True) whose process (its own session: the profiler starts python3 under it) is on record
+    while it runs, so that a deadline can end the whole group instead of orphaning it on the GPU."""
+    proc = subprocess.Popen(cmd, start_new_session=True, **kw)
+    _CHILDREN.append(proc)
+    try:
+        rc = proc.wait(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        _kill_group(proc)
+        raise
+    finally:
+        if proc in _CHILDREN:
+            _CHILDREN.remove(proc)
+    if rc != 0:
+        raise subprocess.CalledProcessError(rc, cmd)
+
+
+def _kill_group(proc):
+    import signal
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)           # the exact process group this script started
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        proc.wait(timeout=10)
+    except Exception:                                  # noqa: BLE001
+        pass
+
+
+def measure_attn_traffic(rows, new, budget_s=480.0):
     """HBM bytes per decode-attention launch from PMC counters, measured NOW: a fresh child process per counter
     (`rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --traffic-child`, one configs[1] generate, nothing
     else; separate passes, no tracing domain beside --kernel-trace) — never this process re-executed.  Units and the
@@ -165,7 +197,12 @@ def measure_attn_traffic(rows, new):
     if not Path(rocprof).exists() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ):
         return None                                       # no profiler here, or this run is itself being profiled
     out = {}
+    t_end = time.monotonic() + budget_s
     for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        left = t_end - time.monotonic()
+        if left < 60:                                     # what remains of the extras deadline cannot hold a pass
+            log('traffic: not enough of the extras deadline left for a PMC pass')
+            return None
         tmp = tempfile.mkdtemp(prefix='vh_pmc_')
         env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR',
                                                                 'MASTER_PORT', 'LOCAL_WORLD_SIZE')}
@@ -174,8 +211,7 @@ def measure_attn_traffic(rows, new):
                sys.executable, str(Path(__file__).resolve()), '--traffic-child']
         log(f'traffic: {" ".join(cmd[:6])} ... (child process)')
         try:
-            subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240,
-                           check=True)
+            _run_child(cmd, min(240.0, left), cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             vals = []
             for path in glob.glob(f'{tmp}/**/*counter_collection.csv', recursive=True):
                 for r in csv.DictReader(open(path)):
@@ -207,16 +243,20 @@ def training_flop(cfg, model_name, batch, padded=False):
     d, dff, L = cfg.d_model, cfg.dim_feedforward, cfg.num_layers
     p_l = 4 * d * d + 2 * d * dff
     fwd = 0.0
+    # NAR: ONE prefix for the whole batch, taken from the PADDED frame count as the model does (prefix_len_of(codes.shape[1]),
+    # the reference's _prepare_audio_codes, valle_nar.py:179): a row's predicted positions are its real frames beyond it
+    t_pad = int(batch['codes'].shape[1])
+    prefix = min(t_pad // 3, 3 * cfg.quantization_factor)
     for b in range(batch['tokens'].shape[0]):
         x, y = int(batch['tokens_lens'][b]), int(batch['codes_lens'][b])
         if padded:
-            x, y = int(batch['tokens_lens'].max()), int(batch['codes_lens'].max())
+            x, y = int(batch['tokens_lens'].max()), t_pad if model_name != 'ValleAR' else int(batch['codes_lens'].max())
         if model_name == 'ValleAR':
             pairs = x * x + y * x + y * (y + 1) // 2
             head = 2.0 * d * (cfg.num_audio_tokens + 1) * y
         else:
-            pairs = (x + y) * (x + y)
-            head = 2.0 * d * cfg.num_audio_tokens * max(0, y - min(y // 3, 3 * cfg.quantization_factor))
+            pairs = (x + y) * (x + y)           # (real positions; the reference masks no padding here, D6: `padded` counts that)
+            head = 2.0 * d * cfg.num_audio_tokens * max(0, y - prefix)
         fwd += 2.0 * L * p_l * (x + y) + 4.0 * d * pairs * L + head
     return 3.0 * fwd
 
@@ -396,8 +436,9 @@ def train_leg(dev, world, rank, small):
                      f'DP x{world}' + (' (RCCL flat-bucket all-reduce overlapped with backward)' if world > 1 else ''),
            'bound': 'mfma', 'peak_tflops': MFMA_F32_PEAK_TF,
            'flop_rule': '3 x forward (fwd + 2 x bwd) over the real, unpadded positions of this rank: GEMMs 2 P_L per '
-                        'position and layer + attention 4 d per visible pair and layer + head (SURVEY 8d); *_frac = this '
-                        "rank's TFLOP/s / 157.3"}
+                        'position and layer + attention 4 d per visible pair and layer + head (SURVEY 8d); NAR head positions = '
+                        "a row's real frames beyond the batch's ONE prefix min(T_pad // 3, 150) (the model's rule, from the "
+                        "padded frame count) in both variants; *_frac = this rank's TFLOP/s / 157.3"}
     kw = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, batch_size=16)
     if small:
         kw.update(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, batch_size=4)
@@ -581,9 +622,13 @@ def main():
             print(json.dumps(result), flush=True)
 
     def on_deadline():
-        emit(f'optional legs exceeded {args.extras_deadline:.0f} s: line printed with what was measured')
-        os._exit(0)
+        result['legs_cut_by_deadline'] = True
+        emit(f'optional legs exceeded {args.extras_deadline:.0f} s: line printed with what was measured (legs_cut_by_deadline)')
+        for proc in list(_CHILDREN):                   # a PMC pass still in flight: end it, do not orphan it on the GPU
+            _kill_group(proc)
+        os._exit(0)                                    # the line is out and says so itself ('legs_cut_by_deadline': true)
 
+    t_extras = time.monotonic()
     watchdog = threading.Timer(args.extras_deadline, on_deadline)
     watchdog.daemon = True
     watchdog.start()
@@ -641,7 +686,9 @@ def main():
                     'marker_bracket_us = two marker events recorded around the same launch (event + dispatch overhead '
                     'included; not used), marker_floor_us = that bracket with nothing inside; traffic = PMC FETCH_SIZE/WRITE_SIZE from separate '
                     'rocprofv3 --pmc passes of this workload, committed under profiles/ (null when absent)'}
-        measured = None if (args.small or args.no_traffic or world > 1) else measure_attn_traffic(rows, new)
+        # (the PMC children get what is left of the extras deadline, less a reserve for the legs after them)
+        left = args.extras_deadline - (time.monotonic() - t_extras) - 240.0
+        measured = None if (args.small or args.no_traffic or world > 1) else measure_attn_traffic(rows, new, left)
         pmc = REPO / 'profiles' / 'attn_decode_traffic.json'
         if measured:
             result['roofline']['traffic'] = measured['bytes_per_launch']
