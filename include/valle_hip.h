@@ -83,7 +83,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_DECODE_COMBINE = 12, /* decode attention with key splits: 0 (default) = a second launch adds the split records,
                                        1 = the last workgroup of a (b, head) to arrive does, in the same launch (same bits:
                                        split order either way; measured 13 us per decode step slower at 4 beams x 8 splits) */
-       VH_TUNE_COUNT = 13 };
+       VH_TUNE_ATTN_BWD = 13,       /* vh_attn_rows_bwd_ws: 0 (default) / 2 = the five-product kernel + slab reduce, 1 = the two-kernel,
+                                       seven-product form of vh_attn_rows_bwd (its D scratch taken from the workspace) */
+       VH_TUNE_COUNT = 14 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- dropout field of the training path -------------------------------------------------------------
@@ -244,6 +246,18 @@ int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* 
                      float* dk, float* dv, int ldg, int B, int n_heads, int T, int S_max, int mode,
                      int x_len, const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
                      const uint8_t* pad, void* stream);
+
+/* The same gradients from FIVE products (round 4): one kernel with keys as lanes computes S, dP, dV, dK per (32-query tile,
+ * 256-key chunk) and sends dS through LDS into the chunk's dQ partial (mfma 16x16x4 over all the chunk's keys, no cross-wave
+ * sum); the partials of the ceil(T / 256) chunks land in slabs inside `ws` and a second launch adds them in chunk order
+ * (T <= 256: dq is written directly, one launch).  No atomics: bitwise reproducible.  ws: vh_attn_rows_bwd_ws_bytes bytes,
+ * 16-byte aligned, scratch.  D = rowsum(dout * out) is computed in the kernel (no dsum argument). */
+size_t vh_attn_rows_bwd_ws_bytes(int B, int n_heads, int T);
+int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache, const float* vcache, const float* out,
+                        int ldo, const float* dout, int lddo, const float* lse2, float* dq, float* dk, float* dv,
+                        int ldg, int B, int n_heads, int T, int S_max, int mode, int x_len,
+                        const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
+                        const uint8_t* pad, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K8b: single-row decode attention over the KV cache (HBM-bound) -------------------------
  * replaces SDPA with q-len 1 (valle/models/modules.py:167 reached via :336-338).

@@ -381,9 +381,20 @@ def test_flat_adamw_gradient_accumulation_adds_onto_the_adopted_slices():
 
 
 # ---- attention backward kernels (vh_attn_rows_bwd) directly against torch autograd -----------------------
+@pytest.mark.parametrize('form', [0, 1])         # VH_TUNE_ATTN_BWD: 0 = five products in one kernel + slab reduce, 1 = two kernels
 @pytest.mark.parametrize('B,h,T,mode', [(2, 2, 70, 'prefix'), (3, 2, 300, 'prefix'), (2, 4, 257, 'full'),
-                                         (1, 2, 129, 'explicit'), (2, 1, 33, 'full')])
-def test_attn_rows_bwd_vs_torch_autograd(B, h, T, mode):
+                                         (1, 2, 129, 'explicit'), (2, 1, 33, 'full'), (2, 2, 1021, 'prefix'),
+                                         (2, 1, 640, 'full'), (1, 2, 515, 'explicit'), (1, 1, 256, 'prefix')])
+def test_attn_rows_bwd_vs_torch_autograd(B, h, T, mode, form):
+    from valle2_amd import _lib
+    _lib.lib().vh_set_tuning(13, form)
+    try:
+        _attn_rows_bwd_vs_torch_autograd(B, h, T, mode)
+    finally:
+        _lib.lib().vh_set_tuning(13, 0)
+
+
+def _attn_rows_bwd_vs_torch_autograd(B, h, T, mode):
     from oracle.valle_oracle import build_attn_mask
     from valle2_amd import kernels as K
     d = 64 * h

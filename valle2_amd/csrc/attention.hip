@@ -801,6 +801,8 @@ struct BwdArgs {
     const int32_t* x_len_dev; const int32_t* kv_len;
     const uint8_t* mask; const uint8_t* pad;
     int n_blocks;
+    float* slab;                      // fused form: dQ partial sums, (n_blocks, B*h, T, 64); null = one key chunk, dq written directly
+    int chunk_keys;                   // fused form: keys per workgroup (a multiple of 32, <= 256)
 };
 
 __device__ __forceinline__ bool bwd_visible(const BwdArgs& a, int b, int qi, int key, int kvl, int xl) {
@@ -1099,6 +1101,262 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
     }
 }
 
+// =============================================================================================
+// many-row attention, backward, FIVE products in one kernel (round 4).  The keys-as-lanes kernel above already holds
+// dS[q][key] in registers; dQ = dS·K contracts over the key, which is the LANE index of those registers, so the
+// two-kernel form recomputes S and dP in a second kernel with queries as lanes (7 products).  Here dS makes one trip
+// through LDS instead: a workgroup of 8 waves owns a chunk of up to 256 keys (K transposed into LDS once per
+// workgroup), every wave writes its 32 x 32 block of dS into a shared [32 q][256 keys] tile, and after a barrier each
+// wave computes ONE 16 x 16 block of the tile's dQ (4 d-blocks x 2 q-blocks = 8 waves) over ALL the chunk's keys on
+// mfma_f32_16x16x4 — no cross-wave reduction.  Both operands are read with ds_read_b128: four consecutive keys per
+// lane (the contraction index of four consecutive MFMAs is permuted accordingly: key(u, g, j) = 16u + 4g + j), rows
+// XOR-swizzled by (row & 15) in 16-byte slots, which is conflict-free for the instruction's four 16-lane groups.
+// The dQ partial of a (query tile, key chunk) pair goes to slab `chunk` — (n_chunks, B*h, T, 64), T/256 = 4 slabs at the
+// training shape — and attn_dq_reduce_kernel adds the slabs in chunk order: bitwise reproducible, no atomics.
+// D = rowsum(dO∘O) is computed while the dO / O rows are staged (the dq kernel used to do it).
+// =============================================================================================
+#define FW 8            // waves per workgroup
+#define FKMAX 256       // keys per workgroup at most (FW x 32)
+
+__global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
+    // [buf][Q|dO][query][KLD] | [buf][lse|D][32] | Kt [64 d][256 keys] | dS [32 q][256 keys]
+    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KLD + 2 * 2 * KT + HD * FKMAX + KT * FKMAX];
+    float* const stat = lds + 2 * 2 * KT * KLD;
+    float* const kt = stat + 2 * 2 * KT;
+    float* const dsb = kt + HD * FKMAX;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n_bh = gridDim.x / a.n_blocks;
+    const int bh = blockIdx.x % n_bh, b = bh / a.n_heads, head = bh - b * a.n_heads;
+    const int chunk = (int)(blockIdx.x / n_bh);                 // chunk 0 first: under the prefix mask it sees every query
+    const int kb0 = chunk * a.chunk_keys;
+    const int kend = min(kb0 + a.chunk_keys, a.T);              // keys [kb0, kend) belong to this workgroup
+    const int kvl = a.kv_len ? min(a.kv_len[b], a.T) : a.T;
+    const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
+    const int sq = tid >> 4, squad = (tid & 15) * 4;            // staging: one row chunk per thread per operand
+
+    if (a.mode != VH_MASK_EXPLICIT && kb0 >= kvl) {
+        // every key of the chunk is padding: dK = dV = 0, no dQ contribution (the reduce kernel skips this chunk too)
+        for (int row = kb0 + sq; row < kend; row += 32) {
+            const int64_t o = ((int64_t)b * a.T + row) * a.ldg + head * HD + squad;
+            st4(a.dk + o, f32x4{0.f, 0.f, 0.f, 0.f});
+            st4(a.dv + o, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        return;
+    }
+    int qmin = 0;
+    if (a.mode == VH_MASK_PREFIX && kb0 >= xl) qmin = kb0;
+    const int t_first = qmin / KT, n_tiles = (a.T + KT - 1) / KT;
+
+    const int wk_min = kb0 + w * 32, wk_max = wk_min + 31;
+    const int kj = wk_min + r;                   // this lane's key
+    const bool kin = kj < kend;
+    const float qscale = 0.125f * LOG2E;
+    f32x4 kf[8], vf[8];
+    {
+        const int64_t krow = (int64_t)bh * a.S_max + min(kj, a.T - 1);
+        const float* kp = a.kc + krow * HD + 4 * h;
+        const float* vp = a.vc + krow * HD + 4 * h;
+        const int kl = w * 32 + r;               // key inside the chunk
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            kf[t] = ld4(kp + 8 * t);
+            vf[t] = ld4(vp + 8 * t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {        // Kt[d][key], 16-byte slot (key >> 2) XOR-swizzled by d & 15
+                const int d = 8 * t + 4 * h + j;
+                kt[d * FKMAX + ((((kl >> 2) ^ (d & 15)) << 2) | (kl & 3))] = kf[t][j];
+            }
+            kf[t] = kf[t] * qscale;
+        }
+    }
+    f32x4 rq, rd;
+    float rlse = 0.f, rdsum = 0.f;
+    const float* qbase = a.q + (int64_t)b * a.T * a.ldq + head * HD;
+    const float* dbase = a.dout + (int64_t)b * a.T * a.lddo + head * HD;
+    const float* obase = a.o + (int64_t)b * a.T * a.ldo + head * HD;
+    auto gload = [&](int q0t) {
+        const int qrow = min(q0t + sq, a.T - 1);
+        rq = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
+        rd = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
+        const f32x4 ro = ld4((const float*)((const char*)obase + (uint32_t)(qrow * a.ldo + squad) * 4u));
+        rdsum = row16_sum((rd.x * ro.x + rd.y * ro.y) + (rd.z * ro.z + rd.w * ro.w));     // D of row q0t + sq
+        if (tid < KT) rlse = a.lse2[(int64_t)bh * a.T + min(q0t + tid, a.T - 1)];
+    };
+    auto lstore = [&](int buf) {
+        float* qd = lds + buf * (2 * KT * KLD);
+        st4(qd + sq * KLD + squad, rq);
+        st4(qd + KT * KLD + sq * KLD + squad, rd);
+        if (tid < KT) stat[buf * 2 * KT + tid] = rlse;
+        if ((tid & 15) == 0) stat[buf * 2 * KT + KT + sq] = rdsum;
+    };
+    f32x16 GK0, GK1, GV0, GV1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { GK0[e] = 0.f; GK1[e] = 0.f; GV0[e] = 0.f; GV1[e] = 0.f; }
+    // the dQ block of this wave: d0 = 16 (w & 3), q0 = 16 (w >> 2); lane (i, g) reads row i of both operands
+    const int mi = lane & 15, mg = lane >> 4;
+    const float* ap = kt + (16 * (w & 3) + mi) * FKMAX;
+    const float* bp = dsb + (16 * (w >> 2) + mi) * FKMAX;
+    const int n_waves_keys = (kend - kb0 + 31) >> 5;            // waves that own at least one key of the chunk
+    if (t_first < n_tiles) {
+        gload(t_first * KT);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int qt = t_first; qt < n_tiles; ++qt) {
+        const int cur = (qt - t_first) & 1, q0t = qt * KT;
+        if (qt + 1 < n_tiles) gload(q0t + KT);
+        // waves of this workgroup that see a query of the tile: a prefix of the waves (every term falls with the key index)
+        int n_act = n_waves_keys;
+        if (a.mode != VH_MASK_EXPLICIT) {
+            n_act = min(n_act, (kvl - kb0 + 31) >> 5);
+            if (a.mode == VH_MASK_PREFIX) {
+                // wave v is active iff kb0 + 32 v < xl  or  kb0 + 32 v <= q0t + 31
+                const int lim = max(xl - 1, q0t + KT - 1) - kb0;   // largest admissible 32 v
+                n_act = min(n_act, lim < 0 ? 0 : (lim >> 5) + 1);
+            }
+        }
+        const bool any = w < n_act;
+        const float* qs = lds + cur * (2 * KT * KLD);
+        const float* ds = qs + KT * KLD;
+        const float* st = stat + cur * 2 * KT;
+        if (any) {
+            f32x16 S, P;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 qv = ld4(qs + r * KLD + 8 * t + 4 * h);
+                const f32x4 dv = ld4(ds + r * KLD + 8 * t + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    S = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[j], kf[t][j], (t | j) ? S : f32x16{}, 0, 0, 0);   // S[q][key]
+                    P = __builtin_amdgcn_mfma_f32_32x32x2f32(dv[j], vf[t][j], (t | j) ? P : f32x16{}, 0, 0, 0);   // dP[q][key]
+                }
+            }
+            bool all = wk_max < min(kvl, kend) && q0t + KT <= a.T;
+            if (a.mode == VH_MASK_PREFIX) all = all && (wk_max < xl || (q0t >= xl && wk_max <= q0t));
+            else if (a.mode == VH_MASK_EXPLICIT) all = false;
+            if (all) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 lse4 = ld4(st + 8 * g4 + 4 * h);
+                    const f32x4 d4 = ld4(st + KT + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const float p = vh_exp2(S[e] - lse4[j]);
+                        S[e] = p;                                   // P[q][key]
+                        P[e] = p * (P[e] - d4[j]);                  // dS[q][key]
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const f32x4 lse4 = ld4(st + 8 * g4 + 4 * h);
+                    const f32x4 d4 = ld4(st + KT + 8 * g4 + 4 * h);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = 4 * g4 + j;
+                        const int qi = q0t + 8 * g4 + 4 * h + j;
+                        const bool vis = kin && qi < a.T && bwd_visible(a, b, qi, kj, kvl, xl);
+                        const float p = vis ? vh_exp2(S[e] - lse4[j]) : 0.f;
+                        S[e] = p;
+                        P[e] = p * (P[e] - d4[j]);
+                    }
+                }
+            }
+            // dS → the shared tile, [q][key] with the slot swizzle: one ds_write_b32 per register, 32 consecutive keys per half-wave
+            {
+                const int kl = w * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int qrow = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    dsb[qrow * FKMAX + ((((kl >> 2) ^ (qrow & 15)) << 2) | (kl & 3))] = P[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qrow = (e & 3) + 8 * (e >> 2) + 4 * h;
+                const float* dorow = ds + qrow * KLD + r;
+                const float* qrowp = qs + qrow * KLD + r;
+                GV0 = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[0], S[e], GV0, 0, 0, 0);    // dVᵀ[d][key]
+                GV1 = __builtin_amdgcn_mfma_f32_32x32x2f32(dorow[32], S[e], GV1, 0, 0, 0);
+                GK0 = __builtin_amdgcn_mfma_f32_32x32x2f32(qrowp[0], P[e], GK0, 0, 0, 0);    // dKᵀ[d][key]
+                GK1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qrowp[32], P[e], GK1, 0, 0, 0);
+            }
+        }
+        __syncthreads();                     // the dS blocks of the n_act active waves are in LDS
+        {
+            // dQ[q][d] block = Σ_key dS[q][key]·K[key][d] over the active waves' keys: A = Kᵀ rows (d), B = dS rows (q)
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+            for (int u = 0; u < 2 * n_act; ++u) {
+                const int slot = ((4 * u + mg) ^ mi) << 2;
+                const f32x4 a4 = ld4(ap + slot);
+                const f32x4 b4 = ld4(bp + slot);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b4[0], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b4[1], c1, 0, 0, 0);
+                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b4[2], c2, 0, 0, 0);
+                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b4[3], c3, 0, 0, 0);
+            }
+            f32x4 c = (c0 + c1) + (c2 + c3);             // lane (q = mi, d = 4 mg + e)
+            const int qi = q0t + 16 * (w >> 2) + mi;
+            const int dcol = 16 * (w & 3) + 4 * mg;
+            if (qi < a.T) {
+                if (a.slab) st4(a.slab + (((int64_t)chunk * n_bh + bh) * a.T + qi) * HD + dcol, c);
+                else st4(a.dq + ((int64_t)b * a.T + qi) * a.ldg + head * HD + dcol, c * 0.125f);
+            }
+        }
+        if (qt + 1 < n_tiles) lstore(cur ^ 1);
+        __syncthreads();                     // next tile staged; every wave is done with this tile's dS
+    }
+    // ---- dK, dV: transposed through LDS (everything above is dead), whole rows out
+    float* ob = lds;                         // [256][KLD]
+    for (int which = 0; which < 2; ++which) {
+        const f32x16& A0 = which ? GV0 : GK0;
+        const f32x16& A1 = which ? GV1 : GK1;
+        const float sc = which ? 1.0f : 0.125f;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 v0 = {A0[4 * g4], A0[4 * g4 + 1], A0[4 * g4 + 2], A0[4 * g4 + 3]};
+            f32x4 v1 = {A1[4 * g4], A1[4 * g4 + 1], A1[4 * g4 + 2], A1[4 * g4 + 3]};
+            st4(ob + (w * 32 + r) * KLD + 8 * g4 + 4 * h, v0 * sc);
+            st4(ob + (w * 32 + r) * KLD + 32 + 8 * g4 + 4 * h, v1 * sc);
+        }
+        __syncthreads();
+        float* dst = which ? a.dv : a.dk;
+#pragma unroll
+        for (int i = 0; i < FW; ++i) {
+            const int row = sq + 32 * i;
+            if (kb0 + row < kend)
+                st4(dst + ((int64_t)b * a.T + kb0 + row) * a.ldg + head * HD + squad, ld4(ob + row * KLD + squad));
+        }
+        __syncthreads();
+    }
+}
+
+// dq[row][head*64 + d] = 1/8 · Σ_chunks slab[chunk][b,head][q][d], chunks in index order; a chunk contributes to a query
+// exactly when the fused kernel visited the pair (same rule, so no slab element is read that was not written).
+__global__ __launch_bounds__(256) void attn_dq_reduce_kernel(BwdArgs a, int64_t n4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n4) return;
+    const int d4 = (int)(idx & 15);
+    const int64_t rh = idx >> 4;
+    const int head = (int)(rh % a.n_heads);
+    const int64_t row = rh / a.n_heads;
+    const int b = (int)(row / a.T), q = (int)(row - (int64_t)b * a.T);
+    const int kvl = a.kv_len ? min(a.kv_len[b], a.T) : a.T;
+    const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
+    const int64_t n_bh = (int64_t)(n4 / 16 / a.T / a.n_heads) * a.n_heads;   // B * h
+    const int bh = b * a.n_heads + head;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.n_blocks; ++c) {
+        const int kb0 = c * a.chunk_keys;
+        if (a.mode != VH_MASK_EXPLICIT && kb0 >= kvl) break;
+        if (a.mode == VH_MASK_PREFIX && kb0 >= xl && q < kb0) break;
+        acc = acc + ld4(a.slab + (((int64_t)c * n_bh + bh) * a.T + q) * HD + 4 * d4);
+    }
+    st4(a.dq + row * a.ldg + head * HD + 4 * d4, acc * 0.125f);
+}
+
 extern "C" int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* vcache,
                                 const float* out, int ldo, const float* dout, int lddo, const float* lse2,
                                 float* dsum, float* dq, float* dk, float* dv, int ldg, int B, int n_heads,
@@ -1120,10 +1378,60 @@ extern "C" int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, co
     if (B == 0 || T == 0) return VH_OK;
     const int nb = (T + QB - 1) / QB;
     BwdArgs a{q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, dsum, dq, dk, dv, ldg,
-              n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nb};
+              n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nb, nullptr, 0};
     dim3 grid(nb * B * n_heads);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     VH_CHECK_LAUNCH("vh_attn_rows_bwd");
+    return VH_OK;
+}
+
+// ---- the same gradients with a caller-provided workspace: the five-product kernel + slab reduce (default), or the
+// two-kernel form above with its D scratch inside the workspace (VH_TUNE_ATTN_BWD = 1)
+static int bwd_chunks(int T) { return (T + FKMAX - 1) / FKMAX; }
+
+extern "C" size_t vh_attn_rows_bwd_ws_bytes(int B, int n_heads, int T) {
+    if (B <= 0 || n_heads <= 0 || T <= 0) return 0;
+    const int nc = bwd_chunks(T);
+    const size_t slabs = nc > 1 ? (size_t)nc * B * n_heads * T * HD * sizeof(float) : 0;
+    const size_t dsum = ((size_t)B * n_heads * T * sizeof(float) + 15) & ~(size_t)15;
+    return slabs > dsum ? slabs : dsum;
+}
+
+extern "C" int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache, const float* vcache,
+                                   const float* out, int ldo, const float* dout, int lddo, const float* lse2,
+                                   float* dq, float* dk, float* dv, int ldg, int B, int n_heads, int T, int S_max,
+                                   int mode, int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
+                                   const uint8_t* mask, const uint8_t* pad, void* ws, size_t ws_bytes, void* stream) {
+    VH_REQUIRE(B < 0 || T < 0 || n_heads <= 0 || ws_bytes >= vh_attn_rows_bwd_ws_bytes(B, n_heads, T), VH_EINVAL,
+               "vh_attn_rows_bwd_ws: workspace of %zu bytes, need %zu", ws_bytes, vh_attn_rows_bwd_ws_bytes(B, n_heads, T));
+    VH_REQUIRE(ws && vh_aligned16(ws), VH_EALIGN, "vh_attn_rows_bwd_ws: workspace must be a 16-byte aligned device pointer");
+    if (vh_tuning(VH_TUNE_ATTN_BWD) == 1)
+        return vh_attn_rows_bwd(q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, (float*)ws, dq, dk, dv, ldg, B,
+                                n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, stream);
+    VH_REQUIRE(q && kcache && vcache && out && dout && lse2 && dq && dk && dv, VH_EINVAL,
+               "vh_attn_rows_bwd_ws: null pointer");
+    VH_REQUIRE(B >= 0 && n_heads > 0 && T >= 0 && S_max >= T, VH_EINVAL,
+               "vh_attn_rows_bwd_ws: bad dims B=%d h=%d T=%d S_max=%d", B, n_heads, T, S_max);
+    VH_REQUIRE(mode == VH_MASK_FULL || mode == VH_MASK_PREFIX || (mode == VH_MASK_EXPLICIT && mask), VH_EINVAL,
+               "vh_attn_rows_bwd_ws: mode=%d", mode);
+    const int wd = n_heads * HD;
+    VH_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && lddo % 4 == 0 && ldg % 4 == 0 && ldq >= wd && ldo >= wd &&
+                   lddo >= wd && ldg >= wd,
+               VH_EINVAL, "vh_attn_rows_bwd_ws: leading dimensions");
+    VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kcache) && vh_aligned16(vcache) && vh_aligned16(out) &&
+                   vh_aligned16(dout) && vh_aligned16(dq) && vh_aligned16(dk) && vh_aligned16(dv),
+               VH_EALIGN, "vh_attn_rows_bwd_ws: pointers must be 16-byte aligned");
+    if (B == 0 || T == 0) return VH_OK;
+    const int nc = bwd_chunks(T);
+    const int chunk_keys = ((T + nc - 1) / nc + 31) / 32 * 32;       // equal chunks of whole 32-key wave blocks
+    BwdArgs a{q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, nullptr, dq, dk, dv, ldg,
+              n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nc, nc > 1 ? (float*)ws : nullptr, chunk_keys};
+    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(nc * B * n_heads), dim3(FW * 64), 0, (hipStream_t)stream, a);
+    if (nc > 1) {
+        const int64_t n4 = (int64_t)B * T * n_heads * 16;
+        hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, n4);
+    }
+    VH_CHECK_LAUNCH("vh_attn_rows_bwd_ws");
     return VH_OK;
 }

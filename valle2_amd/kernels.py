@@ -278,18 +278,23 @@ def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_d
 def attn_rows_bwd(q, kcache, vcache, out, dout, lse2, dq, dk, dv, B, n_heads, T, mode, x_len=0,
                   x_len_dev=None, kv_len=None, mask=None, pad=None):
     """dq, dk, dv (each (B*T, d) views with a common row stride, heads at columns h*64) of
-    attn_rows(q, kcache, vcache) given dout; P is recomputed tile by tile, never materialised."""
+    attn_rows(q, kcache, vcache) given dout; P is recomputed tile by tile, never materialised.  Five products in one
+    kernel + the slab reduce (vh_attn_rows_bwd_ws); `_lib.lib().vh_set_tuning(VH_TUNE_ATTN_BWD = 13, 1)` selects the
+    older two-kernel, seven-product form."""
     S_max = kcache.shape[2]
     if tuple(kcache.shape) != (B, n_heads, S_max, HEAD_DIM) or kcache.shape != vcache.shape or T > S_max:
         raise _lib.VhError(f'attn_rows_bwd: cache {tuple(kcache.shape)} T={T}')
     if not (dq.stride(0) == dk.stride(0) == dv.stride(0)) or dq.stride(1) != 1:
         raise _lib.VhError('attn_rows_bwd: dq/dk/dv must share one row stride')
-    dsum = torch.empty(B, n_heads, T, device=q.device, dtype=torch.float32)
-    check(_lib.lib().vh_attn_rows_bwd(
+    # scratch from torch's caching allocator (stream-ordered reuse): the dQ partial slabs of the five-product kernel
+    # (ceil(T / 256) x (B*h, T, 64) floats) or, under VH_TUNE_ATTN_BWD = 1, the two-kernel form's D vector
+    need = _lib.lib().vh_attn_rows_bwd_ws_bytes(B, n_heads, T)
+    ws = torch.empty(max(need, 16) // 4, device=q.device, dtype=torch.float32)
+    check(_lib.lib().vh_attn_rows_bwd_ws(
         q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0),
-        dout.data_ptr(), dout.stride(0), ptr(lse2), ptr(dsum), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+        dout.data_ptr(), dout.stride(0), ptr(lse2), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
         dq.stride(0), B, n_heads, T, S_max, mode, x_len, ptr(x_len_dev), ptr(kv_len), ptr(mask), ptr(pad),
-        stream()), 'vh_attn_rows_bwd')
+        ptr(ws), ws.numel() * 4, stream()), 'vh_attn_rows_bwd_ws')
     return dq, dk, dv
 
 
