@@ -75,7 +75,12 @@ def ids_to_device(ids, device, vocab, what):
     reference's nn.Embedding raises IndexError); device-resident ids are checked by the kernels
     (`_lib.raise_device_errors`)."""
     if not ids.is_cuda and ids.numel():
-        lo, hi = int(ids.min()), int(ids.max())
+        # numpy on the tensor's own memory, not torch's CPU reductions: those fan a 70 k-element min / max out over
+        # every core `os.cpu_count()` reports (256 on a GPU box whose cgroup grants 16) and then cost 2-70 ms per
+        # call, erratically — the NAR training step with host-resident batches ran at 40-60 ms instead of 28
+        # (gpurun_out/nar_host.log, round 4); numpy's single-threaded pass over the same bytes takes ~30 us
+        a = ids.detach().numpy()
+        lo, hi = int(a.min()), int(a.max())
         if lo < 0 or hi >= vocab:
             raise IndexError(f'{what}: id {lo if lo < 0 else hi} is outside [0, {vocab}) (index out of range)')
     return _lib.to_device_async(ids, device)
