@@ -85,7 +85,9 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
                                        split order either way; measured 13 us per decode step slower at 4 beams x 8 splits) */
        VH_TUNE_ATTN_BWD = 13,       /* vh_attn_rows_bwd_ws: 0 (default) / 2 = the five-product kernel + slab reduce, 1 = the two-kernel,
                                        seven-product form of vh_attn_rows_bwd (its D scratch taken from the workspace) */
-       VH_TUNE_COUNT = 14 };
+       VH_TUNE_ATTN_BWD_CHUNKS = 14, /* five-product attention backward: key chunks per (batch row, head); 0 (default) = chosen from the
+                                       shape (bwd_chunks in csrc/attention.hip), else that many (at least ceil(T / 256)) */
+       VH_TUNE_COUNT = 15 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- dropout field of the training path -------------------------------------------------------------
@@ -253,6 +255,8 @@ int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, const float* 
  * (T <= 256: dq is written directly, one launch).  No atomics: bitwise reproducible.  ws: vh_attn_rows_bwd_ws_bytes bytes,
  * 16-byte aligned, scratch.  D = rowsum(dout * out) is computed in the kernel (no dsum argument). */
 size_t vh_attn_rows_bwd_ws_bytes(int B, int n_heads, int T);
+/* the number of key chunks (= dQ slabs) vh_attn_rows_bwd_ws uses for this shape and mask family (tools, tests) */
+int vh_attn_rows_bwd_chunks(int B, int n_heads, int T, int mode);
 int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache, const float* vcache, const float* out,
                         int ldo, const float* dout, int lddo, const float* lse2, float* dq, float* dk, float* dv,
                         int ldg, int B, int n_heads, int T, int S_max, int mode, int x_len,

@@ -1,7 +1,7 @@
 """Training-step timing at BASELINE.json configs[3]: 12L/512d AR and NAR forward+backward, per-GPU
 batch 16, LibriTTS-shaped synthetic batches (tokens 40..120, codes 225..900), fp32.  Developer tool
 (the graded bench is bench.py); under torch.distributed.run it averages gradients over RCCL.
-usage: python tools/bench_train.py [steps=5] [dropout=0.1]   (dropout = config.dropout: dropout1 / dropout2 / FeedForward
+usage: python tools/bench_train.py [steps=5] [dropout=0.1] [attn_bwd=1] [only=ar|nar]   (attn_bwd: VH_TUNE_ATTN_BWD; dropout = config.dropout: dropout1 / dropout2 / FeedForward
 dropout; the PositionalEncoding dropout 0.1 is live in train mode either way, D9)"""
 import os
 import sys
@@ -15,13 +15,17 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from valle2_amd import ConfigValle, dp, get_model_class, synth  # noqa: E402
 
 
-def main(steps=5, dropout=0.0):
+def main(steps=5, dropout=0.0, attn_bwd=0, only=''):
     os.chdir(tempfile.mkdtemp())
     rank, local, world = dp.env_world()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
     dp.init_distributed('nccl', dev)
+    from valle2_amd import _lib
+    _lib.lib().vh_set_tuning(13, attn_bwd)
     for name, norm in (('ValleAR', 'LayerNorm'), ('ValleNAR', 'AdaptiveLayerNorm')):
+        if only and only not in name.lower():
+            continue
         cfg = ConfigValle(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=dropout, norm=norm,
                           batch_size=16)
         torch.manual_seed(0)
@@ -60,4 +64,4 @@ def main(steps=5, dropout=0.0):
 
 if __name__ == '__main__':
     kv = dict(a.split('=') for a in sys.argv[1:])
-    main(int(kv.get('steps', 5)), float(kv.get('dropout', 0.0)))
+    main(int(kv.get('steps', 5)), float(kv.get('dropout', 0.0)), int(kv.get('attn_bwd', 0)), kv.get('only', ''))

@@ -108,6 +108,7 @@ SIGNATURES = {
                                    c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p]),
     'vh_attn_rows_bwd_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_attn_rows_bwd_chunks': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'vh_attn_rows_bwd_ws': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, c_f32p,
                                       c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_int, c_i32p, c_i32p, c_u8p, c_u8p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -15,7 +15,11 @@
 //                       workspace.   HBM-bound (algorithmic bytes = 2·len·64·4 per (b,head)).
 #include <hip/hip_ext.h>
 #include "vh_common.h"
+#include <mutex>
+#include <queue>
 #include <type_traits>
+#include <unordered_map>
+#include <vector>
 
 #define HD VH_HEAD_DIM
 #define LOG2E 1.44269504088896340736f
@@ -1170,25 +1174,31 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
             kf[t] = kf[t] * qscale;
         }
     }
-    f32x4 rq, rd;
-    float rlse = 0.f, rdsum = 0.f;
+    f32x4 rq, rd, ro;
+    float rlse = 0.f;
     const float* qbase = a.q + (int64_t)b * a.T * a.ldq + head * HD;
     const float* dbase = a.dout + (int64_t)b * a.T * a.lddo + head * HD;
     const float* obase = a.o + (int64_t)b * a.T * a.ldo + head * HD;
+    // loads only: nothing here may wait for them.  Q and dO rows are requested at the top of a tile and land under its
+    // MFMAs; the O row (needed only for D) and lse are requested after the tile's first barrier, when the S / dP
+    // registers are dead (the kernel sits at the register limit), and land under the dQ product.
     auto gload = [&](int q0t) {
         const int qrow = min(q0t + sq, a.T - 1);
         rq = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
         rd = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
-        const f32x4 ro = ld4((const float*)((const char*)obase + (uint32_t)(qrow * a.ldo + squad) * 4u));
-        rdsum = row16_sum((rd.x * ro.x + rd.y * ro.y) + (rd.z * ro.z + rd.w * ro.w));     // D of row q0t + sq
+    };
+    auto gload_late = [&](int q0t) {
+        const int qrow = min(q0t + sq, a.T - 1);
+        ro = ld4((const float*)((const char*)obase + (uint32_t)(qrow * a.ldo + squad) * 4u));
         if (tid < KT) rlse = a.lse2[(int64_t)bh * a.T + min(q0t + tid, a.T - 1)];
     };
     auto lstore = [&](int buf) {
         float* qd = lds + buf * (2 * KT * KLD);
         st4(qd + sq * KLD + squad, rq);
         st4(qd + KT * KLD + sq * KLD + squad, rd);
+        const float dsum = row16_sum((rd.x * ro.x + rd.y * ro.y) + (rd.z * ro.z + rd.w * ro.w));   // D of the staged row
         if (tid < KT) stat[buf * 2 * KT + tid] = rlse;
-        if ((tid & 15) == 0) stat[buf * 2 * KT + KT + sq] = rdsum;
+        if ((tid & 15) == 0) stat[buf * 2 * KT + KT + sq] = dsum;
     };
     f32x16 GK0, GK1, GV0, GV1;
 #pragma unroll
@@ -1200,6 +1210,7 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
     const int n_waves_keys = (kend - kb0 + 31) >> 5;            // waves that own at least one key of the chunk
     if (t_first < n_tiles) {
         gload(t_first * KT);
+        gload_late(t_first * KT);
         lstore(0);
     }
     __syncthreads();
@@ -1285,24 +1296,30 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
             }
         }
         __syncthreads();                     // the dS blocks of the n_act active waves are in LDS
+        if (qt + 1 < n_tiles) gload_late(q0t + KT);
         {
             // dQ[q][d] block = Σ_key dS[q][key]·K[key][d] over the active waves' keys: A = Kᵀ rows (d), B = dS rows (q)
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
-            for (int u = 0; u < 2 * n_act; ++u) {
-                const int slot = ((4 * u + mg) ^ mi) << 2;
-                const f32x4 a4 = ld4(ap + slot);
-                const f32x4 b4 = ld4(bp + slot);
+            const int nu = 2 * n_act;                    // 16-key groups of the active waves (n_act >= 1 on every visited tile)
+            f32x4 a4 = ld4(ap + ((mg ^ mi) << 2)), b4 = ld4(bp + ((mg ^ mi) << 2));
+            for (int u = 0; u < nu; ++u) {               // operands of group u + 1 requested BEFORE group u's MFMAs
+                const int slot = ((4 * min(u + 1, nu - 1) + mg) ^ mi) << 2;
+                const f32x4 an = ld4(ap + slot), bn = ld4(bp + slot);
+                __builtin_amdgcn_sched_barrier(0);       // (left alone the compiler sinks the reads below the MFMAs)
                 c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b4[0], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b4[1], c1, 0, 0, 0);
                 c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b4[2], c2, 0, 0, 0);
                 c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b4[3], c3, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a4 = an;
+                b4 = bn;
             }
             f32x4 c = (c0 + c1) + (c2 + c3);             // lane (q = mi, d = 4 mg + e)
             const int qi = q0t + 16 * (w >> 2) + mi;
-            const int dcol = 16 * (w & 3) + 4 * mg;
-            if (qi < a.T) {
-                if (a.slab) st4(a.slab + (((int64_t)chunk * n_bh + bh) * a.T + qi) * HD + dcol, c);
-                else st4(a.dq + ((int64_t)b * a.T + qi) * a.ldg + head * HD + dcol, c * 0.125f);
+            const uint32_t dcol = 16 * (w & 3) + 4 * mg;
+            if (qi < a.T) {                              // wave-uniform 64-bit base + one 32-bit lane offset
+                if (a.slab) st4((float*)((char*)(a.slab + ((int64_t)chunk * n_bh + bh) * a.T * HD) + (uint32_t)(qi * HD + dcol) * 4u), c);
+                else st4((float*)((char*)(a.dq + (int64_t)b * a.T * a.ldg + head * HD) + (uint32_t)(qi * a.ldg + dcol) * 4u), c * 0.125f);
             }
         }
         if (qt + 1 < n_tiles) lstore(cur ^ 1);
@@ -1388,11 +1405,66 @@ extern "C" int vh_attn_rows_bwd(const float* q, int ldq, const float* kcache, co
 
 // ---- the same gradients with a caller-provided workspace: the five-product kernel + slab reduce (default), or the
 // two-kernel form above with its D scratch inside the workspace (VH_TUNE_ATTN_BWD = 1)
-static int bwd_chunks(int T) { return (T + FKMAX - 1) / FKMAX; }
+// Key chunks per (batch row, head): at least ceil(T / 256) (a workgroup holds 256 keys), more when that evens out the
+// launch.  Model, calibrated with tools/sweep_attn_bwd_chunks.py (profiles/r4_sweep_attn_bwd_chunks.log): workgroups are
+// dealt one per CU in index order (chunk 0 first) to whichever CU frees up; a workgroup's time is its query tiles x
+// 1.0 with 5..8 active 32-key waves (two per SIMD) or x 0.6 with <= 4 (one per SIMD: 10.7 vs 6.5 us per tile); under the
+// prefix mask chunk c only sees the query tiles from its first key on; every chunk adds a slab of dQ partials
+// (B*h*T*512 bytes written and read at ~5 TB/s).  The launch is simulated for every admissible count (chunks of 97..256
+// keys) and the cheapest taken; results are cached per shape.
+static int bwd_chunks_model(int bh, int T, bool causal) {
+    const int nc_min = (T + FKMAX - 1) / FKMAX, nc_max = max(nc_min, (T + 127) / 128);
+    int best = nc_min;
+    double best_cost = 1e300;
+    const int n_tiles = (T + KT - 1) / KT;
+    for (int nc = nc_min; nc <= nc_max; ++nc) {
+        const int keys = ((T + nc - 1) / nc + 31) / 32 * 32;
+        if ((int64_t)keys * (nc - 1) >= T) continue;                     // the last chunk would be empty
+        const double unit = keys > 128 ? 1.0 : 0.6;
+        std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
+        for (int i = 0; i < 256; ++i) cu.push(0.0);
+        double end = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            const double work = unit * (causal ? n_tiles - c * keys / KT : n_tiles);
+            for (int j = 0; j < bh; ++j) {
+                const double t = cu.top() + work;
+                cu.pop();
+                cu.push(t);
+                end = t > end ? t : end;
+            }
+        }
+        const double cost = end + (nc > 1 ? 1e-5 * nc * bh * (double)T : 0.0);
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = nc; }
+    }
+    return best;
+}
+
+static int bwd_chunks(int B, int n_heads, int T, bool causal) {
+    const int nc_min = (T + FKMAX - 1) / FKMAX;
+    const int forced = vh_tuning(VH_TUNE_ATTN_BWD_CHUNKS);
+    if (forced > 0) {
+        int nc = max(nc_min, min(forced, (T + 31) / 32));
+        while (nc > nc_min && (int64_t)(((T + nc - 1) / nc + 31) / 32 * 32) * (nc - 1) >= T) --nc;   // no empty last chunk
+        return nc;
+    }
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, int> cache;
+    const uint64_t key = ((uint64_t)(B * n_heads) << 33) | ((uint64_t)T << 1) | (causal ? 1u : 0u);
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    if (cache.size() > 4096) cache.clear();
+    return cache[key] = bwd_chunks_model(B * n_heads, T, causal);
+}
+
+extern "C" int vh_attn_rows_bwd_chunks(int B, int n_heads, int T, int mode) {
+    if (B <= 0 || n_heads <= 0 || T <= 0) return 0;
+    return bwd_chunks(B, n_heads, T, mode == VH_MASK_PREFIX);
+}
 
 extern "C" size_t vh_attn_rows_bwd_ws_bytes(int B, int n_heads, int T) {
     if (B <= 0 || n_heads <= 0 || T <= 0) return 0;
-    const int nc = bwd_chunks(T);
+    const int nc = max(bwd_chunks(B, n_heads, T, false), bwd_chunks(B, n_heads, T, true));   // either mask family fits
     const size_t slabs = nc > 1 ? (size_t)nc * B * n_heads * T * HD * sizeof(float) : 0;
     const size_t dsum = ((size_t)B * n_heads * T * sizeof(float) + 15) & ~(size_t)15;
     return slabs > dsum ? slabs : dsum;
@@ -1423,7 +1495,7 @@ extern "C" int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache,
                    vh_aligned16(dout) && vh_aligned16(dq) && vh_aligned16(dk) && vh_aligned16(dv),
                VH_EALIGN, "vh_attn_rows_bwd_ws: pointers must be 16-byte aligned");
     if (B == 0 || T == 0) return VH_OK;
-    const int nc = bwd_chunks(T);
+    const int nc = bwd_chunks(B, n_heads, T, mode == VH_MASK_PREFIX);
     const int chunk_keys = ((T + nc - 1) / nc + 31) / 32 * 32;       // equal chunks of whole 32-key wave blocks
     BwdArgs a{q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, nullptr, dq, dk, dv, ldg,
               n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nc, nc > 1 ? (float*)ws : nullptr, chunk_keys};
