@@ -213,6 +213,34 @@ def test_workspace_plans_of_the_gemm_entry_points():
     assert L.vh_gemm_tn_ws_bytes(16320, 512, 2048) == 4 * 512 * 2048 * 4
 
 
+def test_attention_backward_chunk_plan():
+    """The five-product attention backward cuts the keys of a (batch row, head) into chunks of 97..256 keys, one workgroup
+    each (vh_attn_rows_bwd_chunks: host logic, a simulated launch — DESIGN.md 3.5); the workspace holds one dQ slab per
+    chunk for either mask family."""
+    from valle2_amd import _lib
+    L = _lib.load_library()
+    FULL, PREFIX = 0, 1
+    for B, h, T in [(16, 8, 1020), (16, 8, 640), (2, 16, 2875), (8, 8, 1020), (32, 8, 640), (1, 2, 300), (2, 2, 70),
+                    (1, 1, 256), (1, 1, 257), (3, 5, 1), (64, 8, 1024), (4, 16, 5000)]:
+        ncs = []
+        for mode in (FULL, PREFIX):
+            nc = L.vh_attn_rows_bwd_chunks(B, h, T, mode)
+            ncs.append(nc)
+            keys = ((T + nc - 1) // nc + 31) // 32 * 32              # the launch's chunk size
+            assert -(-T // 256) <= nc <= max(-(-T // 256), -(-T // 128)), (B, h, T, mode, nc)
+            assert keys <= 256 and keys * (nc - 1) < T, 'every chunk fits a workgroup and owns at least one key'
+            assert L.vh_attn_rows_bwd_chunks(B, h, T, mode) == nc    # cached, deterministic
+        need = L.vh_attn_rows_bwd_ws_bytes(B, h, T)
+        slabs = max(ncs) * B * h * T * 64 * 4 if max(ncs) > 1 else 0
+        assert need >= slabs and need >= B * h * T * 4 and need % 16 == 0
+    # the shapes the rule was calibrated on (profiles/r4_sweep_attn_bwd_chunks.log)
+    assert L.vh_attn_rows_bwd_chunks(16, 8, 1020, PREFIX) == 4      # AR step of configs[3]
+    assert L.vh_attn_rows_bwd_chunks(16, 8, 640, FULL) == 5          # NAR step: 5 x 128 keys beat 3 x 224 and 4 x 160
+    assert L.vh_attn_rows_bwd_chunks(8, 8, 1020, PREFIX) == 8        # half the (b, head) pairs: twice the chunks
+    assert L.vh_attn_rows_bwd_chunks(2, 2, 70, PREFIX) == 1          # one chunk: dq written directly, no slab, no reduce
+    assert L.vh_attn_rows_bwd_ws_bytes(0, 8, 100) == 0
+
+
 def test_flat_adamw_refuses_cpu_parameters():
     from valle2_amd._lib import VhError
     from valle2_amd.optim import FlatAdamW

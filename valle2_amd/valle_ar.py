@@ -182,9 +182,10 @@ class ValleAR(_Base):
         the steps listed in keep_logits are left in `last_generate_stats['logits']`."""
         self._require_layernorm()
         cfg = self.config
-        if not cfg.use_kv_cache:
-            raise NotImplementedError('use_kv_cache=False is broken in the reference (D2); '
-                                      'the HIP path always uses its in-place cache')
+        no_cache = not cfg.use_kv_cache
+        if no_cache and (perf_mode or profile_attn or forced is not None):
+            raise ValueError('use_kv_cache=False recomputes every step from scratch: perf_mode / profile_attn / forced '
+                             'belong to the cached decoder')
         dev = self.device
         B = len(texts)
         if B == 0 or len(first_codes) != B:
@@ -282,11 +283,36 @@ class ValleAR(_Base):
                                          pl_max + t, dec.x.view(B, 1, d))
             # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
             done, stop = (max_new if forced is not None else 1), None
+            if no_cache:
+                # config.use_kv_cache = False (valle_ar.py:132,150-155 — the reference's branch raises, D2; build-defined
+                # here as what the flag says): every step embeds the WHOLE sequence again and runs the full stack over it
+                # under the prefix mask — no state is carried from step to step except the tokens — and samples from
+                # its last row with the same head / sample kernels.  O(S^2) per token; it exists so that the flag works
+                # and as an independent check of the cached decoder (same tokens, tests/test_models_gpu.py).
+                scratch = ForwardScratch(B * (s0 + max_new), d, cfg.dim_feedforward, dev)
+                rows_idx = torch.arange(B, device=dev)
+                while done < max_new:
+                    t = done
+                    xs = (torch.zeros if ragged else torch.empty)(B, s0 + t, d, device=dev, dtype=torch.float32)
+                    if not ragged:
+                        self._embed_rows(text_ids, codes[:, :pl_max + t], xs)
+                        transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch, **fwd)
+                        last = xs[:, -1]
+                    else:
+                        for b in range(B):
+                            self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :pls[b] + t], xs[b:b + 1])
+                        transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch,
+                                            x_len_dev=fwd['x_len_dev'], kv_len=lens + t)
+                        last = xs[rows_idx, lens.long() + t - 1]
+                    dec.sample_from(last.contiguous())
+                    done += 1
+                    if done % EOS_POLL == 0 and bool((dec.eos_count[:done] == B).any()):
+                        break
             attn_ms = attn_floor_ms = attn_kernel_ms = None
             if profile_attn and max_new > 1:
                 attn_ms, attn_floor_ms, attn_kernel_ms = dec.profile_attn(max_new - 1)
                 done = max_new
-            while done < max_new:
+            while done < max_new and not no_cache:
                 n = min(EOS_POLL, max_new - done)
                 dec.run(n)
                 done += n
