@@ -87,10 +87,7 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
                                        seven-product form of vh_attn_rows_bwd (its D scratch taken from the workspace) */
        VH_TUNE_ATTN_BWD_CHUNKS = 14, /* five-product attention backward: key chunks per (batch row, head); 0 (default) = chosen from the
                                        shape (bwd_chunks in csrc/attention.hip), else that many (at least ceil(T / 256)) */
-       VH_TUNE_TILE_PERSIST = 15,   /* large-M LDS-DMA GEMM with more than 512 whole tiles and no K-sliced tail: 0 (default) = one tile per
-                                       workgroup, 1 = the 512 resident workgroups walk the tiles and request the next tile's first
-                                       slab in the middle of the epilogue (measured in round 4) */
-       VH_TUNE_COUNT = 16 };
+       VH_TUNE_COUNT = 15 };
 int vh_set_tuning(int knob, int value);
 
 /* ---- dropout field of the training path -------------------------------------------------------------

@@ -229,14 +229,9 @@ __device__ __forceinline__ void tile_colsum(const GemmArgs& a, float* ct, f32x4 
 // (e&3)+8(e>>2)+4h, column r: 32 lanes write 32 consecutive floats (conflict-free).
 // DROP (EPI_PLAIN, act NONE / GELU_ERF / GELU_ERF_D): the dropout field of a.drop multiplies act(acc + bias) — and the
 // stored GELU derivative — before the residual is added.  A template parameter: the dropout-off kernels stay as they were.
-// DRAIN (the persistent kernel): every thread first pulls its 16 row groups out of ct into registers (the accumulators
-// are dead by then, so the register count does not grow), a barrier follows and `hook()` runs — the caller's chance to
-// start the NEXT tile's first operand slab into LDS buffer 0 while this tile's arithmetic and global stores are still
-// to come; the column-sum scratch then lives in buffer 1 (ct + 2 * TM * LDS_LD).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <int EPI, bool DROP = false, bool DRAIN = false, class Hook = NoHook>
+template <int EPI, bool DROP = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&acc)[2][2], float* ct, int m0, int n0,
-                                              int tid, const TileEpi& e, Hook hook = Hook{}) {
+                                              int tid, const TileEpi& e) {
     constexpr int LDC = TN + 4;                       // 132 floats: rows stay 16-byte aligned
     const int lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5, wm = w >> 1, wn = w & 1;
     float* cw = ct + (wm * 64 + 4 * h) * LDC + wn * 64 + r;
@@ -251,18 +246,6 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
     const int ec4 = tid & 31, erow = tid >> 5;
     const int en = n0 + 4 * ec4;
     const float* cr = ct + erow * LDC + 4 * ec4;
-    f32x4 drained[DRAIN ? 16 : 1];
-    if constexpr (DRAIN) {
-#pragma unroll
-        for (int it = 0; it < 16; ++it) drained[it] = ld4(cr + it * 8 * LDC);
-        __syncthreads();                               // ct is free: every thread holds its rows
-        hook();
-    }
-    auto ctrow = [&](int it) -> f32x4 {
-        if constexpr (DRAIN) return drained[it];
-        else return ld4(cr + it * 8 * LDC);
-    };
-    float* cs_scratch = DRAIN ? ct + 2 * TM * LDS_LD : ct;
     const bool interior = m0 + TM <= a.M && n0 + TN <= a.N;         // wave-uniform
     // QKV: a tile lies inside one of q / k / v when d_model is a multiple of the tile width
     const bool qkv_tile = EPI == EPI_QKV && a.d_model % TN == 0;
@@ -276,7 +259,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            f32x4 v = ctrow(it);
+            f32x4 v = ld4(cr + it * 8 * LDC);
             if (EPI == EPI_PLAIN) {
                 v += e.bias4;
                 f32x4 dm;
@@ -306,7 +289,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
             st4((float*)(base + (int64_t)it * 8 * a.ldo * 4 + voff), v);
             if (EPI == EPI_PLAIN) csum += v;
         }
-        if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, cs_scratch, csum, n0, tid);
+        if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, ct, csum, n0, tid);
         return;
     }
     if (interior && qkv_tile) {                        // a K or V tile: scatter rows into cache[b][head][pos][64]
@@ -318,7 +301,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
         int cl = a.cache_len ? a.cache_len[b] : 0;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
-            const f32x4 v = ctrow(it);
+            const f32x4 v = ld4(cr + it * 8 * LDC);
             st4(cache + ((int64_t)b * a.n_heads * a.S_max + cl + t) * VH_HEAD_DIM, v);
             t += 8;
             if (t >= a.T) {                           // next batch row (several at once only when T < 8)
@@ -348,7 +331,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
     for (int it = 0; it < 16; ++it) {
         const int row = erow + 8 * it, m = m0 + row;
         if (m >= a.M) break;
-        f32x4 v = ctrow(it);
+        f32x4 v = ld4(cr + it * 8 * LDC);
         if (EPI == EPI_PARTIAL) {                      // raw partial sums of K slice blockIdx.y -> slab [split][M][ldo]
             float* dst = a.out + ((int64_t)blockIdx.y * a.M + m) * a.ldo + en;
             if (ecol_full) st4(dst, v);
@@ -409,7 +392,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, const f32x16 (&
     // (the column-sum epilogue serves whole column groups only: the host refuses it for N % 4 != 0; every thread of a
     // tile that reaches this point — en < N is uniform per column group, not per wave — must take part in the barrier,
     // so edge tiles whose column groups end inside the tile are refused by the host as well: N % 128 == 0)
-    if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, cs_scratch, csum, n0, tid);
+    if (EPI == EPI_PLAIN && a.colsum) tile_colsum(a, ct, csum, n0, tid);
 }
 
 template <int EPI>
@@ -738,166 +721,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tile_dma_kernel(GemmArgs a, int t
 #ifdef VH_TILE_PROBE
     if ((tid & 63) == 0 && blockIdx.x < 8192) vh_tile_probe[(blockIdx.x * 4 + (tid >> 6)) * 200 + 197] = clock64();
 #endif
-}
-
-// =============================================================================================
-// Persistent form of the LDS-DMA tile kernel (round 4; VH_TUNE_TILE_PERSIST = 1, launches of more
-// than 512 whole tiles without a K-sliced tail).  The grid is the 512 resident workgroups; workgroup b walks the tiles
-// of the XCD-aware order at b, b + 512, ...  and — the part round 1's persistent loop did not have — requests the NEXT
-// tile's first operand slab in the middle of the epilogue: the epilogue drains its LDS transpose into registers first
-// (tile_epilogue<.., DRAIN>), so buffer 0 is free for the DMA while the tile's arithmetic and global stores run, and the
-// next tile's K loop starts on a slab that is already there.  Same K order, same epilogue arithmetic: bit-identical to
-// gemm_tile_dma_kernel (test).
-// =============================================================================================
-template <int EPI, bool DROP = false>
-__global__ __launch_bounds__(256, 2) void gemm_tile_dma_persist_kernel(GemmArgs a, int tiles_m, int tiles_n, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) float lds[2][2][TM * LDS_LD];
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
-    const int G = gridDim.x;                              // a multiple of 8: a workgroup's tiles stay on its XCD's run
-    const int q8 = n_tiles / 8, r8 = n_tiles % 8, xcd = blockIdx.x % 8;
-    const int run0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int ws = __builtin_amdgcn_readfirstlane(w);
-
-    int v = blockIdx.x;                                   // position in the XCD-aware order
-    int m0, n0;
-    const char *baseA, *baseW;
-    uint32_t voff[8];
-    auto locate = [&](int vv, int& mm, int& nn, const char*& bA, const char*& bW, uint32_t (&vo)[8]) {
-        const int tile = run0 + vv / 8;
-        mm = (tile / tiles_n) * TM;
-        nn = (tile % tiles_n) * TN;
-        bA = (const char*)(a.A + (int64_t)mm * a.lda);
-        bW = (const char*)(a.W + (int64_t)nn * a.K);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = ws * 8 + i, row = (q & 15) * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            vo[i] = q < 16 ? (uint32_t)(min(row, a.M - 1 - mm) * a.lda + 4 * c) * 4u
-                           : (uint32_t)(min(row, a.N - 1 - nn) * a.K + 4 * c) * 4u;
-        }
-    };
-    auto dma_raw = [&](int i, int buf, int k0, const char* bA, const char* bW, uint32_t vo) {
-        const int q = ws * 8 + i;
-        const char* base = (q < 16 ? bA : bW) + (int64_t)k0 * 4;
-        const uint32_t dst = (uint32_t)(uintptr_t)&lds[buf][q >> 4][(q & 15) * 8 * 32];
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(dst), "v"(vo), "s"(base) : "memory");
-    };
-    auto dma1 = [&](int i, int buf, int k0) { dma_raw(i, buf, k0, baseA, baseW, voff[i]); };
-
-    locate(v, m0, n0, baseA, baseW, voff);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
-
-    const int nk = a.k_len / TK;
-    const int swz = (r >> 1) & 7;
-    f32x4 fa[2][2], fw[2][2];
-    const float* fA[4];
-    const float* fW[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        fA[t] = &lds[0][0][(wm * 64 + r) * 32 + (((2 * t + h) ^ swz) << 2)];
-        fW[t] = &lds[0][1][(wn * 64 + r) * 32 + (((2 * t + h) ^ swz) << 2)];
-    }
-    f32x16 acc[2][2];
-    auto fload = [&](int set, int buf, int t) {
-        fa[set][0] = ld4(fA[t] + buf * 2 * TM * LDS_LD);
-        fa[set][1] = ld4(fA[t] + buf * 2 * TM * LDS_LD + 32 * 32);
-        fw[set][0] = ld4(fW[t] + buf * 2 * TM * LDS_LD);
-        fw[set][1] = ld4(fW[t] + buf * 2 * TM * LDS_LD + 32 * 32);
-    };
-    auto mfma4 = [&](int set, int j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][j], fw[set][0][j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][j], fw[set][1][j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][0][j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][1][j], fw[set][1][j], acc[1][1], 0, 0, 0);
-    };
-    auto kstep = [&](int kt, auto cur_c, auto pf) {       // as in gemm_tile_dma_kernel
-        constexpr bool PF = decltype(pf)::value;
-        constexpr int cur = decltype(cur_c)::value;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            mfma4(t & 1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF) {
-                if (t < 2) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, (kt + 1) * TK);
-                }
-            }
-            if (t < 3) {
-                fload((t + 1) & 1, cur, t + 1);
-            } else if constexpr (PF) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                __syncthreads();
-                fload(0, cur ^ 1, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            mfma4(t & 1, 1);
-            mfma4(t & 1, 2);
-            mfma4(t & 1, 3);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-        TileEpi epi;
-        tile_prefetch<EPI>(a, m0, n0, tid, epi);
-        // loads return in issue order: the slab (requested before the previous tile's stores and these operand loads) is in
-        // LDS once all but the youngest EPI_EARLY (+1) loads have returned — the stores in between only tighten the count
-        const bool res_early = EPI == EPI_PLAIN && a.res && m0 + TM <= a.M && n0 + TN <= a.N;
-        if (res_early && a.bias)
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (EPI_EARLY + 1));
-        else if (res_early)
-            __builtin_amdgcn_s_waitcnt(0x0F70 | EPI_EARLY);
-        else
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(0);
-        fload(0, 0, 0);
-        int kt = 0;
-        for (; kt + 2 < nk; kt += 2) {
-            kstep(kt, B0{}, std::true_type{});
-            kstep(kt + 1, B1{}, std::true_type{});
-        }
-        if (kt + 2 == nk) {
-            kstep(kt, B0{}, std::true_type{});
-            kstep(kt + 1, B1{}, std::false_type{});
-        } else {
-            kstep(kt, B0{}, std::false_type{});
-        }
-        tile_prefetch_late<EPI>(a, m0, n0, tid, epi);
-        __syncthreads();
-        __builtin_amdgcn_s_setprio(3);
-        const int vn = v + G;
-        const bool more = vn < n_tiles;                   // workgroup-uniform
-        int m0n = 0, n0n = 0;
-        const char *bAn = nullptr, *bWn = nullptr;
-        uint32_t voffn[8];
-        auto hook = [&]() {                               // ct is drained: the next tile's slab 0 goes into buffer 0 now
-            if (more) {
-                locate(vn, m0n, n0n, bAn, bWn, voffn);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) dma_raw(i, 0, 0, bAn, bWn, voffn[i]);
-            }
-        };
-        tile_epilogue<EPI, DROP, true>(a, acc, &lds[0][0][0], m0, n0, tid, epi, hook);
-        if (!more) break;
-        v = vn; m0 = m0n; n0 = n0n; baseA = bAn; baseW = bWn;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) voff[i] = voffn[i];
-    }
 }
 
 // =============================================================================================
@@ -1545,17 +1368,6 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
                     ts = TailSplit{n_whole, split, a.K / split, tail_ws};
             }
             const int tail = tm * tn - ts.n_whole;
-            if constexpr (EPI != EPI_PARTIAL) {
-                if (vh_tuning(VH_TUNE_TILE_PERSIST) == 1 && tail == 0 && tm * tn > 512) {
-                    if (EPI == EPI_PLAIN && a.drop.thresh)
-                        hipLaunchKernelGGL((gemm_tile_dma_persist_kernel<EPI, EPI == EPI_PLAIN>), dim3(512), dim3(256), 0, s, a, tm,
-                                           tn, tm * tn);
-                    else
-                        hipLaunchKernelGGL((gemm_tile_dma_persist_kernel<EPI>), dim3(512), dim3(256), 0, s, a, tm, tn, tm * tn);
-                    VH_CHECK_LAUNCH(name);
-                    return VH_OK;
-                }
-            }
             if (EPI == EPI_PLAIN && a.drop.thresh)
                 hipLaunchKernelGGL((gemm_tile_dma_kernel<EPI, EPI == EPI_PLAIN>), dim3(ts.n_whole + tail * ts.split), dim3(256), 0,
                                    s, a, tm, tn, ts);
