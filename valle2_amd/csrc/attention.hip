@@ -1119,15 +1119,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
 // training shape — and attn_dq_reduce_kernel adds the slabs in chunk order: bitwise reproducible, no atomics.
 // D = rowsum(dO∘O) is computed while the dO / O rows are staged (the dq kernel used to do it).
 // =============================================================================================
-#define FW 8            // waves per workgroup
-#define FKMAX 256       // keys per workgroup at most (FW x 32)
+#define FKMAX 256       // keys per workgroup at most (8 waves x 32)
 
-__global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
-    // [buf][Q|dO][query][KLD] | [buf][lse|D][32] | Kt [64 d][256 keys] | dS [32 q][256 keys]
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * KT * KLD + 2 * 2 * KT + HD * FKMAX + KT * FKMAX];
-    float* const stat = lds + 2 * 2 * KT * KLD;
-    float* const kt = stat + 2 * 2 * KT;
-    float* const dsb = kt + HD * FKMAX;
+// FW waves per workgroup = FW x 32 keys per chunk at most.  FW = 8: one workgroup per CU (113 KB of LDS); FW = 4: two per
+// CU (65 KB each) — the same eight waves per CU in half-size work items.  The Q / dO tile is single-buffered: every read
+// of tile i happens before the tile's first barrier and the staged rows of tile i + 1 are stored after it, so the two
+// barriers the dS hand-over needs anyway also order the tile buffer.
+template <int FW>
+__global__ __launch_bounds__(FW * 64, FW == 8 ? 1 : 2) void attn_bwd_fused_kernel(BwdArgs a) {
+    constexpr int KEYS = FW * 32;                    // row length of Kt and dS
+    constexpr int RPT = 8 / FW;                      // staged tile rows per thread (32 rows x 16 threads over FW x 64 threads)
+    constexpr int QB_W = 8 / FW;                     // 16-query blocks of the dQ tile per wave (FW = 4: both, one d-block per wave)
+    // [Q|dO][query][KLD] | [lse|D][32] | Kt [64 d][KEYS] | dS [32 q][KEYS]
+    __shared__ __attribute__((aligned(16))) float lds[2 * KT * KLD + 2 * KT + HD * KEYS + KT * KEYS];
+    float* const stat = lds + 2 * KT * KLD;
+    float* const kt = stat + 2 * KT;
+    float* const dsb = kt + HD * KEYS;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n_bh = gridDim.x / a.n_blocks;
@@ -1137,11 +1144,11 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
     const int kend = min(kb0 + a.chunk_keys, a.T);              // keys [kb0, kend) belong to this workgroup
     const int kvl = a.kv_len ? min(a.kv_len[b], a.T) : a.T;
     const int xl = a.x_len_dev ? a.x_len_dev[b] : a.x_len;
-    const int sq = tid >> 4, squad = (tid & 15) * 4;            // staging: one row chunk per thread per operand
+    const int sq = tid >> 4, squad = (tid & 15) * 4;            // staging: row sq (+ 16 with four waves), one 16-byte chunk
 
     if (a.mode != VH_MASK_EXPLICIT && kb0 >= kvl) {
         // every key of the chunk is padding: dK = dV = 0, no dQ contribution (the reduce kernel skips this chunk too)
-        for (int row = kb0 + sq; row < kend; row += 32) {
+        for (int row = kb0 + sq; row < kend; row += FW * 4) {
             const int64_t o = ((int64_t)b * a.T + row) * a.ldg + head * HD + squad;
             st4(a.dk + o, f32x4{0.f, 0.f, 0.f, 0.f});
             st4(a.dv + o, f32x4{0.f, 0.f, 0.f, 0.f});
@@ -1169,12 +1176,12 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {        // Kt[d][key], 16-byte slot (key >> 2) XOR-swizzled by d & 15
                 const int d = 8 * t + 4 * h + j;
-                kt[d * FKMAX + ((((kl >> 2) ^ (d & 15)) << 2) | (kl & 3))] = kf[t][j];
+                kt[d * KEYS + ((((kl >> 2) ^ (d & 15)) << 2) | (kl & 3))] = kf[t][j];
             }
             kf[t] = kf[t] * qscale;
         }
     }
-    f32x4 rq, rd, ro;
+    f32x4 rq[RPT], rd[RPT], ro[RPT];
     float rlse = 0.f;
     const float* qbase = a.q + (int64_t)b * a.T * a.ldq + head * HD;
     const float* dbase = a.dout + (int64_t)b * a.T * a.lddo + head * HD;
@@ -1182,40 +1189,52 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
     // loads only: nothing here may wait for them.  Q and dO rows are requested at the top of a tile and land under its
     // MFMAs; the O row (needed only for D) and lse are requested after the tile's first barrier, when the S / dP
     // registers are dead (the kernel sits at the register limit), and land under the dQ product.
+    // (four waves stage two rows per thread: the second row's Q / dO are requested late as well — eight registers less
+    // across the S / dP / dV / dK phase, where the count peaks)
     auto gload = [&](int q0t) {
         const int qrow = min(q0t + sq, a.T - 1);
-        rq = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
-        rd = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
+        rq[0] = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
+        rd[0] = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
     };
     auto gload_late = [&](int q0t) {
-        const int qrow = min(q0t + sq, a.T - 1);
-        ro = ld4((const float*)((const char*)obase + (uint32_t)(qrow * a.ldo + squad) * 4u));
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int qrow = min(q0t + sq + 16 * i, a.T - 1);
+            if (i > 0) {
+                rq[i] = ld4((const float*)((const char*)qbase + (uint32_t)(qrow * a.ldq + squad) * 4u));
+                rd[i] = ld4((const float*)((const char*)dbase + (uint32_t)(qrow * a.lddo + squad) * 4u));
+            }
+            ro[i] = ld4((const float*)((const char*)obase + (uint32_t)(qrow * a.ldo + squad) * 4u));
+        }
         if (tid < KT) rlse = a.lse2[(int64_t)bh * a.T + min(q0t + tid, a.T - 1)];
     };
-    auto lstore = [&](int buf) {
-        float* qd = lds + buf * (2 * KT * KLD);
-        st4(qd + sq * KLD + squad, rq);
-        st4(qd + KT * KLD + sq * KLD + squad, rd);
-        const float dsum = row16_sum((rd.x * ro.x + rd.y * ro.y) + (rd.z * ro.z + rd.w * ro.w));   // D of the staged row
-        if (tid < KT) stat[buf * 2 * KT + tid] = rlse;
-        if ((tid & 15) == 0) stat[buf * 2 * KT + KT + sq] = dsum;
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            st4(lds + (sq + 16 * i) * KLD + squad, rq[i]);
+            st4(lds + KT * KLD + (sq + 16 * i) * KLD + squad, rd[i]);
+            const float dsum = row16_sum((rd[i].x * ro[i].x + rd[i].y * ro[i].y) + (rd[i].z * ro[i].z + rd[i].w * ro[i].w));
+            if ((tid & 15) == 0) stat[KT + sq + 16 * i] = dsum;                  // D of the staged row
+        }
+        if (tid < KT) stat[tid] = rlse;
     };
     f32x16 GK0, GK1, GV0, GV1;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { GK0[e] = 0.f; GK1[e] = 0.f; GV0[e] = 0.f; GV1[e] = 0.f; }
-    // the dQ block of this wave: d0 = 16 (w & 3), q0 = 16 (w >> 2); lane (i, g) reads row i of both operands
+    // the dQ block(s) of this wave: d0 = 16 (w & 3); q0 = 16 (w >> 2) with eight waves, both q-blocks with four;
+    // lane (i, g) reads row i of both operands
     const int mi = lane & 15, mg = lane >> 4;
-    const float* ap = kt + (16 * (w & 3) + mi) * FKMAX;
-    const float* bp = dsb + (16 * (w >> 2) + mi) * FKMAX;
+    const float* ap = kt + (16 * (w & 3) + mi) * KEYS;
+    const float* bp = dsb + (FW == 8 ? 16 * (w >> 2) + mi : mi) * KEYS;
     const int n_waves_keys = (kend - kb0 + 31) >> 5;            // waves that own at least one key of the chunk
     if (t_first < n_tiles) {
         gload(t_first * KT);
         gload_late(t_first * KT);
-        lstore(0);
+        lstore();
     }
     __syncthreads();
     for (int qt = t_first; qt < n_tiles; ++qt) {
-        const int cur = (qt - t_first) & 1, q0t = qt * KT;
+        const int q0t = qt * KT;
         if (qt + 1 < n_tiles) gload(q0t + KT);
         // waves of this workgroup that see a query of the tile: a prefix of the waves (every term falls with the key index)
         int n_act = n_waves_keys;
@@ -1228,9 +1247,9 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
             }
         }
         const bool any = w < n_act;
-        const float* qs = lds + cur * (2 * KT * KLD);
+        const float* qs = lds;
         const float* ds = qs + KT * KLD;
-        const float* st = stat + cur * 2 * KT;
+        const float* st = stat;
         if (any) {
             f32x16 S, P;
 #pragma unroll
@@ -1281,7 +1300,7 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int qrow = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    dsb[qrow * FKMAX + ((((kl >> 2) ^ (qrow & 15)) << 2) | (kl & 3))] = P[e];
+                    dsb[qrow * KEYS + ((((kl >> 2) ^ (qrow & 15)) << 2) | (kl & 3))] = P[e];
                 }
             }
 #pragma unroll
@@ -1295,38 +1314,52 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
                 GK1 = __builtin_amdgcn_mfma_f32_32x32x2f32(qrowp[32], P[e], GK1, 0, 0, 0);
             }
         }
-        __syncthreads();                     // the dS blocks of the n_act active waves are in LDS
+        __syncthreads();                     // the dS blocks of the n_act active waves are in LDS; the Q / dO tile is free
         if (qt + 1 < n_tiles) gload_late(q0t + KT);
         {
             // dQ[q][d] block = Σ_key dS[q][key]·K[key][d] over the active waves' keys: A = Kᵀ rows (d), B = dS rows (q)
-            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0, c2 = c0, c3 = c0;
+            f32x4 c[QB_W][4];
+#pragma unroll
+            for (int qb = 0; qb < QB_W; ++qb)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[qb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             const int nu = 2 * n_act;                    // 16-key groups of the active waves (n_act >= 1 on every visited tile)
-            f32x4 a4 = ld4(ap + ((mg ^ mi) << 2)), b4 = ld4(bp + ((mg ^ mi) << 2));
+            f32x4 a4 = ld4(ap + ((mg ^ mi) << 2)), b4[QB_W];
+#pragma unroll
+            for (int qb = 0; qb < QB_W; ++qb) b4[qb] = ld4(bp + qb * 16 * KEYS + ((mg ^ mi) << 2));
             for (int u = 0; u < nu; ++u) {               // operands of group u + 1 requested BEFORE group u's MFMAs
                 const int slot = ((4 * min(u + 1, nu - 1) + mg) ^ mi) << 2;
-                const f32x4 an = ld4(ap + slot), bn = ld4(bp + slot);
+                const f32x4 an = ld4(ap + slot);
+                f32x4 bn[QB_W];
+#pragma unroll
+                for (int qb = 0; qb < QB_W; ++qb) bn[qb] = ld4(bp + qb * 16 * KEYS + slot);
                 __builtin_amdgcn_sched_barrier(0);       // (left alone the compiler sinks the reads below the MFMAs)
-                c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[0], b4[0], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[1], b4[1], c1, 0, 0, 0);
-                c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[2], b4[2], c2, 0, 0, 0);
-                c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[3], b4[3], c3, 0, 0, 0);
+#pragma unroll
+                for (int qb = 0; qb < QB_W; ++qb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        c[qb][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b4[qb][j], c[qb][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 a4 = an;
-                b4 = bn;
+#pragma unroll
+                for (int qb = 0; qb < QB_W; ++qb) b4[qb] = bn[qb];
             }
-            f32x4 c = (c0 + c1) + (c2 + c3);             // lane (q = mi, d = 4 mg + e)
-            const int qi = q0t + 16 * (w >> 2) + mi;
             const uint32_t dcol = 16 * (w & 3) + 4 * mg;
-            if (qi < a.T) {                              // wave-uniform 64-bit base + one 32-bit lane offset
-                if (a.slab) st4((float*)((char*)(a.slab + ((int64_t)chunk * n_bh + bh) * a.T * HD) + (uint32_t)(qi * HD + dcol) * 4u), c);
-                else st4((float*)((char*)(a.dq + (int64_t)b * a.T * a.ldg + head * HD) + (uint32_t)(qi * a.ldg + dcol) * 4u), c * 0.125f);
+#pragma unroll
+            for (int qb = 0; qb < QB_W; ++qb) {
+                const f32x4 cc = (c[qb][0] + c[qb][1]) + (c[qb][2] + c[qb][3]);   // lane (q = mi, d = 4 mg + e)
+                const int qi = q0t + (FW == 8 ? 16 * (w >> 2) : 16 * qb) + mi;
+                if (qi < a.T) {                          // wave-uniform 64-bit base + one 32-bit lane offset
+                    if (a.slab) st4((float*)((char*)(a.slab + ((int64_t)chunk * n_bh + bh) * a.T * HD) + (uint32_t)(qi * HD + dcol) * 4u), cc);
+                    else st4((float*)((char*)(a.dq + (int64_t)b * a.T * a.ldg + head * HD) + (uint32_t)(qi * a.ldg + dcol) * 4u), cc * 0.125f);
+                }
             }
         }
-        if (qt + 1 < n_tiles) lstore(cur ^ 1);
+        if (qt + 1 < n_tiles) lstore();
         __syncthreads();                     // next tile staged; every wave is done with this tile's dS
     }
     // ---- dK, dV: transposed through LDS (everything above is dead), whole rows out
-    float* ob = lds;                         // [256][KLD]
+    float* ob = lds;                         // [KEYS][KLD]
     for (int which = 0; which < 2; ++which) {
         const f32x16& A0 = which ? GV0 : GK0;
         const f32x16& A1 = which ? GV1 : GK1;
@@ -1341,8 +1374,8 @@ __global__ __launch_bounds__(FW * 64, 1) void attn_bwd_fused_kernel(BwdArgs a) {
         __syncthreads();
         float* dst = which ? a.dv : a.dk;
 #pragma unroll
-        for (int i = 0; i < FW; ++i) {
-            const int row = sq + 32 * i;
+        for (int i = 0; i < 8; ++i) {
+            const int row = sq + FW * 4 * i;
             if (kb0 + row < kend)
                 st4(dst + ((int64_t)b * a.T + kb0 + row) * a.ldg + head * HD + squad, ld4(ob + row * KLD + squad));
         }
@@ -1420,7 +1453,7 @@ static int bwd_chunks_model(int bh, int T, bool causal) {
     for (int nc = nc_min; nc <= nc_max; ++nc) {
         const int keys = ((T + nc - 1) / nc + 31) / 32 * 32;
         if ((int64_t)keys * (nc - 1) >= T) continue;                     // the last chunk would be empty
-        const double unit = keys > 128 ? 1.0 : 0.6;
+        const double unit = keys > 128 ? 1.0 : (causal ? 0.6 : 0.55);   // <= 128 keys: four active waves (full / explicit masks: the 4-wave kernel, two per CU)
         std::priority_queue<double, std::vector<double>, std::greater<double>> cu;
         for (int i = 0; i < 256; ++i) cu.push(0.0);
         double end = 0.0;
@@ -1499,7 +1532,13 @@ extern "C" int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache,
     const int chunk_keys = ((T + nc - 1) / nc + 31) / 32 * 32;       // equal chunks of whole 32-key wave blocks
     BwdArgs a{q, ldq, kcache, vcache, out, ldo, dout, lddo, lse2, nullptr, dq, dk, dv, ldg,
               n_heads, T, S_max, mode, x_len, x_len_dev, kv_len, mask, pad, nc, nc > 1 ? (float*)ws : nullptr, chunk_keys};
-    hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(nc * B * n_heads), dim3(FW * 64), 0, (hipStream_t)stream, a);
+    // chunks of <= 128 keys under a uniform mask: the four-wave kernel, two workgroups per CU (NAR step 391 -> 375 us per
+    // layer).  Not under the prefix mask: both slots of every CU are filled at once in index order, which pairs the heavy
+    // low chunks with each other's neighbours instead of with the light high ones (B = 8: 269 -> 305 us).
+    if (chunk_keys <= 128 && mode != VH_MASK_PREFIX)
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<4>, dim3(nc * B * n_heads), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(attn_bwd_fused_kernel<8>, dim3(nc * B * n_heads), dim3(512), 0, (hipStream_t)stream, a);
     if (nc > 1) {
         const int64_t n4 = (int64_t)B * T * n_heads * 16;
         hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, n4);
