@@ -173,3 +173,44 @@ def test_config5_joint_ar_then_nar_pipeline():
         margin = (top2.values[..., 0] - top2.values[..., 1])[off]
         assert off.float().mean().item() < 1e-3 and (margin.numel() == 0 or float(margin.max()) < 1e-3), \
             (stage, int(off.sum()), float(margin.max()) if margin.numel() else 0.0)
+
+
+def test_maximum_length_of_the_positional_table():
+    """The longest sequence the path can represent: the sinusoid tables hold 5000 positions per stream
+    (valle/models/modules.py:56-66, max_len 5000).  A tiny AR model over 30 text + 5000 audio positions (BOS + 4999
+    frames; row 1 shorter, so key padding is live): teacher-forced loss and every gradient against the oracle's autograd —
+    157 query tiles, 20 key chunks through the attention backward — and one position more is refused, not read past
+    the table."""
+    from oracle import valle_oracle as O
+    from tests.test_train_gpu import _grad_check
+    from valle2_amd import _lib, get_model_class, synth
+    kw = dict(C.TINY, norm='LayerNorm')
+    cfg = C.cfg_of(kw)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=11, rich=True)
+    batch = synth.synth_ar_batch(cfg, 2, tok_range=(30, 30), code_range=(4999, 4999), seed=5)
+    cut = 3777                                                # row 1: 3777 real frames, then padding (zeros, as collate pads)
+    batch['codes'][1, cut + 1:] = 0
+    batch['target'][1, cut:] = 0
+    batch['target'][1, cut] = cfg.eos_token
+    batch['codes_lens'][1] = cut + 1
+    assert batch['codes'].shape[1] == 5000
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    ref = O.ar_training_loss(params, cfg, batch)
+    ref.backward()
+    model = get_model_class('ValleAR')(cfg)
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    assert _lib.lib().vh_attn_rows_bwd_chunks(2, cfg.n_heads, 5030, 1) >= 20
+    loss = model.training_step({k: v.clone() for k, v in batch.items()})
+    torch.testing.assert_close(loss.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    _grad_check(model, params, sorted(k for k in params if not k.endswith('.pe')))
+    # one more audio position than the table holds
+    longer = synth.synth_ar_batch(cfg, 1, tok_range=(30, 30), code_range=(5000, 5000), seed=6)
+    with pytest.raises((_lib.VhError, IndexError)):
+        model.training_step(longer)
+    utt = synth.synth_utterance(cfg, 4, 4, 4990, seed=3)
+    gen = get_model_class('ValleAR')(C.cfg_of(dict(kw, num_beams=2, top_k=1, max_audio_len=64)))
+    gen.load_state_dict(sd)
+    with pytest.raises(_lib.VhError):
+        gen.to(DEV).eval().generate(*[u.to(DEV) for u in utt])
