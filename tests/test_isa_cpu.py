@@ -14,3 +14,10 @@ def test_tile_dma_kernel_isa_properties():
     import check_isa
     problems = check_isa.check(check_isa.compile_asm())
     assert not problems, '\n'.join(problems)
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc'), reason='hipcc not installed')
+def test_attention_backward_isa_properties():
+    import check_isa
+    problems = check_isa.check_attention(check_isa.compile_attention_asm())
+    assert not problems, '\n'.join(problems)

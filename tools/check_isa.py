@@ -1,4 +1,4 @@
-"""Static checks on the compiled gfx950 code of the LDS-DMA tile GEMMs (forward NT kernel and the TN weight-gradient kernel) (no GPU needed; hipcc cross-compiles).
+"""Static checks on the compiled gfx950 code of the LDS-DMA tile GEMMs (forward NT kernel and the TN weight-gradient kernel) and of the five-product attention backward (no GPU needed; hipcc cross-compiles).
 
 The kernel issues its DMA from inline assembly that writes M0, a reserved register the compiler does not track
 through a clobber list, and relies on its main loop holding no vector ALU instruction besides the MFMAs.  Both are
@@ -69,8 +69,53 @@ def check(asm):
     return problems
 
 
+def compile_attention_asm():
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / 'attention.s'
+        subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+                        '-mllvm', '-amdgpu-kernarg-preload-count=16',
+                        f'-I{REPO / "include"}', str(REPO / 'valle2_amd/csrc/attention.hip'), '-o', str(out)],
+                       check=True, capture_output=True)
+        return out.read_text()
+
+
+def check_attention(asm):
+    """The five-product attention backward (csrc/attention.hip, attn_bwd_fused_kernel<8>) sits at the register limit of
+    two waves per SIMD and depends on a hand-pinned schedule of its dQ loop:
+      * no scratch access anywhere in the eight-wave kernel (a spill there is a memory round trip inside every tile);
+      * the dQ loop (the inner loop with the 16x16x4 MFMAs) requests the NEXT key group's two operands before the
+        current group's MFMAs and never drains the LDS queue (`s_waitcnt lgkmcnt(0)`) inside the loop."""
+    problems = []
+    m = re.search(r'^_Z21attn_bwd_fused_kernelILi8EEv7BwdArgs:[^\n]*\n(.*?)^\.Lfunc_end', asm, re.S | re.M)   # (the kernel has an early s_endpgm)
+    if not m:
+        return ['attn_bwd_fused_kernel<8> not found']
+    lines = [l.strip() for l in m.group(1).splitlines()]
+    if any(l.startswith('scratch_') for l in lines):
+        problems.append('attn_bwd_fused_kernel<8>: scratch access (register spill)')
+    heads = [i for i, l in enumerate(lines) if 'Loop Header' in l]
+    loop = None
+    for hi in heads:
+        # (a nested loop's header comment sits on the line after its label)
+        label = (lines[hi] if not lines[hi].startswith(';') else lines[hi - 1]).split(':')[0]
+        ends = [i for i in range(hi, len(lines)) if lines[i].startswith('s_cbranch') and lines[i].endswith(label)]
+        if ends and any(x.startswith('v_mfma_f32_16x16x4') for x in lines[hi:ends[-1]]) and \
+                not any(x.startswith('v_mfma_f32_32x32x2') for x in lines[hi:ends[-1]]):
+            loop = [x for x in lines[hi:ends[-1] + 1] if x and not x.startswith(';') and not x.endswith(':')]
+    if loop is None:
+        return problems + ['attn_bwd_fused_kernel<8>: dQ loop not found']
+    ops = [x.split()[0] for x in loop]
+    first_read = next((i for i, o in enumerate(ops) if o == 'ds_read_b128'), None)
+    first_mfma = next((i for i, o in enumerate(ops) if o.startswith('v_mfma')), None)
+    if first_read is None or first_mfma is None or first_read > first_mfma:
+        problems.append('attn_bwd_fused_kernel<8>: the dQ loop does not request its next operands before its MFMAs')
+    for x in loop:
+        if x.startswith('s_waitcnt') and 'lgkmcnt(0)' in x:
+            problems.append(f'attn_bwd_fused_kernel<8>: the dQ loop drains the LDS queue: {x}')
+    return problems
+
+
 if __name__ == '__main__':
-    probs = check(compile_asm())
+    probs = check(compile_asm()) + check_attention(compile_attention_asm())
     for p in probs:
         print('ISA check:', p)
     print('ISA check:', 'FAILED' if probs else 'ok')
