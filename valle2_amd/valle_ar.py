@@ -259,10 +259,10 @@ class ValleAR(_Base):
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
         if perf_mode:
             cache = cache.narrowed(s_max)                 # fp32 prompt K/V -> the bf16 cache of the decode steps
-        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph,
+        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph and not no_cache,
                         seed=seed)
         try:
-            dec.capture()
+            dec.capture()                                 # (a no-op without a graph: the no-cache path only borrows the sampler)
             dec.sample_from(last.contiguous())
             marks[1].record()
             del x, last
