@@ -402,9 +402,11 @@ def test_module_level_errors_are_loud():
     from valle2_amd import _lib
     from valle2_amd.modules import FeedForward, MultiHeadAttention
     with pytest.raises(_lib.VhError):
-        MultiHeadAttention(128, 4).to(DEV)(torch.randn(1, 3, 128, device=DEV))   # head_dim 32
+        MultiHeadAttention(10, 5).to(DEV)(torch.randn(1, 3, 10, device=DEV))     # head_dim 2: not a multiple of 4
     with pytest.raises(_lib.VhError):
-        MultiHeadAttention(128, 4)(torch.randn(1, 3, 128))                       # same, through the mirror
+        MultiHeadAttention(10, 5)(torch.randn(1, 3, 10))                         # same, through the mirror
+    y, _ = MultiHeadAttention(128, 4)(torch.randn(1, 3, 128))                    # head_dim 32: the general kernels (test_head_dim_gpu.py)
+    assert not y.is_cuda and y.shape == (1, 3, 128)
     y = FeedForward(128, 512).to(DEV)(torch.randn(1, 3, 128))                    # CPU input, device module
     assert not y.is_cuda and y.shape == (1, 3, 128)
 

@@ -251,6 +251,53 @@ class QkvAttentionFn(torch.autograd.Function):
         return dx, dw, None, None, None, None
 
 
+class QkvAttentionAnyHeadDimFn(torch.autograd.Function):
+    """QkvAttentionFn for a head width other than 64 (modules.py:109-111 allows any divisor of d_model): the whole node
+    on the general kernels with the probabilities materialised — qkv = x Wqkv^T, P = softmax(Q K^T / sqrt(hd) + mask),
+    out = P V forward; dV = P^T dO, dP = dO V^T, dS, dQ = dS K, dK = dS^T Q backward — every operand a strided view of
+    the (rows, 3 d) projection or its gradient, read and written in place.  Correct, not tuned (P is kept: O(T^2) memory
+    per (batch row, head))."""
+
+    @staticmethod
+    def forward(ctx, x, wqkv, B, T, n_heads, spec):
+        x = x.contiguous()
+        d = x.shape[1]
+        hd = d // n_heads
+        if hd % 4:
+            raise _lib.VhError(f'head_dim {hd}: the general attention path needs a multiple of 4')
+        qkv = kernels.linear(x, wqkv.detach(), out=torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32))
+        q, k, v = (qkv.view(B, T, 3, n_heads, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        out = torch.empty(B * T, d, device=x.device, dtype=torch.float32)
+        P = kernels.attn_generic(q, k, v, out.view(B, T, n_heads, hd).permute(0, 2, 1, 3), hd ** -0.5, **spec)
+        ctx.save_for_backward(x, wqkv, qkv, P)
+        ctx.dims = (B, T, n_heads, hd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wqkv, qkv, P = ctx.saved_tensors
+        B, T, h, hd = ctx.dims
+        d = h * hd
+        q, k, v = (qkv.view(B, T, 3, h, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        do = dout.contiguous().view(B, T, h, hd).permute(0, 2, 1, 3)
+        dqkv = torch.empty(B * T, 3 * d, device=x.device, dtype=torch.float32)
+        dq, dk, dv = (dqkv.view(B, T, 3, h, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        tp = P.stride(2)
+        dP = torch.empty(B, h, T, tp, device=x.device, dtype=torch.float32)[..., :T]
+        _mm(P, do, dv, a_kmajor=True, b_kmajor=True)                      # dV = P^T dO
+        _mm(do, v, dP)                                                    # dP = dO V^T
+        check(_lib.lib().vh_softmax_bwd(P.data_ptr(), dP.data_ptr(), tp, B * h * T, T, hd ** -0.5, stream()), 'vh_softmax_bwd')
+        _mm(dP, k, dq, b_kmajor=True)                                     # dQ = dS K
+        _mm(dP, q, dk, a_kmajor=True, b_kmajor=True)                      # dK = dS^T Q
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = _dx(dqkv, wqkv, 3 * d)
+        if ctx.needs_input_grad[1]:
+            dw = optim.grad_out(wqkv)
+            kernels.gemm_tn(dqkv, x, out=dw)
+        return dx, dw, None, None, None, None
+
+
 def _drop_ref(sp):
     return None if sp is None else C.byref(sp)
 
@@ -559,7 +606,8 @@ def encoder_layer_train(layer, x, B, T, spec, embedding=None):
         wb = linear(embedding.reshape(1, -1), n.project_layer.weight, n.project_layer.bias).view(2, -1)
         return layer_norm(inp, n.norm.weight, n.norm.bias, wb[0], wb[1], eps=n.eps)
 
-    a = QkvAttentionFn.apply(norm(layer.norm1, x), at.qkv.weight, B, T, at.n_heads, spec)
+    attention = QkvAttentionFn if at.head_dim == HEAD_DIM else QkvAttentionAnyHeadDimFn
+    a = attention.apply(norm(layer.norm1, x), at.qkv.weight, B, T, at.n_heads, spec)
     d1, d2 = layer.dropout1, layer.dropout2
     if d1.training and d1.p > 0:
         x = x + dropout.apply(d1, linear(a, at.out.weight, at.out.bias))
@@ -604,7 +652,8 @@ def _stack_transposes(transformer):
 def transformer_train(transformer, x, B, T, spec, embedding=None):
     layers = list(transformer.layers)
     cfg = transformer.hparams
-    fused = ATTENTION_BACKWARD == 'flash' and cfg.dim_feedforward % 32 == 0 and cfg.d_model % 32 == 0
+    fused = (ATTENTION_BACKWARD == 'flash' and cfg.dim_feedforward % 32 == 0 and cfg.d_model % 32 == 0 and
+             cfg.d_model == cfg.n_heads * HEAD_DIM)      # (another head width: node by node on the general kernels)
     if not fused:
         for layer in layers:
             x = encoder_layer_train(layer, x, B, T, spec, embedding)

@@ -185,7 +185,10 @@ def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_
         raise _lib.VhError('x must be contiguous')
     if x_in is not None and (tuple(x_in.shape) != tuple(x.shape) or x_in.dtype != torch.float32):
         raise _lib.VhError('x_in must match x')
-    if cache.batch != B or cache.s_max < T or cache.n_layers != cfg.num_layers:
+    if d != cfg.n_heads * HEAD_DIM:                          # a head width the native composite is not built for
+        return _transformer_forward_generic(transformer, x, mode=mode, x_len=x_len, x_len_dev=x_len_dev, kv_len=kv_len,
+                                            mask=mask, pad=pad, embedding=embedding, x_in=x_in)
+    if cache is None or cache.batch != B or cache.s_max < T or cache.n_layers != cfg.num_layers:
         raise _lib.VhError('KV cache does not fit this forward')
     scratch = scratch or ForwardScratch(B * T, d, cfg.dim_feedforward, x.device)
     table = layer_table(transformer, cache)
@@ -201,6 +204,42 @@ def transformer_forward(transformer, x, cache: KVCache, *, mode, x_len=0, x_len_
         x=ptr(x), xn=ptr(scratch.xn), q=ptr(scratch.q), attn=ptr(scratch.attn),
         hidden=ptr(scratch.hidden), gemm_ws=ptr(scratch.ws), gemm_ws_bytes=scratch.ws_bytes, x_in=ptr(x_in))
     check(_lib.lib().vh_transformer_forward(C.byref(desc), stream()), 'vh_transformer_forward')
+    return x
+
+
+def _transformer_forward_generic(transformer, x, *, mode, x_len, x_len_dev, kv_len, mask, pad, embedding, x_in):
+    """`transformer_forward` for a head width other than 64 (valle/models/modules.py:109-111 allows any divisor of d_model;
+    every configuration of the path and of the reference's tests has 64, which is what the flash kernels and the native
+    composite are built for).  The same pre-norm stack layer by layer on the general kernels — LayerNorm, the tile / skinny
+    GEMMs, materialised attention (`kernels.attn_generic`) — correct, not tuned, and without a KV cache: a caller that
+    decodes recomputes (ValleAR.generate_batch does)."""
+    cfg = transformer.hparams
+    B, T, d = x.shape
+    h = cfg.n_heads
+    hd = d // h
+    if hd % 4:
+        raise _lib.VhError(f'head_dim {hd}: the general attention path needs a multiple of 4')
+    ada = None
+    if cfg.norm != 'LayerNorm':
+        if embedding is None:
+            raise TypeError('AdaptiveLayerNorm needs `embedding` (reference: Linear(None) TypeError)')
+        ada = adaln_table(transformer, embedding)
+    cur = (x_in if x_in is not None else x).reshape(B * T, d)
+    spec = dict(mode=mode, x_len=int(x_len), x_len_dev=x_len_dev, kv_len=kv_len, mask=mask, pad=pad)
+    f32 = dict(device=x.device, dtype=torch.float32)
+    for i, layer in enumerate(transformer.layers):
+        g1, b1, wqkv, wo, bo, g2, b2, w1, bb1, w2, bb2 = (t.detach() for t in _layer_params(layer))
+        sc1, sh1, sc2, sh2 = (ada[i, 0, 0], ada[i, 0, 1], ada[i, 1, 0], ada[i, 1, 1]) if ada is not None else (None,) * 4
+        xn = kernels.layernorm(cur, g1, b1, ada_scale=sc1, ada_shift=sh1, eps=layer.norm1.eps)
+        qkv = kernels.linear(xn, wqkv, out=torch.empty(B * T, 3 * d, **f32))
+        q, k, v = (qkv.view(B, T, 3, h, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        attn = torch.empty(B * T, d, **f32)
+        kernels.attn_generic(q, k, v, attn.view(B, T, h, hd).permute(0, 2, 1, 3), hd ** -0.5, **spec)
+        nxt = kernels.linear(attn, wo, bo, residual=cur, out=torch.empty(B * T, d, **f32))
+        xn = kernels.layernorm(nxt, g2, b2, ada_scale=sc2, ada_shift=sh2, eps=layer.norm2.eps)
+        hid = kernels.linear(xn, w1, bb1, act=kernels.ACT_GELU, out=torch.empty(B * T, w1.shape[0], **f32))
+        cur = kernels.linear(hid, w2, bb2, residual=nxt, out=torch.empty(B * T, d, **f32))
+    x.reshape(B * T, d).copy_(cur)
     return x
 
 
@@ -223,6 +262,45 @@ def _capture_stream(device_index):
     if st is None:
         st = _CAPTURE_STREAMS[device_index] = torch.cuda.Stream(device=device_index)
     return st
+
+
+class StepSampler:
+    """Head + sampling step on the last hidden row of a full forward (valle_ar.py:158-171: logits, top-k / top-p / greedy
+    draw, EOS bookkeeping, token append) with the decode state on the device — what ArDecoder.sample_from does, without
+    the native decoder behind it: the recompute path of ValleAR.generate_batch (use_kv_cache=False, or a head width the
+    decoder is not built for) samples through this."""
+
+    def __init__(self, model, batch, codes, cache_len, audio_pos, pos_base, seed=0):
+        cfg = model.config
+        dev = codes.device
+        self.B, self.V, self.d = batch, cfg.num_audio_tokens + 1, cfg.d_model
+        self.eos = cfg.num_audio_tokens
+        self.logits = torch.zeros(batch, (self.V + 3) // 4 * 4, device=dev, dtype=torch.float32)
+        self.x = torch.empty(batch, cfg.d_model, device=dev, dtype=torch.float32)       # the appended token's embedding (unused here)
+        self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
+        self.sum_logprobs = torch.zeros(batch, device=dev, dtype=torch.float32)
+        self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
+        self.codes, self.cache_len, self.audio_pos, self.pos_base = codes, cache_len, audio_pos, pos_base
+        self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(), model.audio_position_emb.pe)
+        self.n_split, self.ffn_ws, self.kv_bf16 = 0, None, False
+
+    def sample_from(self, hidden_last):
+        m = self._keep
+        kernels.linear(hidden_last, m[0], out=self.logits[:, : self.V])
+        if self.sampling[0] == 1:
+            kernels.greedy_step(self.logits, self.V, self.eos, self.codes, self.eos_count, m[1], m[2],
+                                self.audio_pos, self.cache_len, self.x, pos_base=self.pos_base)
+        else:
+            top_k, top_p, temp, seed = self.sampling
+            kernels.sample_step(self.logits, self.V, self.eos, top_k, top_p, temp, seed, self.codes,
+                                self.eos_count, self.sum_logprobs, m[1], m[2], self.audio_pos,
+                                self.cache_len, self.x, pos_base=self.pos_base)
+
+    def capture(self):
+        pass
+
+    def close(self):
+        pass
 
 
 class ArDecoder:

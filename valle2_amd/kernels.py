@@ -303,6 +303,32 @@ def attn_rows_bwd(q, kcache, vcache, out, dout, lse2, dq, dk, dv, B, n_heads, T,
     return dq, dk, dv
 
 
+def softmax_rows(S, ld, B, n_heads, Tq, Tk, scale, mode=MASK_FULL, x_len=0, x_len_dev=None, kv_len=None, mask=None,
+                 pad=None):
+    """P = softmax(S * scale + mask) in place over the rows of the (B, h, Tq, Tk) maps inside S (row stride ld); the mask
+    arguments are those of attn_rows."""
+    check(_lib.lib().vh_softmax_rows(S.data_ptr(), ld, B, n_heads, Tq, Tk, float(scale), mode, x_len, ptr(x_len_dev),
+                                     ptr(kv_len), ptr(mask), ptr(pad), stream()), 'vh_softmax_rows')
+    return S
+
+
+def attn_generic(q, k, v, out, scale, **spec):
+    """Attention for a head width the flash kernels are not built for (they serve 64 = every configuration of the path;
+    valle/models/modules.py:109-111 allows any divisor of d_model): the probabilities are MATERIALISED — S = Q K^T on the
+    batched MFMA GEMM, the masked row softmax, O = P V on the same GEMM.  Correct for any head width that is a multiple
+    of 4, not tuned: O(T^2) memory per (batch row, head).  q (B, h, Tq, hd), k / v (B, h, Tk, hd), out (B, h, Tq, hd):
+    views with unit stride in the last dimension (the per-head column blocks of a (rows, 3 d) projection are read in
+    place).  Returns P (B, h, Tq, Tk) for a backward that wants it."""
+    B, h, Tq, hd = q.shape
+    Tk = k.shape[2]
+    tp = (Tk + 3) // 4 * 4
+    P = torch.empty(B, h, Tq, tp, device=q.device, dtype=torch.float32)[..., :Tk]
+    gemm(q, k, P)                                               # raw scores
+    softmax_rows(P, tp, B, h, Tq, Tk, scale, **spec)
+    gemm(P, v, out, b_kmajor=True)
+    return P
+
+
 def attn_decode_ws(B, n_heads, n_split, device):
     """Workspace of a key-split decode attention: split records + the per-(b, head) ticket words, which must start at
     zero (the kernel re-arms them itself) — hence zeros, not empty."""

@@ -260,7 +260,7 @@ class MultiHeadAttention(nn.Module):
         """x (B, n, d) → (out (B, n, d), (k, v) | None) with k, v of shape (B, h, S, hd).
         `_ln` / `_residual` are internal fusion hooks used by EncoderLayer."""
         if self.head_dim != HEAD_DIM:
-            raise _lib.VhError(f'head_dim {self.head_dim} unsupported: the kernels are built for 64')
+            return self._forward_any_head_dim(x, attn_mask, padding_mask, kv_cache, use_cache, _ln, _residual)
         b, n, d = x.shape
         h = self.n_heads
         x2 = x.reshape(b * n, d)
@@ -309,6 +309,34 @@ class MultiHeadAttention(nn.Module):
         if use_cache:
             new = _CacheView(info.kbuf, info.vbuf, total)
             kv = _tag(info.kbuf[:, :, :total], info.vbuf[:, :, :total], new)
+        return out.view(b, n, d), kv
+
+    def _forward_any_head_dim(self, x, attn_mask, padding_mask, kv_cache, use_cache, _ln, _residual):
+        """The same forward for a head width other than 64 (modules.py:109-111 allows any divisor; 64 is what every
+        configuration of the path has and what the flash / decode kernels are built for): the projection on the general
+        GEMMs and materialised attention (kernels.attn_generic) — correct, not tuned; the cache is the reference's own
+        protocol, (k, v) tensors grown by a device copy per call."""
+        b, n, d = x.shape
+        h, hd = self.n_heads, self.head_dim
+        if hd % 4:
+            raise _lib.VhError(f'head_dim {hd}: the general attention path needs a multiple of 4')
+        x2 = x.reshape(b * n, d).contiguous()
+        if _ln is not None:
+            x2 = kernels.layernorm(x2, *_ln[:2], ada_scale=_ln[2], ada_shift=_ln[3], eps=_ln[4])
+        f32 = dict(device=x.device, dtype=torch.float32)
+        qkv = kernels.linear(x2, self.qkv.weight.detach(), out=torch.empty(b * n, 3 * d, **f32))
+        q, k, v = (qkv.view(b, n, 3, h, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        if use_cache and kv_cache is not None:
+            k = torch.cat([kv_cache[0].to(x.device), k], dim=2)
+            v = torch.cat([kv_cache[1].to(x.device), v], dim=2)
+        total = k.shape[2]
+        spec = _mask_spec(attn_mask, padding_mask, n, total, x.device)
+        attn = torch.empty(b * n, d, **f32)
+        kernels.attn_generic(q, k, v, attn.view(b, n, h, hd).permute(0, 2, 1, 3), hd ** -0.5, **spec)
+        res2 = _residual.reshape(b * n, d) if _residual is not None else None
+        out = kernels.linear(attn, self.out.weight.detach(), self.out.bias.detach(), residual=res2,
+                             out=torch.empty(b * n, d, **f32))
+        kv = (k.contiguous(), v.contiguous()) if use_cache else None
         return out.view(b, n, d), kv
 
     def merge_masks(self, batch_size, attn_mask, key_padding_mask):
@@ -420,7 +448,8 @@ class Transformer(nn.Module):
             attn_mask = None
         else:
             kv_cache = tuple([None] * self.hparams.num_layers)
-            if not self._any_dropout() and x.shape[0] * x.shape[1] > 64:
+            if (not self._any_dropout() and x.shape[0] * x.shape[1] > 64 and
+                    self.hparams.d_model == self.hparams.n_heads * HEAD_DIM):      # (another head width: layer by layer)
                 return self._forward_native(x, padding_mask, attn_mask, embedding, use_cache)
         for layer, past_kv in zip(self.layers, kv_cache):
             x, next_kv = layer(x, padding_mask=padding_mask, attn_mask=attn_mask,

@@ -14,7 +14,7 @@ import torch.nn as nn
 from torch import optim
 
 from . import _lib, dropout, kernels
-from .engine import ArDecoder, ForwardScratch, KVCache, transformer_forward
+from .engine import ArDecoder, ForwardScratch, KVCache, StepSampler, transformer_forward
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device, device_mirror
 from .utils import get_best_beam
 
@@ -182,10 +182,13 @@ class ValleAR(_Base):
         the steps listed in keep_logits are left in `last_generate_stats['logits']`."""
         self._require_layernorm()
         cfg = self.config
-        no_cache = not cfg.use_kv_cache
+        # a head width other than 64 (modules.py:109-111 allows it; no configuration of the path has it): the native
+        # decoder and its KV-cache kernels are built for 64, so such a model decodes by recomputation on the general kernels
+        any_head_dim = cfg.d_model != cfg.n_heads * kernels.HEAD_DIM
+        no_cache = not cfg.use_kv_cache or any_head_dim
         if no_cache and (perf_mode or profile_attn or forced is not None):
-            raise ValueError('use_kv_cache=False recomputes every step from scratch: perf_mode / profile_attn / forced '
-                             'belong to the cached decoder')
+            raise ValueError('use_kv_cache=False (or a head width other than 64) recomputes every step from scratch: '
+                             'perf_mode / profile_attn / forced belong to the cached decoder')
         dev = self.device
         B = len(texts)
         if B == 0 or len(first_codes) != B:
@@ -227,7 +230,7 @@ class ValleAR(_Base):
         # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None).  Row b is laid
         # out [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.
         # (perf mode: the prompt pass needs its fp32 cache only as long as the prompt; the bf16 cache holds the run)
-        cache = KVCache(cfg.num_layers, B, cfg.n_heads, s0 if perf_mode else s_max, dev)
+        cache = None if any_head_dim else KVCache(cfg.num_layers, B, cfg.n_heads, s0 if perf_mode else s_max, dev)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # prefill | decode phase times
         marks[0].record()
         texts = [kernels.ids_to_device(t, dev, cfg.vocab_size, 'text ids') for t in texts]
@@ -252,15 +255,18 @@ class ValleAR(_Base):
         audio_pos = _lib.to_device_async(torch.tensor(pls, dtype=torch.int32), dev)   # cache_len: +1 by the sample step
         pos_base = audio_pos.clone()
         transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
-                            scratch=ForwardScratch(B * s0, d, cfg.dim_feedforward, dev), **fwd)
+                            scratch=None if any_head_dim else ForwardScratch(B * s0, d, cfg.dim_feedforward, dev), **fwd)
         if ragged:
             last = x[torch.arange(B, device=dev), lens.long() - 1]
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
         if perf_mode:
             cache = cache.narrowed(s_max)                 # fp32 prompt K/V -> the bf16 cache of the decode steps
-        dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base, use_graph=use_graph and not no_cache,
-                        seed=seed)
+        if any_head_dim:
+            dec = StepSampler(self, B, codes, cache_len, audio_pos, pos_base, seed=seed)
+        else:
+            dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base,
+                            use_graph=use_graph and not no_cache, seed=seed)
         try:
             dec.capture()                                 # (a no-op without a graph: the no-cache path only borrows the sampler)
             dec.sample_from(last.contiguous())
@@ -289,7 +295,7 @@ class ValleAR(_Base):
                 # under the prefix mask — no state is carried from step to step except the tokens — and samples from
                 # its last row with the same head / sample kernels.  O(S^2) per token; it exists so that the flag works
                 # and as an independent check of the cached decoder (same tokens, tests/test_models_gpu.py).
-                scratch = ForwardScratch(B * (s0 + max_new), d, cfg.dim_feedforward, dev)
+                scratch = None if any_head_dim else ForwardScratch(B * (s0 + max_new), d, cfg.dim_feedforward, dev)
                 rows_idx = torch.arange(B, device=dev)
                 while done < max_new:
                     t = done
