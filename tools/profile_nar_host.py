@@ -45,7 +45,6 @@ def step(i, prof=None):
 
 
 for i in range(16):
-    print(f'step {i} stage {1 + i % 7}: fwd enqueue {step.__call__(i)}', flush=True) if False else None
     r = step(i)
     print(f'step {i:2d} stage {1 + i % 7}: fwd enqueue {r[0]:6.1f} ms, fwd {r[1]:6.1f}, bwd {r[2]:6.1f}, opt {r[3]:5.1f}', flush=True)
 pr = cProfile.Profile()
