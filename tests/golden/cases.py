@@ -447,7 +447,57 @@ def _ref_collate(ref):
     return dict(rcollate.ValleARCollate(cfg)(collate_inputs()))
 
 
+# ---- head widths other than 64 (round 4): d_model // n_heads = 32 and 128 -------------------------------------------
+HD_MHA_SHAPES = [(128, 4, 3, 19), (256, 2, 2, 23)]            # (d_model, n_heads, batch, seq): head_dim 32, 128
+AR_HD32 = dict(d_model=128, n_heads=4, dim_feedforward=256, num_layers=2, dropout=0.0, norm='LayerNorm', num_beams=3,
+               top_k=1, max_audio_len=24)
+
+
+def head_dim_inputs():
+    cfg = cfg_of(AR_HD32)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=31, rich=True), cfg)
+    utt = synth.synth_utterance(cfg, 9, 7, 25, seed=77)
+    batch = synth.synth_ar_batch(cfg, 3, tok_range=(5, 11), code_range=(20, 45), seed=8)
+    return AR_HD32, sd, utt, batch
+
+
+def _ref_head_dim(ref):
+    """The real reference at head widths 32 and 128: MultiHeadAttention (causal, causal + padding, a cached step) and a
+    2-layer ValleAR with head width 32 — greedy generate with margins, training loss and per-parameter gradient norms."""
+    out = {}
+    for d, h, b, t in HD_MHA_SHAPES:
+        sd, x, causal, pad = mha_inputs(d, h, b, t)
+        m = ref['modules'].MultiHeadAttention(d, h).eval()
+        m.load_state_dict(sd)
+        assert m.head_dim == d // h != 64
+        o, (k, v) = m(x, attn_mask=causal, use_cache=True)
+        o2, _ = m(x, attn_mask=causal, padding_mask=pad)
+        xn = _randn((b, 1, d), 300 + d)
+        o4, (k4, _) = m(xn, kv_cache=(k, v), use_cache=True)
+        out.update({f'out_{d}': o, f'k_{d}': k, f'out_pad_{d}': o2, f'out_step_{d}': o4, f'k_step_{d}': k4})
+    kw, sd, utt, batch = head_dim_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['ar'].ValleAR(cfg).eval()
+    m.load_state_dict(sd)
+    rows = []
+    hook = m.proj.register_forward_hook(lambda mod, i, o: rows.append(o[:, -1].clone()))
+    torch.manual_seed(0)
+    tokens = m.generate(*utt)
+    hook.remove()
+    top2 = torch.topk(torch.stack(rows)[:, 0], 2, dim=-1)[0]
+    out.update({'tokens': tokens, 'margin': top2[:, 0] - top2[:, 1]})
+    with torch.enable_grad():
+        m = ref['ar'].ValleAR(cfg).eval()
+        m.load_state_dict(sd)
+        loss = m.training_step({k: v.clone() for k, v in batch.items()})
+        loss.backward()
+        grads = {n: p.grad.norm() for n, p in m.named_parameters()}
+    out.update({'loss': loss.detach(), 'grad_norms': torch.stack([grads[n] for n in sorted(grads)]).detach()})
+    return out
+
+
 REFERENCE_RUNNERS = {
+    'head_dim': _ref_head_dim,
     'collate': _ref_collate,
     'masks': _ref_masks,
     'mha': _ref_mha,

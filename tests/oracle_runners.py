@@ -57,6 +57,29 @@ def transformer():
     return out
 
 
+def head_dim():
+    out = {}
+    for d, h, b, t in C.HD_MHA_SHAPES:
+        sd, x, causal, pad = C.mha_inputs(d, h, b, t)
+        o, (k, v) = O.multi_head_attention(sd, '', x, h, attn_mask=causal, use_cache=True)
+        o2, _ = O.multi_head_attention(sd, '', x, h, attn_mask=causal, padding_mask=pad)
+        xn = C._randn((b, 1, d), 300 + d)
+        o4, (k4, _) = O.multi_head_attention(sd, '', xn, h, kv_cache=(k, v), use_cache=True)
+        out.update({f'out_{d}': o, f'k_{d}': k, f'out_pad_{d}': o2, f'out_step_{d}': o4, f'k_step_{d}': k4})
+    kw, sd, utt, batch = C.head_dim_inputs()
+    cfg = C.cfg_of(kw)
+    trace = {}
+    out['tokens'] = O.ar_generate(sd, cfg, *utt, trace=trace)
+    out['margin'] = torch.tensor(trace['margin'])
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    with torch.enable_grad():
+        loss = O.ar_training_loss(params, cfg, batch)
+        loss.backward()
+    names = sorted(k for k in params if not k.endswith('.pe'))
+    out.update({'loss': loss.detach(), 'grad_norms': torch.stack([params[n].grad.norm() for n in names])})
+    return out
+
+
 def ar_train():
     kw, sd, batch = C.ar_train_inputs()
     cfg = C.cfg_of(kw)
@@ -225,7 +248,7 @@ ORACLE_RUNNERS = {
     'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full, 'ar_generate_big': ar_generate_big,
     'nar_full': nar_full,
     'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
-    'masks': masks, 'mha': mha, 'transformer': transformer, 'ar_train': ar_train,
+    'masks': masks, 'mha': mha, 'head_dim': head_dim, 'transformer': transformer, 'ar_train': ar_train,
     'ar_train_dropout': ar_train_dropout, 'transformer_dropout': transformer_dropout,
     'ar_generate_tiny': ar_generate_tiny, 'ar_generate_mid': ar_generate_mid,
     'ar_generate_eos': ar_generate_eos, 'nar': nar, 'sampling': sampling,

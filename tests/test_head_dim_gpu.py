@@ -162,3 +162,38 @@ def test_nar_generate_batch_any_head_dim_matches_the_oracle_per_utterance():
     for (text, pc, first), got in zip(us, outs):
         ref = O.nar_generate(sd, cfg, text[:4], pc, text[4:], first, greedy=True)
         assert torch.equal(got.cpu(), ref), f'{(got.cpu() != ref).sum().item()} of {ref.numel()} tokens differ'
+
+
+def test_head_dim_32_and_128_match_the_real_reference():
+    """tests/golden/head_dim.npz was written by the REAL reference (gen_golden.py): MultiHeadAttention at head widths 32
+    and 128 (causal, causal + padding, a cached step), and a 2-layer ValleAR with head width 32 — greedy generate with its
+    margins, training loss and per-parameter gradient norms."""
+    from tests.oracle_runners import load_golden
+    from valle2_amd import get_model_class
+    from valle2_amd.modules import MultiHeadAttention
+    gold = load_golden('head_dim')
+    for d, h, b, t in C.HD_MHA_SHAPES:
+        sd, x, causal, pad = C.mha_inputs(d, h, b, t)
+        m = MultiHeadAttention(d, h)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval()
+        o, (k, v) = m(x.to(DEV), attn_mask=causal.to(DEV), use_cache=True)
+        o2, _ = m(x.to(DEV), attn_mask=causal.to(DEV), padding_mask=pad.to(DEV))
+        o4, (k4, _) = m(C._randn((b, 1, d), 300 + d).to(DEV), kv_cache=(k, v), use_cache=True)
+        for got, key in ((o, f'out_{d}'), (k, f'k_{d}'), (o2, f'out_pad_{d}'), (o4, f'out_step_{d}'), (k4, f'k_step_{d}')):
+            close(got, gold[key])
+    kw, sd, utt, batch = C.head_dim_inputs()
+    model = get_model_class('ValleAR')(C.cfg_of(kw))
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    out = model.generate(*[u.to(DEV) for u in utt]).cpu()
+    ref = gold['tokens']
+    n = min(len(out), len(ref))
+    bad = (out[:n] != ref[:n]).nonzero()
+    assert len(out) == len(ref) and (bad.numel() == 0 or float(gold['margin'][int(bad[0])]) < 1e-4), (out, ref)
+    loss = model.training_step({k: v.clone() for k, v in batch.items()})
+    torch.testing.assert_close(loss.detach().cpu(), gold['loss'], rtol=1e-5, atol=1e-6)
+    loss.backward()
+    names = sorted(n for n, _ in model.named_parameters())
+    norms = torch.stack([dict(model.named_parameters())[n].grad.norm().cpu() for n in names])
+    torch.testing.assert_close(norms, gold['grad_norms'], rtol=1e-3, atol=1e-7)
