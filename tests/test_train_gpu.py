@@ -591,3 +591,58 @@ def test_train_accumulation_windows_end_with_the_epoch(n_batches, accum, max_ste
     full_epochs, rest = divmod(expect_steps, windows_per_epoch)
     want = full_epochs * n_batches + (min(n_batches, rest * accum) if rest else 0)
     assert len(losses) == len(seen) == want, (len(losses), want)
+
+
+def test_attn_rows_bwd_forms_agree_on_random_shapes():
+    """Property test: the five-product kernel (both wave counts, every chunk plan the rule picks) and the two-kernel form
+    compute the same dQ / dK / dV on 40 random (batch, heads, length, mask family, prefix length, key lengths) draws —
+    lengths that are no multiple of the 32-key wave block or the 32-query tile, rows whose keys end inside a chunk, chunks
+    that are all padding, one-key rows — and a forced chunk count never changes more than the summation order."""
+    from valle2_amd import _lib
+    from valle2_amd import kernels as K
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(2024)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))     # noqa: E731
+    for trial in range(40):
+        B, h = ri(1, 5), ri(1, 4)
+        T = [ri(1, 40), ri(33, 300), ri(257, 700), ri(700, 1300)][trial % 4]
+        mode = [K.MASK_PREFIX, K.MASK_FULL, K.MASK_EXPLICIT][trial % 3]
+        d = 64 * h
+        q = torch.randn(B * T, d, generator=g).to(DEV)
+        k = torch.randn(B, h, T, 64, generator=g).to(DEV)
+        v = torch.randn(B, h, T, 64, generator=g).to(DEV)
+        dout = torch.randn(B * T, d, generator=g).to(DEV)
+        kvl = torch.randint(1, T + 1, (B,), generator=g, dtype=torch.int32)
+        if trial % 5 == 0:
+            kvl[0] = T
+        if mode == K.MASK_EXPLICIT:
+            m2 = torch.rand(T, T, generator=g) < 0.4
+            m2[torch.arange(T), torch.arange(T)] = False
+            spec = dict(mode=mode, mask=m2.to(torch.uint8).to(DEV))
+        elif mode == K.MASK_PREFIX:
+            xl = ri(0, T)
+            # a query must see at least one key: rows shorter than the prefix still see keys < their length
+            spec = dict(mode=mode, x_len=xl, kv_len=kvl.to(DEV))
+        else:
+            spec = dict(mode=mode, kv_len=kvl.to(DEV))
+        out = torch.empty(B * T, d, device=DEV)
+        lse2 = torch.empty(B, h, T, device=DEV)
+        K.attn_rows(q, k, v, out, B, h, T, T, lse2=lse2, **spec)
+        res = []
+        for form, chunks in ((1, 0), (0, 0), (0, ri(1, 12))):
+            L.vh_set_tuning(13, form)
+            L.vh_set_tuning(14, chunks)
+            try:
+                dqkv = torch.full((B * T, 3 * d), float('nan'), device=DEV)
+                K.attn_rows_bwd(q, k, v, out, dout, lse2, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, T, **spec)
+                again = torch.empty_like(dqkv)
+                K.attn_rows_bwd(q, k, v, out, dout, lse2, again[:, :d], again[:, d:2 * d], again[:, 2 * d:], B, h, T, **spec)
+            finally:
+                L.vh_set_tuning(13, 0)
+                L.vh_set_tuning(14, 0)
+            assert torch.equal(dqkv, again), (trial, form, chunks)
+            res.append(dqkv)
+        ok = torch.isfinite(res[0])                  # (a fully masked query row is NaN in every form, as SDPA gives)
+        for r in res[1:]:
+            assert torch.equal(torch.isfinite(r), ok), trial
+            torch.testing.assert_close(r[ok], res[0][ok], atol=3e-5, rtol=1e-4, msg=lambda m: f'trial {trial} B={B} h={h} T={T} mode={mode}: {m}')
