@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 110            /* 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 111            /* 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
