@@ -291,10 +291,12 @@ def attn_rows_bwd(q, kcache, vcache, out, dout, lse2, dq, dk, dv, B, n_heads, T,
         raise _lib.VhError(f'attn_rows_bwd: cache {tuple(kcache.shape)} T={T}')
     if not (dq.stride(0) == dk.stride(0) == dv.stride(0)) or dq.stride(1) != 1:
         raise _lib.VhError('attn_rows_bwd: dq/dk/dv must share one row stride')
-    # scratch from torch's caching allocator (stream-ordered reuse): the dQ partial slabs of the five-product kernel
-    # (ceil(T / 256) x (B*h, T, 64) floats) or, under VH_TUNE_ATTN_BWD = 1, the two-kernel form's D vector
+    # scratch: the dQ partial slabs of the five-product kernel (chunks x (B*h, T, 64) floats: 134 MB at the configs[3] AR
+    # step) or, under VH_TUNE_ATTN_BWD = 1, the two-kernel form's D vector.  One growing buffer per (device, stream) —
+    # launches of a stream run in order, so its 12 layers share it — instead of 12 allocations of that size per step
+    # whose sizes change with every ragged batch.
     need = _lib.lib().vh_attn_rows_bwd_ws_bytes(B, n_heads, T)
-    ws = torch.empty(max(need, 16) // 4, device=q.device, dtype=torch.float32)
+    ws = _stream_ws(_BWD_WS, q.device, need)
     check(_lib.lib().vh_attn_rows_bwd_ws(
         q.data_ptr(), q.stride(0), ptr(kcache), ptr(vcache), out.data_ptr(), out.stride(0),
         dout.data_ptr(), dout.stride(0), ptr(lse2), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
@@ -401,6 +403,21 @@ def pad32(n):
 
 
 _TAIL_WS = {}
+_BWD_WS = {}
+
+
+def _stream_ws(pool, device, need, floor=1 << 20):
+    """A float32 workspace of >= need bytes owned by (device, current stream): grown when too small, kept otherwise."""
+    key = (device.index, stream())
+    ws = pool.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        if len(pool) >= 8 and key not in pool:       # streams come and go: keep the most recent few
+            torch.cuda.synchronize(device)           # (rare: nothing in flight may still be using the one let go)
+            pool.pop(next(iter(pool)))
+        # (the buffer let go was allocated on this stream and only ever used by launches of this stream: torch's caching
+        # allocator hands its block to later work of the same stream only, so no wait is needed before it is replaced)
+        ws = pool[key] = torch.empty(max(need, floor) // 4, device=device, dtype=torch.float32)
+    return ws
 
 
 def _tail_ws(device, stream_handle, M, N, K):
