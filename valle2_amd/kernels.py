@@ -519,12 +519,7 @@ def gemm_tn(a, b, out=None):
     if tuple(out.shape) != (NI, NJ) or out.stride(1) != 1:
         raise _lib.VhError('gemm_tn: out shape')
     need = _lib.lib().vh_gemm_tn_ws_bytes(M, NI, NJ)
-    ws = None
-    if need:                      # one growing workspace per device: calls are stream-ordered
-        key = a.device.index
-        ws = _tn_ws.get(key)
-        if ws is None or ws.numel() * 4 < need:
-            ws = _tn_ws[key] = torch.empty(need // 4, device=a.device, dtype=torch.float32)
+    ws = _stream_ws(_tn_ws, a.device, need) if need else None     # one growing workspace per (device, stream)
     check(_lib.lib().vh_gemm_tn(_dev_f32(a, 'a'), a.stride(0), _dev_f32(b, 'b'), b.stride(0), _dev_f32(out, 'out'),
                                 out.stride(0), M, NI, NJ, ptr(ws), ws.numel() * 4 if ws is not None else 0, stream()),
           'vh_gemm_tn')
