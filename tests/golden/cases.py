@@ -97,6 +97,19 @@ def ar_generate_inputs(which):
     return kw, sd, utt
 
 
+FORCED_BIG_NEW = 2250                                        # configs[4]: 2250 new tokens after a 225-frame prompt
+FORCED_BIG_POS = (225, 230, 900, 1536, 2047, 2048, 2474)     # audio positions whose teacher-forced logits are kept
+
+
+def ar_forced_big_inputs():
+    """configs[4]'s AR leg over its WHOLE context range (round 5): the 24L/1024d/h16 model and utterance of
+    `ar_generate_inputs('big')` (400 text + BOS + 225 prompt frames) followed by 2250 FORCED tokens — 2875 positions, the
+    end of a 30 s utterance.  Audio position p = 225 + t holds the logits decode step t produces (context 626 + t)."""
+    kw, sd, utt = ar_generate_inputs('big')
+    forced = torch.randint(0, cfg_of(kw).num_audio_tokens, (FORCED_BIG_NEW,), generator=torch.Generator().manual_seed(4242))
+    return kw, sd, utt, forced
+
+
 def ar_prefill_full_inputs():
     """4 DISTINCT utterances at the configs[1] prompt shape (generate() itself replicates one utterance
     over its beams, valle_ar.py:136-138, so distinct rows go through the reference's sub-modules)."""
@@ -312,6 +325,23 @@ def _ref_prefill_full(ref):
     return {'logits': logits, 'hidden_last': y[:, -1]}
 
 
+def _ref_ar_forced_big(ref):
+    """ONE teacher-forced pass of the real reference's sub-modules over 400 text + 2475 audio positions under its own
+    prefix-LM mask (valle_ar.py:61-83 / :141-158 at kv_cache=None): embed + PE, build_attn_mask, Transformer, proj."""
+    kw, sd, utt, forced = ar_forced_big_inputs()
+    cfg = cfg_of(kw, ref['config'].ConfigValle)
+    m = ref['ar'].ValleAR(cfg).eval()
+    m.load_state_dict(sd)
+    text = torch.cat([utt[0], utt[2]])[None]
+    codes = torch.cat([torch.tensor([cfg.bos_token]), utt[1][:, 0], forced[:-1]])[None]      # (1, 2475)
+    assert text.shape[1] == 400 and codes.shape[1] == 2475
+    tok = m.tokens_position_emb(m.tokens_emb(text))
+    aud = m.audio_position_emb(m.audio_emb(codes))
+    mask = ref['utils'].build_attn_mask(text.shape[1], codes.shape[1], device='cpu')
+    y, _ = m.transformer(torch.cat([tok, aud], dim=1), attn_mask=mask)
+    return {'logits': m.proj(y[0, text.shape[1]:][list(FORCED_BIG_POS)])}
+
+
 def _ref_ar_train_full(ref):
     kw, sd, batch = ar_train_full_inputs()
     with torch.enable_grad():
@@ -517,4 +547,5 @@ REFERENCE_RUNNERS = {
     'ar_prefill_full': _ref_prefill_full,
     'ar_train_full': _ref_ar_train_full,
     'nar_big': _ref_nar_big,
+    'ar_forced_big': _ref_ar_forced_big,
 }

@@ -208,6 +208,19 @@ def ar_prefill_full():
             'hidden_last': y[:, -1]}
 
 
+def ar_forced_big():
+    """configs[4]'s AR leg, one teacher-forced pass over 400 text + 2475 audio positions (24L/1024d/h16)."""
+    kw, sd, utt, forced = C.ar_forced_big_inputs()
+    cfg = C.cfg_of(kw)
+    text = torch.cat([utt[0], utt[2]])[None]
+    codes = torch.cat([torch.tensor([cfg.bos_token]), utt[1][:, 0], forced[:-1]])[None]
+    tok = O.add_position(O.embed(sd['tokens_emb.word_embeddings.weight'], text), sd['tokens_position_emb.pe'])
+    aud = O.add_position(O.embed(sd['audio_emb.word_embeddings.weight'], codes), sd['audio_position_emb.pe'])
+    mask = O.build_attn_mask(text.shape[1], codes.shape[1])
+    y, _ = O.transformer(sd, 'transformer.', torch.cat([tok, aud], dim=1), cfg, attn_mask=mask)
+    return {'logits': torch.nn.functional.linear(y[0, text.shape[1]:][list(C.FORCED_BIG_POS)], sd['proj.weight'])}
+
+
 def ar_train_full():
     kw, sd, batch = C.ar_train_full_inputs()
     cfg = C.cfg_of(kw)
@@ -246,7 +259,7 @@ PREFIX_KEYS = {'ar_generate_full': ('tokens', 'margin'), 'ar_generate_big': ('to
 
 ORACLE_RUNNERS = {
     'sampling_filter': sampling_filter, 'ar_generate_full': ar_generate_full, 'ar_generate_big': ar_generate_big,
-    'nar_full': nar_full,
+    'nar_full': nar_full, 'ar_forced_big': ar_forced_big,
     'ar_prefill_full': ar_prefill_full, 'ar_train_full': ar_train_full, 'nar_big': nar_big,
     'masks': masks, 'mha': mha, 'head_dim': head_dim, 'transformer': transformer, 'ar_train': ar_train,
     'ar_train_dropout': ar_train_dropout, 'transformer_dropout': transformer_dropout,

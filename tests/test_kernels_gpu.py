@@ -576,6 +576,55 @@ def test_attn_decode_ring_kernels_short_and_ragged_rows(K, variant, S_max):
     close(out, ref, atol=3e-5)
 
 
+def _decode_ref64(q, k, v, lens, h):
+    """Double-precision one-query attention per (row, head) over the row's first lens[b] keys."""
+    B, d = q.shape
+    S = k.shape[2]
+    qd = q.double().view(B, h, 1, 64)
+    s = (qd @ k.double().transpose(-1, -2)) / 8.0                          # (B, h, 1, S)
+    s = s.masked_fill(torch.arange(S)[None, None, None, :] >= lens.long()[:, None, None, None], float('-inf'))
+    return (torch.softmax(s, dim=-1) @ v.double()).reshape(B, d).float()
+
+
+@pytest.mark.parametrize('S', [2048, 2907, 4999])
+@pytest.mark.parametrize('form', ['ring', 'burst', 'split2', 'split4', 'split16', 'kv16'])
+def test_attn_decode_long_context(K, form, S):
+    """Round 5: the decode-attention kernels over the 1.5 k - 5 k contexts configs[4] decodes at
+    (PositionalEncoding max_len 5000, modules.py:56): ring and burst kernels at 256 (row, head) pairs, key splits 2 / 4 /
+    16 + combine at fewer pairs, and the bf16-cache variant — against a double-precision reference, ragged lengths that
+    end inside / at the edge of 32-key chunks and of the split ranges, NaN / Inf beyond every row's length."""
+    from valle2_amd import _lib
+    n_split = int(form[5:]) if form.startswith('split') else 1
+    B, h = (16, 16) if n_split == 1 else {2: (8, 16), 4: (8, 8), 16: (2, 8)}[n_split]
+    d = 64 * h
+    S_max = (S + 31) // 32 * 32
+    gen = g(300 + S + n_split)
+    q = torch.randn(B, d, generator=gen)
+    k = torch.randn(B, h, S_max, 64, generator=gen)
+    v = torch.randn(B, h, S_max, 64, generator=gen)
+    if form == 'kv16':
+        k, v = k.bfloat16(), v.bfloat16()
+    tails = [0, 1, 31, 32, 33, 255, 256, 1000, S // 2, S - 1537, 63, 64, 65, 511, 512, 513]
+    lens = torch.tensor([max(1, S - tails[i % len(tails)]) for i in range(B)], dtype=torch.int32)
+    ref = _decode_ref64(q, k.float(), v.float(), lens, h)
+    for b in range(B):
+        k[b, :, int(lens[b]):] = float('nan')
+        v[b, :, int(lens[b]):] = float('inf')
+    out = torch.full((B, d), float('nan'), device=DEV)
+    lib = _lib.lib()
+    if form == 'kv16':
+        K.attn_decode_kv16(q.to(DEV), k.to(DEV), v.to(DEV), out, (lens - 1).to(DEV), 1)
+    else:
+        lib.vh_set_tuning(0, 1 if form == 'burst' else 0)
+        try:
+            ws = K.attn_decode_ws(B, h, n_split, DEV) if n_split > 1 else None
+            K.attn_decode(q.to(DEV), k.to(DEV), v.to(DEV), out, (lens - 1).to(DEV), 1, n_split, ws)
+        finally:
+            lib.vh_set_tuning(0, 0)
+    assert bool(torch.isfinite(out).all()), 'garbage beyond a row\'s length leaked into the attention output'
+    close(out, ref, atol=2e-5)
+
+
 def test_linear_qkv_scatter(K):
     B, T, h = 3, 5, 2
     d = 64 * h
