@@ -549,6 +549,8 @@ def main():
     # barrier and max-time reduction of the timed region run over a host-side gloo group (the inference path has no
     # collective of its own); RCCL carries the training leg's gradient all-reduce
     host_pg = dp.host_group()
+    # what the default group (RCCL at N > 1) itself saw: world size from the group and a count carried by a collective
+    seen = dp.ranks_seen(dev)
 
     rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
     ar_kw = dict(AR)
@@ -608,6 +610,10 @@ def main():
                    'rows_per_gpu': rows, 'prompt_tokens': text + frames + 1, 'new_tokens': new,
                    'sharding': f'utterance-batch x{world}',
                    'timed_region': 'embed + prefill + (new-1) hipGraph-replayed decode steps'},
+        # proof that the N ranks of this line were N ranks of ONE RCCL communicator: the default group's backend ("nccl" =
+        # RCCL on ROCm), its own world size, and the sum of one 1 per rank through a device all-reduce on it
+        'distributed': dict(seen, env_world_size=world),
+        'rccl_ranks_seen': seen['allreduce_count'] if seen['backend'] == 'nccl' else (1 if world == 1 else None),
     }
 
     # ---- optional legs under a deadline: the line is printed exactly once, by whoever gets there first

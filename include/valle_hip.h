@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 111            /* 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 120            /* 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -133,6 +133,11 @@ int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t ids_tstride
                     const float* pe, int pos0, const int32_t* lens, float* out,
                     int64_t out_bstride, int out_t0, int B, int T, int d, int32_t* err_flag,
                     const int32_t* row_pos0, const int32_t* row_t0, const vh_dropout_spec* drop, void* stream);
+
+/* PositionalEncoding.forward as a module call (valle/models/modules.py:78-80; its dropout is vh_dropout):
+ *   out[b, t, :] = x[b, t, :] + pe[(pos0 + t) * d + :]   for (B, T, d) contiguous x / out (out may be x); d % 4 == 0;
+ * the caller guarantees pos0 + T rows in `pe`.  (The model paths add the position inside vh_embed_sum_pe.) */
+int vh_add_pe(const float* x, const float* pe, float* out, int B, int T, int d, int pos0, void* stream);
 
 /* ---- K3/K4: LayerNorm (eps) with optional adaptive scale/shift ------------------------------
  * replaces nn.LayerNorm (valle/models/modules.py:284) and AdaptiveLayerNorm.forward (:93-99):
@@ -556,6 +561,51 @@ typedef struct {
     const float *x_in;
 } vh_forward_desc;
 int vh_transformer_forward(const vh_forward_desc* desc, void* stream);
+
+/* ---- perf mode of the MFMA-bound legs: bf16 operands, fp32 accumulate (opt-in; never the parity path) ------------
+ * SURVEY.md section 7's "perf mode" for the prompt pass (valle/models/valle_ar.py:141-158 at kv_cache=None) and the NAR
+ * stage forward (valle_nar.py:87-100): every matrix product on v_mfma_f32_32x32x16_bf16 with bf16 operands and fp32
+ * accumulators; the residual stream, LayerNorm statistics, biases, softmax and the heads stay fp32.  The reference itself
+ * asks for reduced-precision matmuls on a GPU (valle/utils.py:11, set_float32_matmul_precision('high')).  Teacher-forced
+ * logits agree with the reference to atol 5e-2; greedy tokens are NOT guaranteed.  bf16 = the upper 16 bits
+ * of an fp32, round to nearest even, passed as uint16_t.
+ *   vh_to_bf16              narrows a (rows, cols) fp32 matrix (weights: once per weight set); cols % 8 == 0.
+ *   vh_layernorm_bf16       vh_layernorm with a bf16 output (the A operand of the product that follows); d % 8 == 0.
+ *   vh_linear_bf16          out = act(A W^T + bias) + residual, A (M,K) lda and W (N,K) bf16, bias (N) / residual (M,N) ldr
+ *                           fp32; out fp32 (M,N) ldo, or bf16 when out_bf16 != 0 (no residual then).  N % 128 == 0,
+ *                           K % 64 == 0, act NONE / GELU_ERF.
+ *   vh_linear_qkv_bf16      vh_linear_qkv with bf16 operands: q_out (M, d) ldq bf16, K / V rows appended to bf16 caches
+ *                           (B,h,S_max,64) — the layout vh_attn_decode_kv16 streams, so a perf-mode generate needs no
+ *                           narrowing pass.  d_model % 128 == 0.
+ *   vh_attn_rows_bf16       vh_attn_rows over bf16 q / K / V with a bf16 output; analytic masks only (FULL / PREFIX). */
+int vh_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int cols, void* stream);
+int vh_layernorm_bf16(const float* x, const float* gamma, const float* beta, const float* ada_scale,
+                      const float* ada_shift, uint16_t* out, int rows, int d, float eps, void* stream);
+int vh_linear_bf16(const uint16_t* A, int lda, const uint16_t* W, const float* bias, const float* residual, int ldr,
+                   void* out, int ldo, int out_bf16, int M, int N, int K, int act, void* stream);
+int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wqkv, uint16_t* q_out, int ldq, uint16_t* kcache16,
+                       uint16_t* vcache16, const int32_t* cache_len, int B, int T, int d_model, int n_heads, int S_max,
+                       void* stream);
+int vh_attn_rows_bf16(const uint16_t* q, int ldq, const uint16_t* kcache16, const uint16_t* vcache16, uint16_t* out, int ldo,
+                      int B, int n_heads, int Tq, int Tk, int S_max, int mode, int x_len, const int32_t* x_len_dev,
+                      const int32_t* kv_len, void* stream);
+
+/* vh_transformer_forward in perf mode.  `layers` supplies the fp32 LayerNorm parameters and biases (its weight matrices
+ * and caches are not touched); layers16[i] the bf16 copies of the four matrices (vh_to_bf16) and the layer's bf16 caches.
+ * x (B*T, d) fp32 in/out (x_in as in vh_forward_desc); scratch: xn16, q16, attn16 (B*T, d) and hidden16 (B*T, dff) bf16. */
+typedef struct { const uint16_t *wqkv, *wo, *w1, *w2; uint16_t *kcache16, *vcache16; } vh_layer16;
+typedef struct {
+    int B, T, d_model, n_heads, dff, n_layers, S_max, mode, x_len;
+    float ln_eps;
+    const vh_layer* layers;
+    const vh_layer16* layers16;
+    const float* ada;                 /* (L,2,2,d) or NULL */
+    const int32_t *x_len_dev, *kv_len;
+    float* x;
+    const float* x_in;
+    uint16_t *xn16, *q16, *attn16, *hidden16;
+} vh_forward16_desc;
+int vh_transformer_forward_bf16(const vh_forward16_desc* desc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,9 @@ def test_bench_small_four_ranks_on_one_gpu():
     assert len(lines) == 1, out.stdout                       # rank 0 prints the ONE line
     r = lines[0]
     assert r['n_gpus'] == 4 and r['steps'] == 2 and r['warmup'] == 1 and r['scaling'] == 'weak'
+    # the default group's own account of itself (gloo in this rehearsal: RCCL wants a device per rank)
+    assert r['distributed'] == {'backend': 'gloo', 'group_world_size': 4, 'allreduce_count': 4, 'env_world_size': 4}
+    assert r['rccl_ranks_seen'] is None
     assert r['value'] > 0 and r['config']['sharding'] == 'utterance-batch x4'
     train = r['train']
     assert 'error' not in train, train

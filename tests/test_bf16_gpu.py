@@ -1,0 +1,209 @@
+"""Perf mode of the MFMA-bound legs (SECONDARY): the bf16-MFMA kernels of csrc/bf16.hip.
+
+Kernel level: each kernel against fp32 / fp64 torch math ON THE SAME bf16-ROUNDED OPERANDS (the kernel's products are
+exact in fp32 accumulators: what may differ is summation order, and — in attention — the bf16 rounding of P), plus
+integer-valued operands through the GEMM coming out EXACTLY (MFMA operand / accumulator layout check, asymmetric data).
+Model level: teacher-forced logits of the perf-mode forward within SURVEY 8(c)'s atol 5e-2 of the REAL reference's goldens
+(`ar_prefill_full`, `nar_full`, `nar_big`); greedy tokens are not asserted in this mode."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.golden import cases as C
+from tests.oracle_runners import load_golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def K():
+    from valle2_amd import kernels
+    return kernels
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def test_to_bf16_rounds_to_nearest_even(K):
+    x = torch.randn(37, 264, generator=g(1)) * 3
+    x[0, :4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65280.0])       # exact ties, signed zero
+    out = K.to_bf16(x.to(DEV))
+    assert torch.equal(out.cpu().view(torch.int16), x.bfloat16().view(torch.int16))
+
+
+@pytest.mark.parametrize('rows,d,ada', [(5, 128, False), (1000, 512, True), (33, 1024, True), (7, 2048, False)])
+def test_layernorm_bf16(K, rows, d, ada):
+    x = torch.randn(rows, d, generator=g(2)) * 2 + 0.5
+    gm, bt = 1 + 0.2 * torch.randn(d, generator=g(3)), 0.2 * torch.randn(d, generator=g(4))
+    sc, sh = (1 + 0.1 * torch.randn(d, generator=g(5)), 0.1 * torch.randn(d, generator=g(6))) if ada else (None, None)
+    ref = F.layer_norm(x.double(), (d,), gm.double(), bt.double(), 1e-5)
+    if ada:
+        ref = sc.double() * ref + sh.double()
+    out = K.layernorm_bf16(x.to(DEV), gm.to(DEV), bt.to(DEV), ada_scale=None if sc is None else sc.to(DEV),
+                           ada_shift=None if sh is None else sh.to(DEV))
+    assert out.dtype == torch.bfloat16
+    # one bf16 rounding of an fp32-accurate value: half an ulp of bf16 = 2^-9 relative
+    torch.testing.assert_close(out.cpu().double(), ref, atol=1e-5, rtol=2 ** -8)
+
+
+@pytest.mark.parametrize('M,N,K_,out16,act,res', [
+    (128, 128, 64, False, 0, False), (300, 256, 128, False, 0, True), (1000, 512, 512, True, 1, False),
+    (77, 1536, 512, False, 1, True), (4096, 512, 2048, False, 0, True), (129, 2048, 512, True, 1, False), (1, 128, 64, False, 0, False)])
+def test_linear_bf16(K, M, N, K_, out16, act, res):
+    a = torch.randn(M, K_, generator=g(10)).bfloat16()
+    w = (0.05 * torch.randn(N, K_, generator=g(11))).bfloat16()
+    bias = torch.randn(N, generator=g(12))
+    r = torch.randn(M, N, generator=g(13)) if res else None
+    ref = a.double() @ w.double().T + bias.double()
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    out = K.linear_bf16(a.to(DEV), w.to(DEV), bias.to(DEV), residual=None if r is None else r.to(DEV),
+                        act=K.ACT_GELU if act else K.ACT_NONE, out_bf16=out16)
+    assert out.dtype == (torch.bfloat16 if out16 else torch.float32)
+    if out16:
+        # one bf16 rounding (2^-9 relative) of an fp32 sum; with GELU also gelu16_2's 4e-5 absolute / 3e-4 relative
+        torch.testing.assert_close(out.cpu().double(), ref, atol=1e-4 if act else 1e-5, rtol=2 ** -7 if act else 2 ** -8)
+    else:
+        torch.testing.assert_close(out.cpu().double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5)
+
+
+def test_linear_bf16_integer_operands_are_exact(K):
+    """Small integers are exact in bf16 and their products / sums exact in fp32: any operand-layout or accumulator-map
+    error shows as a wrong integer.  Asymmetric data (a[m][k] depends on m and k differently than w[n][k] on n and k)."""
+    M, N, K_ = 260, 256, 192
+    m, n, k = torch.arange(M)[:, None], torch.arange(N)[:, None], torch.arange(K_)[None, :]
+    a = ((3 * m + 5 * k) % 7 - 3).float()
+    w = ((2 * n + k) % 5 - 2).float()
+    ref = a @ w.T
+    out = K.linear_bf16(a.bfloat16().to(DEV), w.bfloat16().to(DEV))
+    assert torch.equal(out.cpu(), ref)
+    out16 = K.linear_bf16(a.bfloat16().to(DEV), w.bfloat16().to(DEV), out_bf16=True)
+    assert torch.equal(out16.cpu().float(), ref.bfloat16().float())
+
+
+def test_linear_bf16_refuses_shapes_outside_the_tile_kernel(K):
+    from valle2_amd._lib import VhError
+    a = torch.zeros(8, 96, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(VhError, match='N % 128'):
+        K.linear_bf16(a, torch.zeros(128, 96, device=DEV, dtype=torch.bfloat16))
+    with pytest.raises(VhError, match='bf16'):
+        K.linear_bf16(a.float(), torch.zeros(128, 96, device=DEV, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize('B,T,h,with_len', [(2, 5, 2, False), (3, 150, 4, True), (1, 1000, 8, False), (40, 7, 2, True)])
+def test_linear_qkv_bf16_scatter(K, B, T, h, with_len):
+    d = 64 * h
+    S_max = T + 20
+    a = torch.randn(B * T, d, generator=g(20)).bfloat16()
+    w = (0.1 * torch.randn(3 * d, d, generator=g(21))).bfloat16()
+    ref = (a.double() @ w.double().T).float()
+    cl = torch.tensor([(3 * i) % 17 for i in range(B)], dtype=torch.int32) if with_len else None
+    kc = torch.zeros(B, h, S_max, 64, device=DEV, dtype=torch.bfloat16)
+    vc = torch.zeros_like(kc)
+    q = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+    K.linear_qkv_bf16(a.to(DEV), w.to(DEV), q, kc, vc, B, T, h, cache_len=None if cl is None else cl.to(DEV))
+    torch.testing.assert_close(q.cpu().float(), ref[:, :d], atol=1e-5, rtol=2 ** -8)
+    kref = ref[:, d:2 * d].view(B, T, h, 64).permute(0, 2, 1, 3)
+    vref = ref[:, 2 * d:].view(B, T, h, 64).permute(0, 2, 1, 3)
+    for b in range(B):
+        p0 = 0 if cl is None else int(cl[b])
+        torch.testing.assert_close(kc[b, :, p0:p0 + T].cpu().float(), kref[b], atol=1e-5, rtol=2 ** -8)
+        torch.testing.assert_close(vc[b, :, p0:p0 + T].cpu().float(), vref[b], atol=1e-5, rtol=2 ** -8)
+        assert float(kc[b, :, :p0].abs().sum()) == 0 and float(kc[b, :, p0 + T:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize('B,h,T,mode', [(2, 2, 5, 'prefix'), (3, 2, 150, 'prefix'), (2, 8, 300, 'full'), (2, 2, 129, 'full'),
+                                        (1, 1, 64, 'prefix'), (2, 4, 1000, 'prefix'), (1, 2, 2875, 'full')])
+def test_attn_rows_bf16(K, B, h, T, mode):
+    """Against double-precision attention over the same bf16 q / K / V.  The kernel rounds P to bf16 before P V (relative
+    2^-9 per weight): the tolerance is that rounding on O(1) values, not the fp32 path's 3e-5."""
+    from oracle.valle_oracle import build_attn_mask
+    d = 64 * h
+    q = torch.randn(B, T, d, generator=g(40)).bfloat16()
+    k = torch.randn(B, h, T, 64, generator=g(41)).bfloat16()
+    v = torch.randn(B, h, T, 64, generator=g(42)).bfloat16()
+    xl = T // 3
+    kvl = torch.tensor([T - (5 * i) % (T // 2 + 1) for i in range(B)], dtype=torch.int32)
+    keypad = torch.arange(T)[None, :] >= kvl[:, None]
+    masked = (build_attn_mask(xl, T - xl)[None] | keypad[:, None, :]) if mode == 'prefix' else keypad[:, None, :].expand(B, T, T)
+    qh = q.view(B, T, h, 64).permute(0, 2, 1, 3).double()
+    ref = F.scaled_dot_product_attention(qh, k.double(), v.double(), attn_mask=~masked[:, None])
+    ref = ref.permute(0, 2, 1, 3).reshape(B * T, d)
+    S_max = T + 9
+    kc = torch.full((B, h, S_max, 64), float('nan'), dtype=torch.bfloat16)
+    vc = torch.full((B, h, S_max, 64), float('nan'), dtype=torch.bfloat16)       # garbage beyond T must never be read as a key
+    kc[:, :, :T], vc[:, :, :T] = k, v
+    out = torch.full((B * T, d), float('nan'), device=DEV, dtype=torch.bfloat16)
+    kw = dict(mode=K.MASK_PREFIX, x_len=xl, kv_len=kvl.to(DEV)) if mode == 'prefix' else dict(mode=K.MASK_FULL, kv_len=kvl.to(DEV))
+    K.attn_rows_bf16(q.view(B * T, d).to(DEV), kc.to(DEV), vc.to(DEV), out, B, h, T, T, **kw)
+    assert bool(torch.isfinite(out.float()).all())
+    torch.testing.assert_close(out.cpu().double(), ref, atol=6e-3, rtol=2 ** -7)
+
+
+def test_attn_rows_bf16_peaked_softmax(K):
+    """|q.k| in the hundreds at a late tile: the online-softmax rescale branch."""
+    B, h, T = 1, 2, 200
+    k = torch.randn(B, h, T, 64, generator=g(44))
+    v = torch.randn(B, h, T, 64, generator=g(45)).bfloat16()
+    q = torch.randn(B, T, h, 64, generator=g(46)).bfloat16()
+    k[:, :, 170] *= 40.0
+    k[:, :, 3] *= 15.0
+    k = k.bfloat16()
+    out = torch.empty(B * T, 64 * h, device=DEV, dtype=torch.bfloat16)
+    K.attn_rows_bf16(q.reshape(B * T, -1).to(DEV), k.to(DEV), v.to(DEV), out, B, h, T, T, mode=K.MASK_FULL)
+    ref = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3).double(), k.double(), v.double())
+    torch.testing.assert_close(out.cpu().double(), ref.permute(0, 2, 1, 3).reshape(B * T, -1), atol=6e-3, rtol=2 ** -7)
+
+
+# ---- model level: the perf-mode forward against the REAL reference's goldens (atol 5e-2) --------------------
+def build(name, kw, sd):
+    from valle2_amd import get_model_class
+    m = get_model_class(name)(C.cfg_of(kw))
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+def test_perf_mode_prefill_logits_within_tolerance_of_the_reference():
+    gold = load_golden('ar_prefill_full')
+    kw, sd, text, codes, pos = C.ar_prefill_full_inputs()
+    m = build('ValleAR', kw, sd)
+    b = text.shape[0]
+    batch = {'tokens': text, 'tokens_lens': torch.full((b,), text.shape[1]), 'codes': codes,
+             'codes_lens': torch.full((b,), codes.shape[1])}
+    with torch.no_grad():
+        logits = m.forward_logits(batch, perf_mode=True)
+        exact = m.forward_logits(batch)
+    err = float((logits[:, pos.to(DEV)].cpu() - gold['logits']).abs().max())
+    print(f'perf-mode prefill (configs[1], 12L/512d): max |logit error| vs the reference = {err:.2e} '
+          f'(parity path {float((exact[:, pos.to(DEV)].cpu() - gold["logits"]).abs().max()):.2e})')
+    assert err < 5e-2, err
+
+
+def test_perf_mode_nar_stage_logits_within_tolerance_of_the_reference():
+    gold = load_golden('nar_full')
+    kw, sd, batch = C.nar_full_inputs()
+    m = build('ValleNAR', kw, sd)
+    with torch.no_grad():
+        logits, p = m.stage_logits(batch, C.NAR_FULL_STAGE, perf_mode=True)
+    assert p == int(gold['prefix'])
+    got = logits[list(C.NAR_FULL_ROWS)][:, ::C.NAR_FULL_STRIDE].cpu()
+    err = float((got - gold['logits']).abs().max())
+    print(f'perf-mode NAR stage (configs[2], 64 x 1024): max |logit error| vs the reference = {err:.2e}')
+    assert err < 5e-2, err
+
+
+def test_perf_mode_nar_big_logits_within_tolerance_of_the_reference():
+    gold = load_golden('nar_big')
+    kw, sd, batch = C.nar_big_inputs()
+    m = build('ValleNAR', kw, sd)
+    for stage in (2, 7):
+        with torch.no_grad():
+            logits, p = m.stage_logits(batch, stage, perf_mode=True)
+        got = logits[:, ::C.NAR_BIG_STRIDE].cpu()
+        err = float((got - gold[f'logits_{stage}']).abs().max())
+        print(f'perf-mode NAR stage {stage} (configs[4], 24L/1024d, 2875 positions): max |logit error| = {err:.2e}')
+        assert err < 5e-2, err

@@ -59,3 +59,22 @@ def test_oracle_mask_mode_replays_its_torch_mode():
     torch.testing.assert_close(again, ref, atol=1e-6, rtol=1e-6)    # (1/(1-p) as a float product vs torch's division)
     gold_free = O.ar_logits(sd, cfg, batch)
     assert float((gold_free - ref).abs().max()) > 1e-2              # and dropout really changed the forward
+
+
+def test_no_cpu_randomness_is_consumed_when_every_dropout_is_off():
+    """Round-4 advisor finding: a forward in eval mode (or with p = 0) drew a seed from torch's global CPU generator anyway,
+    advancing the user's random stream (DataLoader shuffling ...) where the reference consumes none."""
+    import torch
+    from valle2_amd import dropout
+    from valle2_amd.config import ConfigValle
+    from valle2_amd.modules import Transformer
+    tr = Transformer(ConfigValle(d_model=128, n_heads=2, dim_feedforward=256, num_layers=2, dropout=0.1))
+    torch.manual_seed(123)
+    before = torch.get_rng_state()
+    sd = dropout.StackDropout(list(tr.eval().layers))
+    assert not sd.any and sd.seed == 0 and dropout.seed_if(0.0, 0.0) == 0
+    assert torch.equal(torch.get_rng_state(), before)
+    sd = dropout.StackDropout(list(tr.train().layers))            # live dropouts: one draw
+    assert sd.any and not torch.equal(torch.get_rng_state(), before)
+    mid = torch.get_rng_state()
+    assert dropout.seed_if(0.0, 0.1) != 0 and not torch.equal(torch.get_rng_state(), mid)

@@ -103,7 +103,7 @@ def test_config4_ar_leg_long_context_logits_match_the_reference(rows):
     assert float((got - got[:, :1]).abs().max()) < 1e-4
     err = float((got - gold['logits'][:, None]).abs().max())
     print(f'config4 long context, {rows} rows: max |logit error| over contexts 626..2875 = {err:.2e}')
-    torch.testing.assert_close(got, gold['logits'][:, None].expand_as(got), atol=1e-3, rtol=1e-4)
+    torch.testing.assert_close(got, gold["logits"][:, None].expand_as(got), atol=2e-4, rtol=1e-4)     # measured 4.3e-5
     top2 = torch.topk(gold['logits'], 2, dim=-1)
     sure = (top2.values[:, 0] - top2.values[:, 1]) > 2e-3
     assert torch.equal(got[:, 0].argmax(-1)[sure], top2.indices[:, 0][sure])

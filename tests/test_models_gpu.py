@@ -449,3 +449,27 @@ def test_generate_batch_beyond_64_rows_runs_in_groups():
     for r in (0, 63, 64, 69):
         alone = m.generate_batch([texts[r]], [firsts[r]])
         assert torch.equal(out[r, starts[r]:starts[r] + 10], alone[0, starts[r]:starts[r] + 10]), r
+
+
+def test_host_logits_and_module_level_positional_encoding_run_on_the_device():
+    """`topk_sampling` on CPU logits hops to the device like every module does (a reference caller holding
+    CPU logits keeps working: valle/models/utils.py:46-68) and returns host tensors; `PositionalEncoding.forward` as a module
+    call is a library kernel (vh_add_pe), bit-identical to the fp32 add it replaces (valle/models/modules.py:78-80)."""
+    from valle2_amd.modules import PositionalEncoding
+    from valle2_amd.utils import topk_sampling
+    gen = torch.Generator().manual_seed(3)
+    logits = 3 * torch.randn(5, 1025, generator=gen)
+    tok, lp = topk_sampling(logits, top_k=1)
+    assert not tok.is_cuda and not lp.is_cuda and tuple(tok.shape) == (5, 1) and tok.dtype == torch.int64
+    assert torch.equal(tok[:, 0], logits.argmax(-1)) and float(lp.abs().max()) == 0.0
+    t_dev, lp_dev = topk_sampling(logits.to(DEV), top_k=20, tok_p=0.9, temperature=0.8, seed=11)
+    t_cpu, lp_cpu = topk_sampling(logits, top_k=20, tok_p=0.9, temperature=0.8, seed=11)
+    assert torch.equal(t_dev.cpu(), t_cpu) and torch.equal(lp_dev.cpu(), lp_cpu)
+    pe = PositionalEncoding(128, dropout=0.0).eval()
+    x = torch.randn(3, 37, 128, generator=gen)
+    want = x + pe.pe[:37, 0]
+    assert torch.equal(pe(x), want)                                     # CPU module, CPU input: through the device mirror
+    assert torch.equal(pe.to(DEV)(x.to(DEV)).cpu(), want)
+    from valle2_amd._lib import VhError
+    with pytest.raises(VhError, match='max_len'):
+        PositionalEncoding(128, max_len=16).to(DEV)(x.to(DEV))

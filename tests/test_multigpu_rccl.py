@@ -29,6 +29,7 @@ def test_bench_small_two_gpus_spawns_its_own_ranks():
     assert len(lines) == 1, 'exactly one JSON line (rank 0)'
     res = lines[0]
     assert res['n_gpus'] == 2 and res['scaling'] == 'weak' and res['value'] > 0
+    assert res['rccl_ranks_seen'] == 2 and res['distributed']['backend'] == 'nccl'
     assert 'error' not in res.get('train', {}), res.get('train')
     assert res['train']['ar_allreduce_bytes'] > 0
 

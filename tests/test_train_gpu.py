@@ -394,6 +394,30 @@ def test_attn_rows_bwd_vs_torch_autograd(B, h, T, mode, form):
         _lib.lib().vh_set_tuning(13, 0)
 
 
+def test_attn_rows_bwd_row_without_valid_keys_leaves_zero_gradients():
+    """Round-4 advisor finding: a batch row with kv_len = 0 in a single-chunk launch (T <= 256: no slab, no reduce launch)
+    took the fused kernel's all-padding exit, which zeroed dK / dV but never wrote dQ — the row's dq slice kept whatever
+    the caller's torch.empty held.  It must be zero (no key is attended, nothing depends on q), and the other rows exact."""
+    from valle2_amd import kernels as K
+    B, h, T = 3, 2, 40
+    d = 64 * h
+    gen = torch.Generator().manual_seed(77)
+    q = torch.randn(B * T, d, generator=gen).to(DEV)
+    k = torch.randn(B, h, T, 64, generator=gen).to(DEV)
+    v = torch.randn(B, h, T, 64, generator=gen).to(DEV)
+    dout = torch.randn(B * T, d, generator=gen).to(DEV)
+    kvl = torch.tensor([T, 0, 17], dtype=torch.int32, device=DEV)
+    out = torch.empty(B * T, d, device=DEV)
+    lse2 = torch.empty(B, h, T, device=DEV)
+    K.attn_rows(q, k, v, out, B, h, T, T, lse2=lse2, mode=K.MASK_FULL, kv_len=kvl)
+    dqkv = torch.full((B * T, 3 * d), float('nan'), device=DEV)
+    K.attn_rows_bwd(q, k, v, out, dout, lse2, dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:], B, h, T, mode=K.MASK_FULL, kv_len=kvl)
+    row1 = dqkv.view(B, T, 3 * d)[1]
+    assert float(row1.abs().max()) == 0.0, 'the row without valid keys must get zero dq / dk / dv'
+    rest = dqkv.view(B, T, 3 * d)[[0, 2]]
+    assert bool(torch.isfinite(rest).all())
+
+
 def _attn_rows_bwd_vs_torch_autograd(B, h, T, mode):
     from oracle.valle_oracle import build_attn_mask
     from valle2_amd import kernels as K
@@ -646,3 +670,45 @@ def test_attn_rows_bwd_forms_agree_on_random_shapes():
         for r in res[1:]:
             assert torch.equal(torch.isfinite(r), ok), trial
             torch.testing.assert_close(r[ok], res[0][ok], atol=3e-5, rtol=1e-4, msg=lambda m: f'trial {trial} B={B} h={h} T={T} mode={mode}: {m}')
+
+
+@pytest.mark.parametrize('p', [0.0, 0.1])
+def test_a_gradient_hook_that_edits_a_layer_outputs_gradient_in_place_is_honoured(p):
+    """Round-4 advisor finding: a layer's backward re-used the pre-dropped copy of its incoming gradient and the column
+    sums the layer above had made of it whenever the data pointer matched — a tensor hook that scales the gradient IN PLACE
+    keeps the pointer.  The hand-over now also compares the version counter: an in-place hook, a hook that returns a new
+    tensor and no hook on a pre-scaled loss all give the same gradients (same seed: same dropout fields)."""
+    from valle2_amd import ConfigValle, autograd as A, dropout, get_model_class, synth
+    cfg = ConfigValle(d_model=128, n_heads=2, dim_feedforward=256, num_layers=3, dropout=p, norm='LayerNorm')
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=4, rich=True)
+    batch = synth.synth_ar_batch(cfg, 2, tok_range=(5, 9), code_range=(12, 20), seed=5)
+
+    def run(hook):
+        m = get_model_class('ValleAR')(cfg)
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        m.tokens_position_emb.dropout.p = m.audio_position_emb.dropout.p = 0.0
+        dropout.manual_seed(99)
+        A.LAYER_OUTPUT_HOOK = hook
+        try:
+            with torch.enable_grad():
+                m.training_step({k: v.clone() for k, v in batch.items()}).backward()
+        finally:
+            A.LAYER_OUTPUT_HOOK = None
+        return {n: q.grad.clone() for n, q in m.named_parameters()}
+
+    def in_place(i, g):
+        if i == 1:
+            g.mul_(0.5)                      # edits the tensor autograd hands on; returns None
+
+    def new_tensor(i, g):
+        return g * 0.5 if i == 1 else None
+
+    a, b = run(in_place), run(new_tensor)
+    base = run(None)
+    for n in a:
+        torch.testing.assert_close(a[n], b[n], atol=1e-7, rtol=1e-5, msg=lambda s, n=n: f'{n}: {s}')
+    changed = [n for n in a if 'layers.0.' in n and not torch.allclose(a[n], base[n], rtol=1e-3, atol=1e-9)]
+    assert changed, 'the hook must have changed the gradients below it'
+    top = [n for n in a if 'layers.2.' in n]
+    assert all(torch.equal(a[n], base[n]) for n in top), 'layers above the hook are untouched'

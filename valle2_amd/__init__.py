@@ -23,8 +23,17 @@ class _LazyModelDict(dict):
             self.update(_models())
             return self[key]
         if key == 'EncodecPip':
-            raise ImportError('EncodecPip wraps the third-party `encodec` package, which is outside '
-                              'the MI355X hot path; install the reference for it')
+            # valle/models/__init__.py:1,6 — resolved only when asked for: the adapter over the third-party codec when
+            # `encodec` is installed (valle2_amd/codec_io.py: layouts only, the codec computes), ImportError otherwise
+            try:
+                import encodec  # noqa: F401
+            except ImportError as e:
+                raise ImportError('EncodecPip wraps the third-party `encodec` package, which is not installed here '
+                                  '(pip install encodec==0.1.1); the token layouts it exchanges with the models are in '
+                                  'valle2_amd.codec_io') from e
+            from .codec_io import EncodecPip
+            self[key] = EncodecPip
+            return EncodecPip
         raise KeyError(key)
 
     def keys(self):

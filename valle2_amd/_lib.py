@@ -67,6 +67,22 @@ class VhForwardDesc(C.Structure):
     ]
 
 
+class VhLayer16(C.Structure):
+    """include/valle_hip.h vh_layer16: bf16 copies of a layer's four matrices + its bf16 K / V caches (perf mode)."""
+    _fields_ = [(n, C.c_void_p) for n in ('wqkv', 'wo', 'w1', 'w2', 'kcache16', 'vcache16')]
+
+
+class VhForward16Desc(C.Structure):
+    _fields_ = [
+        ('B', C.c_int), ('T', C.c_int), ('d_model', C.c_int), ('n_heads', C.c_int),
+        ('dff', C.c_int), ('n_layers', C.c_int), ('S_max', C.c_int), ('mode', C.c_int),
+        ('x_len', C.c_int), ('ln_eps', C.c_float),
+        ('layers', C.POINTER(VhLayer)), ('layers16', C.POINTER(VhLayer16)), ('ada', C.c_void_p),
+        ('x_len_dev', C.c_void_p), ('kv_len', C.c_void_p), ('x', C.c_void_p), ('x_in', C.c_void_p),
+        ('xn16', C.c_void_p), ('q16', C.c_void_p), ('attn16', C.c_void_p), ('hidden16', C.c_void_p),
+    ]
+
+
 # name → (restype, argtypes); must list every symbol include/valle_hip.h declares
 SIGNATURES = {
     'vh_version': (C.c_int, []),
@@ -77,6 +93,7 @@ SIGNATURES = {
                                   C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_i32p, c_dropp, C.c_void_p]),
     'vh_dropout': (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int, c_dropp, C.c_void_p]),
     'vh_dropout_mask': (C.c_int, [c_u8p, C.c_int64, C.c_int, c_dropp, C.c_void_p]),
+    'vh_add_pe': (C.c_int, [c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_layernorm': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int,
                                C.c_float, C.c_void_p]),
     'vh_linear': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int,
@@ -164,6 +181,16 @@ SIGNATURES = {
                                   C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_transformer_forward': (C.c_int, [C.POINTER(VhForwardDesc), C.c_void_p]),
+    'vh_to_bf16': (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    'vh_layernorm_bf16': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                    C.c_void_p]),
+    'vh_linear_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_linear_qkv_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, c_i32p,
+                                     C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'vh_attn_rows_bf16': (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, C.c_void_p]),
+    'vh_transformer_forward_bf16': (C.c_int, [C.POINTER(VhForward16Desc), C.c_void_p]),
 }
 
 _lib = None

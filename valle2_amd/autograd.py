@@ -462,8 +462,9 @@ class _StackPass:
       bias_ahead[l]  layer l+1's norm1 backward writes dx — the gradient of layer l's output — and accumulates its column
                      sums, which ARE the gradient of layer l's linear_2 bias, into that bias' gradient slot; layer l's
                      backward picks the tensor up here instead of launching a column-sum kernel.
-      dy_drop[l]     (dx, dx under layer l's dropout2 field) from the same launch: layer l's backward uses the dropped
-                     copy for the products of its FeedForward branch when the gradient it receives IS that dx."""
+      dy_drop[l]     (dx, dx under layer l's dropout2 field or None, dx's version counter) from the same launch: layer l's
+                     backward uses the dropped copy and the column sums above only when the gradient it receives IS that
+                     dx, unmodified (same storage, same version); otherwise it recomputes both."""
 
     def __init__(self, drops):
         self.drops = drops                 # dropout.StackDropout
@@ -537,9 +538,15 @@ class EncoderLayerFn(torch.autograd.Function):
         # above's norm1 backward next to dY itself; the top layer — or a dY autograd re-made — gets it from one launch here)
         ahead_dy = sp.dy_drop.pop(idx, None)
         db2 = sp.bias_ahead.pop(idx, None)                                 # the layer above summed (dropped) dY's columns already
+        # the hand-over holds only while the gradient received IS the dx the layer above wrote, UNCHANGED: same storage
+        # and same version counter — a tensor hook that scales or clips the layer output's gradient in place keeps the
+        # pointer but bumps the version (round-4 advisor finding), one that returns a new tensor changes the pointer
+        same = ahead_dy is not None and ahead_dy[0].data_ptr() == dy.data_ptr() and ahead_dy[0]._version == ahead_dy[2]
+        if ahead_dy is not None and not same:
+            db2 = None                                                     # (recomputed below, overwriting the stale sums)
         dyd = dy
         if dr2 is not None:
-            if ahead_dy is not None and ahead_dy[0].data_ptr() == dy.data_ptr():
+            if same and ahead_dy[1] is not None:
                 dyd = ahead_dy[1]
             else:
                 dyd = dropout.apply_raw(dy, dr2)
@@ -579,8 +586,8 @@ class EncoderLayerFn(torch.autograd.Function):
         dx, dg1, dbe1, dx_d = _ln_bwd(x, g1, be1, det(s1), dxn1, dxm, ahead, eps, dst1, drop=below_dr2)
         if ahead is not None:
             sp.bias_ahead[idx - 1] = ahead
-        if dx_d is not None:
-            sp.dy_drop[idx - 1] = (dx, dx_d)
+        if ahead is not None or dx_d is not None:
+            sp.dy_drop[idx - 1] = (dx, dx_d, dx._version)              # (dx, its dropped copy or None, dx's version now)
         dada = ada_grads if ctx.returns_ada else None            # the whole stack's buffer, complete once layer 0 is done
         return (dx, None, dwqkv, dwo, dbo, dg1, dbe1, dg2, dbe2, dw1, db1, dw2, db2, dada)
 
@@ -649,6 +656,11 @@ def _stack_transposes(transformer):
     return [tuple(outs[4 * i:4 * i + 4]) for i in range(len(layers))]
 
 
+# test hook: a callable (layer index, grad) -> grad | None registered as a tensor hook on every layer's output of the fused
+# stack (what a user's gradient-clipping / scaling hook on an intermediate activation would be)
+LAYER_OUTPUT_HOOK = None
+
+
 def transformer_train(transformer, x, B, T, spec, embedding=None):
     layers = list(transformer.layers)
     cfg = transformer.hparams
@@ -683,4 +695,6 @@ def transformer_train(transformer, x, B, T, spec, embedding=None):
         x = EncoderLayerFn.apply(x, meta, at.qkv.weight, at.out.weight, at.out.bias, n1.weight, n1.bias, n2.weight,
                                  n2.bias, ff.linear_1.weight, ff.linear_1.bias, ff.linear_2.weight, ff.linear_2.bias,
                                  ada_all if i == 0 else None)
+        if LAYER_OUTPUT_HOOK is not None and x.requires_grad:
+            x.register_hook(lambda g, i=i: LAYER_OUTPUT_HOOK(i, g))
     return x

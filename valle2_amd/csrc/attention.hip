@@ -1153,6 +1153,11 @@ __global__ __launch_bounds__(FW * 64, FW == 8 ? 1 : 2) void attn_bwd_fused_kerne
             st4(a.dk + o, f32x4{0.f, 0.f, 0.f, 0.f});
             st4(a.dv + o, f32x4{0.f, 0.f, 0.f, 0.f});
         }
+        // a single chunk writes dQ itself (no slab, no reduce launch): a row without any valid key (kv_len = 0, T <= 256)
+        // must leave zeros there, not the caller's uninitialised buffer (round-4 advisor finding)
+        if (a.slab == nullptr)
+            for (int row = sq; row < a.T; row += FW * 4)
+                st4(a.dq + ((int64_t)b * a.T + row) * a.ldg + head * HD + squad, f32x4{0.f, 0.f, 0.f, 0.f});
         return;
     }
     int qmin = 0;

@@ -87,6 +87,32 @@ extern "C" int vh_embed_sum_pe(const int64_t* ids, int64_t ids_bstride, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// out[b, t, :] = x[b, t, :] + pe[pos0 + t, :]: PositionalEncoding.forward called as a module (valle/models/modules.py:78-80);
+// the model paths add the position inside embed_sum_pe_kernel.  One float4 per thread.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_pe_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                     float* __restrict__ out, int64_t n4, int T, int d4, int pos0) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const int64_t row = i / d4;
+    const int c = (int)(i - row * d4), t = (int)(row % T);
+    st4(out + i * 4, ld4(x + i * 4) + ld4(pe + ((int64_t)(pos0 + t) * d4 + c) * 4));
+}
+
+extern "C" int vh_add_pe(const float* x, const float* pe, float* out, int B, int T, int d, int pos0, void* stream) {
+    VH_REQUIRE(x && pe && out, VH_EINVAL, "vh_add_pe: null pointer");
+    VH_REQUIRE(B >= 0 && T >= 0 && d > 0 && d % 4 == 0 && pos0 >= 0, VH_EINVAL, "vh_add_pe: bad dims B=%d T=%d d=%d pos0=%d", B, T,
+               d, pos0);
+    VH_REQUIRE(vh_aligned16(x) && vh_aligned16(pe) && vh_aligned16(out), VH_EALIGN, "vh_add_pe: pointers must be 16-byte aligned");
+    const int64_t n4 = (int64_t)B * T * (d / 4);
+    if (n4 == 0) return VH_OK;
+    hipLaunchKernelGGL(add_pe_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, pe, out, n4, T,
+                       d / 4, pos0);
+    VH_CHECK_LAUNCH("vh_add_pe");
+    return VH_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Free-standing dropout (a module-level nn.Dropout outside the fused training step) and the field itself.
 // One float4 per thread and Philox call; rows x cols/4 work items.
 // ---------------------------------------------------------------------------------------------

@@ -33,6 +33,18 @@ def init_distributed(backend: str | None = None, device: torch.device | None = N
     return rank, world
 
 
+def ranks_seen(device=None) -> dict:
+    """What the DEFAULT process group itself reports, for the benchmark's JSON line: its backend name, its world size,
+    and the result of a sum all-reduce of one 1 per rank on `device` through it — on the `nccl` backend that number is how
+    many ranks RCCL really connected (it comes from the collective, not from the environment).  One rank: no group."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {'backend': None, 'group_world_size': 1, 'allreduce_count': 1}
+    backend = dist.get_backend()
+    one = torch.ones(1, dtype=torch.float32, device=device if backend == 'nccl' else 'cpu')
+    dist.all_reduce(one)
+    return {'backend': backend, 'group_world_size': dist.get_world_size(), 'allreduce_count': int(one.item())}
+
+
 def shard_range(n_items: int, rank: int, world: int) -> range:
     """Contiguous, balanced shard of `n_items` independent utterances for `rank` (first
     n_items % world ranks get one more).  Shards are disjoint and cover range(n_items)."""
@@ -181,9 +193,11 @@ class GradReducer:
             rs = dist.reduce_scatter_tensor(mine, buf, op=dist.ReduceOp.SUM, async_op=True)
             if dist.get_backend() != 'nccl':
                 rs.wait()
-            self._work[b] = dist.all_gather_into_tensor(buf, mine, async_op=True)
+            # BOTH handles are kept and waited for in finish(): an error or a timeout of the reduce-scatter must surface
+            # there too, not only the gather's (round-4 advisor finding)
+            self._work[b] = (rs, dist.all_gather_into_tensor(buf, mine, async_op=True))
         else:
-            self._work[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+            self._work[b] = (dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True),)
 
     @property
     def launches_per_step(self):
@@ -212,8 +226,9 @@ class GradReducer:
         if self.active:
             for b in range(self._next, len(self.buckets)):
                 self._launch(b)
-            for w in self._work:
-                w.wait()
+            for works in self._work:
+                for w in works:
+                    w.wait()
         self._arrived = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._next = 0

@@ -42,6 +42,12 @@ def draw_seed() -> int:
     return int(torch.randint(0, 2 ** 62, (1,), generator=_state['generator']).item())
 
 
+def seed_if(*ps) -> int:
+    """A fresh seed when any of the probabilities `ps` is live, else 0 WITHOUT touching the generator: a forward with every
+    dropout off (eval mode, p = 0) must not advance the caller's CPU random stream."""
+    return draw_seed() if any(p > 0 for p in ps) else 0
+
+
 def site(kind: int, layer: int = 0) -> int:
     return (_state['rank'] << 48) | ((int(layer) & 0xFFFFFF) << 8) | (int(kind) & 0xFF)
 
@@ -122,8 +128,11 @@ class StackDropout:
     with its (rows, cols) so they can export the masks afterwards."""
 
     def __init__(self, layers, seed=None):
-        self.seed = draw_seed() if seed is None else int(seed)
         self.p = [(live(l.dropout1), live(l.ffn.dropout), live(l.dropout2)) for l in layers]
+        # a seed is drawn from torch's CPU generator only when some dropout is live: an eval-mode or p = 0 forward must not
+        # advance the user's CPU random stream (DataLoader shuffling, random_split ...) — the reference consumes no CPU
+        # randomness there (round-4 advisor finding)
+        self.seed = int(seed) if seed is not None else (draw_seed() if self.any else 0)
         for ps in self.p:
             if any(q >= 1.0 for q in ps):
                 raise _lib.VhError('dropout p = 1 is not supported on the fused training path')

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -69,13 +70,35 @@ FOLD_LAYERNORM = os.environ.get('VALLE2_FOLD_LN', '1') != '0'   # LayerNorm fold
 
 
 _WEIGHTS_EPOCH = 0
+# Derived weights (folded LayerNorm forms, AdaLN tables, bf16 copies) per Transformer module.  Kept HERE, not in the
+# module's __dict__: the entries hold weak references and device tensors that torch.save(model) must not try to pickle, and
+# an entry dies with its module.
+_DERIVED = weakref.WeakKeyDictionary()
+
+
+def _derived(module) -> dict:
+    d = _DERIVED.get(module)
+    if d is None:
+        d = _DERIVED[module] = {}
+    return d
 
 
 def bump_weights_epoch():
-    """Called by code that rewrites parameters behind torch's back (the flat optimizer kernel), so
-    that derived weights (the folded LayerNorm forms) are rebuilt."""
+    """Invalidate every derived weight form (folded LayerNorm weights, AdaLN tables, bf16 copies).  Called by code that
+    rewrites parameters behind torch's back (the flat optimizer kernel) — and the hook for USER code that does: the caches
+    are keyed on (tensor identity, `_version`, `data_ptr`), and a write through `p.data` (an EMA swap by
+    `p.data.copy_(...)`) moves none of them.  After such a write call this (or `invalidate_derived`)."""
     global _WEIGHTS_EPOCH
     _WEIGHTS_EPOCH += 1
+
+
+def invalidate_derived(module=None):
+    """Drop the derived weights of `module` (a Transformer), or of every module when None."""
+    if module is None:
+        _DERIVED.clear()
+        bump_weights_epoch()
+    else:
+        _DERIVED.pop(module, None)
 
 
 def folded_layer_norms(transformer):
@@ -90,14 +113,14 @@ def folded_layer_norms(transformer):
     srcs = [(l.norm1.weight, l.norm1.bias, l.self_attn.qkv.weight, l.norm2.weight, l.norm2.bias,
              l.ffn.linear_1.weight, l.ffn.linear_1.bias) for l in layers]
     key = (_WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version) for ps in srcs for t in ps)
-    cached = getattr(transformer, '_vh_folded', None)
+    cached = _derived(transformer).get('folded')
     if cached is not None and cached[0] == key:
         return cached[1]
     with torch.no_grad():
         folded = [(kernels.ln_fold(wq.detach(), g1.detach(), b1.detach()),
                    kernels.ln_fold(w1.detach(), g2.detach(), b2.detach(), bias1.detach()))
                   for g1, b1, wq, g2, b2, w1, bias1 in srcs]
-    transformer._vh_folded = (key, folded)
+    _derived(transformer)['folded'] = (key, folded)
     return folded
 
 
@@ -111,8 +134,9 @@ def layer_table(transformer, cache: KVCache, folded=None):
             if t.dtype != torch.float32:
                 raise _lib.VhError(f'parameter {name} of layer {i} is {t.dtype}; the path is fp32')
             setattr(arr[i], name, ptr(t.detach()))
-        arr[i].kcache = ptr(cache.k(i))
-        arr[i].vcache = ptr(cache.v(i))
+        if cache is not None:
+            arr[i].kcache = ptr(cache.k(i))
+            arr[i].vcache = ptr(cache.v(i))
         if folded is not None:
             (arr[i].wqkv_f, arr[i].qkv_c1, arr[i].qkv_c2), (arr[i].w1_f, arr[i].w1_c1, arr[i].w1_c2) = (
                 tuple(ptr(t) for t in folded[i][0]), tuple(ptr(t) for t in folded[i][1]))
@@ -129,14 +153,12 @@ def adaln_table(transformer, embedding):
     tensor's entry dies with it, and a recycled address can never alias a live entry) and reused while neither that
     tensor's version, nor any projection parameter's, nor the weights epoch (flat optimizer steps) has moved — the 7
     stages of ValleNAR.generate_batch build 7 tables once, not 7 per call."""
-    import weakref
-
     import numpy as np
     layers = list(transformer.layers)
     d = embedding.shape[-1]
     projs = [(n.project_layer.weight, n.project_layer.bias) for l in layers for n in (l.norm1, l.norm2)]
     n = len(projs)
-    state = transformer.__dict__.setdefault('_vh_ada', {'items': None, 'tables': []})
+    state = _derived(transformer).setdefault('ada', {'items': None, 'tables': []})
     pkey = (_WEIGHTS_EPOCH,) + tuple(x for w, b in projs for x in (w.data_ptr(), w._version, b.data_ptr(), b._version))
     for ref, ver, key, table in state['tables']:
         if ref() is embedding and ver == embedding._version and key == pkey and table.device == embedding.device:
@@ -160,6 +182,72 @@ def adaln_table(transformer, embedding):
     except TypeError:
         pass
     return table
+
+
+def bf16_weights(transformer):
+    """Per layer (Wqkv, Wo, W1, W2) as bf16 (vh_to_bf16, round to nearest even) for the perf-mode forward; built once per
+    weight set (same cache rule as `folded_layer_norms`)."""
+    layers = list(transformer.layers)
+    srcs = [(l.self_attn.qkv.weight, l.self_attn.out.weight, l.ffn.linear_1.weight, l.ffn.linear_2.weight) for l in layers]
+    key = (_WEIGHTS_EPOCH,) + tuple((t.data_ptr(), t._version) for ps in srcs for t in ps)
+    cached = _derived(transformer).get('bf16')
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.no_grad(), torch.inference_mode(False):
+        out = [tuple(kernels.to_bf16(t.detach()) for t in ps) for ps in srcs]
+    _derived(transformer)['bf16'] = (key, out)
+    return out
+
+
+class ForwardScratch16:
+    """bf16 activations of the perf-mode forward: xn, q, attn (rows, d) and hidden (rows, dff)."""
+
+    def __init__(self, rows, d, dff, device):
+        bf = dict(device=device, dtype=torch.bfloat16)
+        self.xn = torch.empty(rows, d, **bf)
+        self.q = torch.empty(rows, d, **bf)
+        self.attn = torch.empty(rows, d, **bf)
+        self.hidden = torch.empty(rows, dff, **bf)
+
+
+def perf_forward_supported(cfg):
+    """Shapes the bf16 tile kernels serve: d_model = n_heads x 64, d_model and dim_feedforward multiples of 128."""
+    return cfg.d_model == cfg.n_heads * HEAD_DIM and cfg.d_model % 128 == 0 and cfg.dim_feedforward % 128 == 0
+
+
+def transformer_forward_bf16(transformer, x, cache: 'KVCache', *, mode, x_len=0, x_len_dev=None, kv_len=None, embedding=None,
+                             scratch=None, x_in=None):
+    """`transformer_forward` in PERF MODE (SECONDARY): every product of the stack on the bf16 matrix
+    cores (bf16 operands, fp32 accumulators), residual stream x fp32 in place, K/V written to a bf16 cache.  Analytic
+    masks only.  Teacher-forced logits agree with the reference to 5e-2, not to the parity path's 2e-4."""
+    cfg = transformer.hparams
+    B, T, d = x.shape
+    if not x.is_contiguous() or x.dtype != torch.float32:
+        raise _lib.VhError('x must be contiguous fp32')
+    if not perf_forward_supported(cfg):
+        raise _lib.VhError(f'perf mode needs d_model = n_heads x 64 and d_model, dim_feedforward multiples of 128 '
+                           f'(got {cfg.d_model}, {cfg.n_heads}, {cfg.dim_feedforward})')
+    if cache is None or not cache.bf16 or cache.batch != B or cache.s_max < T or cache.n_layers != cfg.num_layers:
+        raise _lib.VhError('perf mode needs a bf16 KV cache that fits this forward')
+    scratch = scratch or ForwardScratch16(B * T, d, cfg.dim_feedforward, x.device)
+    w16 = bf16_weights(transformer)
+    table = layer_table(transformer, None)
+    t16 = (_lib.VhLayer16 * cfg.num_layers)()
+    for i, (wq, wo, w1, w2) in enumerate(w16):
+        t16[i].wqkv, t16[i].wo, t16[i].w1, t16[i].w2 = wq.data_ptr(), wo.data_ptr(), w1.data_ptr(), w2.data_ptr()
+        t16[i].kcache16, t16[i].vcache16 = cache.k(i).data_ptr(), cache.v(i).data_ptr()
+    ada = None
+    if cfg.norm != 'LayerNorm':
+        if embedding is None:
+            raise TypeError('AdaptiveLayerNorm needs `embedding` (reference: Linear(None) TypeError)')
+        ada = adaln_table(transformer, embedding)
+    desc = _lib.VhForward16Desc(
+        B=B, T=T, d_model=d, n_heads=cfg.n_heads, dff=cfg.dim_feedforward, n_layers=cfg.num_layers, S_max=cache.s_max,
+        mode=mode, x_len=int(x_len), ln_eps=1e-5, layers=table, layers16=t16, ada=ptr(ada), x_len_dev=ptr(x_len_dev),
+        kv_len=ptr(kv_len), x=ptr(x), x_in=ptr(x_in), xn16=scratch.xn.data_ptr(), q16=scratch.q.data_ptr(),
+        attn16=scratch.attn.data_ptr(), hidden16=scratch.hidden.data_ptr())
+    check(_lib.lib().vh_transformer_forward_bf16(C.byref(desc), stream()), 'vh_transformer_forward_bf16')
+    return x
 
 
 class ForwardScratch:

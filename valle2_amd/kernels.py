@@ -93,6 +93,17 @@ def _dev_f32(t, name):
     return _f32(t, name).data_ptr()
 
 
+def add_pe(x, pe, pos0=0):
+    """x (B, T, d) + pe[pos0 : pos0 + T] (pe (P, 1, d) or (P, d)) -> new tensor: PositionalEncoding.forward as a module call."""
+    B, T, d = x.shape
+    if pos0 + T > pe.shape[0] or pe.shape[-1] != d:
+        raise _lib.VhError(f'add_pe: positions {pos0}..{pos0 + T} / width {d} outside the table {tuple(pe.shape)}')
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    check(_lib.lib().vh_add_pe(_dev_f32(x, 'x'), ptr(_f32(pe, 'pe')), ptr(out), B, T, d, pos0, stream()), 'vh_add_pe')
+    return out
+
+
 def layernorm(x, gamma, beta, out=None, ada_scale=None, ada_shift=None, eps=1e-5):
     d = x.shape[-1]
     rows = x.numel() // d
@@ -375,6 +386,71 @@ def linear_qkv_folded_kv16(a, folded, q_out, kcache16, vcache16, n_heads, cache_
                                                q_out.stride(0), ptr(kcache16), ptr(vcache16), ptr(cache_len), B, d,
                                                n_heads, S_max, eps, stream()), 'vh_linear_qkv_folded_kv16')
     return q_out
+
+
+# ---- perf mode of the MFMA-bound legs: bf16 operands, fp32 accumulate (include/valle_hip.h; SECONDARY, never the parity path)
+def _bf16(t, name):
+    if t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(-1) != 1:
+        raise _lib.VhError(f'{name} must be a row-major bf16 HIP tensor, got {t.dtype} on {t.device}')
+    return t.data_ptr()
+
+
+def to_bf16(x, out=None):
+    """Round-to-nearest-even narrowing of a (rows, cols) fp32 matrix (vh_to_bf16): weights once per weight set."""
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, cols, device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().vh_to_bf16(_dev_f32(x, 'x'), x.stride(0), _bf16(out, 'out'), out.stride(0), rows, cols, stream()),
+          'vh_to_bf16')
+    return out
+
+
+def layernorm_bf16(x, gamma, beta, out=None, ada_scale=None, ada_shift=None, eps=1e-5):
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    check(_lib.lib().vh_layernorm_bf16(ptr(_f32(x, 'x')), ptr(gamma), ptr(beta), ptr(ada_scale), ptr(ada_shift),
+                                       _bf16(out, 'out'), rows, d, eps, stream()), 'vh_layernorm_bf16')
+    return out
+
+
+def linear_bf16(a, w, bias=None, residual=None, out=None, act=ACT_NONE, out_bf16=False):
+    """out = act(a @ w.T + bias) + residual with a (M,K), w (N,K) bf16; fp32 accumulate; out fp32 or bf16."""
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2 or not w.is_contiguous():
+        raise _lib.VhError(f'linear_bf16: K mismatch {K} vs {K2} / w must be contiguous')
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    if out.dtype != (torch.bfloat16 if out_bf16 else torch.float32) or out.stride(1) != 1:
+        raise _lib.VhError('linear_bf16: out dtype / layout')
+    check(_lib.lib().vh_linear_bf16(_bf16(a, 'a'), a.stride(0), _bf16(w, 'w'), ptr(bias),
+                                    _dev_f32(residual, 'residual') if residual is not None else None,
+                                    residual.stride(0) if residual is not None else 0, out.data_ptr(), out.stride(0),
+                                    int(out_bf16), M, N, K, act, stream()), 'vh_linear_bf16')
+    return out
+
+
+def linear_qkv_bf16(a, wqkv, q_out, kcache16, vcache16, B, T, n_heads, cache_len=None):
+    d = a.shape[1]
+    S_max = kcache16.shape[2]
+    if tuple(wqkv.shape) != (3 * d, d) or tuple(kcache16.shape) != (B, n_heads, S_max, HEAD_DIM) or a.shape[0] != B * T:
+        raise _lib.VhError('linear_qkv_bf16: shapes')
+    check(_lib.lib().vh_linear_qkv_bf16(_bf16(a, 'a'), a.stride(0), _bf16(wqkv, 'wqkv'), _bf16(q_out, 'q_out'),
+                                        q_out.stride(0), _bf16(kcache16, 'kcache'), _bf16(vcache16, 'vcache'), ptr(cache_len),
+                                        B, T, d, n_heads, S_max, stream()), 'vh_linear_qkv_bf16')
+    return q_out
+
+
+def attn_rows_bf16(q, kcache16, vcache16, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_dev=None, kv_len=None):
+    S_max = kcache16.shape[2]
+    if tuple(kcache16.shape) != (B, n_heads, S_max, HEAD_DIM) or Tk > S_max or Tq > Tk or q.shape[0] != B * Tq:
+        raise _lib.VhError(f'attn_rows_bf16: cache {tuple(kcache16.shape)} Tq={Tq} Tk={Tk}')
+    check(_lib.lib().vh_attn_rows_bf16(_bf16(q, 'q'), q.stride(0), _bf16(kcache16, 'kcache'), _bf16(vcache16, 'vcache'),
+                                       _bf16(out, 'out'), out.stride(0), B, n_heads, Tq, Tk, S_max, mode, x_len,
+                                       ptr(x_len_dev), ptr(kv_len), stream()), 'vh_attn_rows_bf16')
+    return out
 
 
 def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next,

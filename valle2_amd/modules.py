@@ -165,7 +165,7 @@ class PositionalEncoding(nn.Module):
         b, t, c = x.shape
         if t > self.pe.shape[0]:
             raise _lib.VhError(f'sequence length {t} exceeds max_len {self.pe.shape[0]}')
-        out = x + self.pe[:t, 0]          # plumbing-level add; the fused kernel is embed_sum_pe
+        out = kernels.add_pe(x.float(), self.pe)      # (the model paths fuse this add into embed_sum_pe)
         return _drop(self.dropout, out)
 
 

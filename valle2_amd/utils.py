@@ -48,8 +48,12 @@ def topk_sampling(logits: Tensor, top_k: int = 50, tok_p: float = 1.0, temperatu
     The random stream is the kernel's counter-based generator seeded from torch's RNG (or `seed`),
     not torch.multinomial's, so agreement with the reference is distributional."""
     from . import kernels
+    home = logits.device
     if not logits.is_cuda:
-        raise _lib.VhError('topk_sampling: logits must be on a HIP device (no CPU fallback)')
+        # host logits hop to the HIP device and the draw comes back, as every module does for host inputs
+        # (modules._on_device); without a device this raises VhError — there is no CPU sampler
+        _lib.lib()
+        logits = logits.to(torch.device('cuda', torch.cuda.current_device()))
     B, V = logits.shape
     dev = logits.device
     temperature = 1.0 if temperature is None else float(temperature)
@@ -69,7 +73,7 @@ def topk_sampling(logits: Tensor, top_k: int = 50, tok_p: float = 1.0, temperatu
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         kernels.sample_step(lg, V, -1, top_k, tok_p, temperature, seed, codes, state['eos_count'], lp, emb,
                             pe, state['audio_pos'], state['cache_len'], x)
-    return codes[:, 1:2].clone(), lp.to(logits.dtype)
+    return codes[:, 1:2].clone().to(home), lp.to(logits.dtype).to(home)
 
 
 def get_best_beam(x, sum_logprobs, stop_token, length_penalty=1.0):

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, dropout, kernels
-from .engine import ForwardScratch, KVCache, transformer_forward
+from .engine import ForwardScratch, ForwardScratch16, KVCache, transformer_forward, transformer_forward_bf16
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device
 from .valle_ar import _Base
 
@@ -78,10 +78,12 @@ class ValleNAR(_Base):
         return y, p
 
     @_on_device
-    def stage_logits(self, batch, stage: int):
+    def stage_logits(self, batch, stage: int, perf_mode: bool = False):
         """Intended forward of valle_nar.py:71-100 for `stage` in 1..Q-1: logits (B, T-prefix, V_a)
         of codebook `stage` for the non-prefix frames.  Full attention; key padding is dropped
-        exactly as the reference's Transformer does when attn_mask is None (defect D6)."""
+        exactly as the reference's Transformer does when attn_mask is None (defect D6).
+        perf_mode=True (opt-in, SECONDARY — SURVEY section 7): the stack's products run on the bf16 matrix cores
+        (engine.transformer_forward_bf16); logits agree with the reference to 5e-2, not to the parity path's 2e-4."""
         dev = self._dev()
         cfg = self.config
         tokens = kernels.ids_to_device(batch['tokens'], dev, cfg.vocab_size, 'tokens')
@@ -93,9 +95,14 @@ class ValleNAR(_Base):
         kernels.embed_sum_pe(tokens[:, :tx], [self.tokens_emb.weight.detach()],
                              self.tokens_position_emb.pe, 0, x)
         p = self._embed_audio(codes, stage, x, tx, self.audio_position_emb.pe)
-        cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev)
-        transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL,
-                            embedding=self.stage_embs[stage - 1].weight)      # (the parameter itself: adaln_table keys on it)
+        if perf_mode:
+            cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev, dtype=torch.bfloat16)
+            transformer_forward_bf16(self.transformer, x, cache, mode=kernels.MASK_FULL,
+                                     embedding=self.stage_embs[stage - 1].weight)
+        else:
+            cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev)
+            transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL,
+                                embedding=self.stage_embs[stage - 1].weight)  # (the parameter itself: adaln_table keys on it)
         z = x[:, tx + p:].reshape(b * (t - p), d)
         logits = kernels.linear(z, self.proj_layers[stage - 1].weight.detach())
         return logits.reshape(b, t - p, -1), p
@@ -116,7 +123,7 @@ class ValleNAR(_Base):
         # text | prefix frames (all codebooks) | target frames (codebooks < stage) written into ONE buffer; a codebook
         # table that two parts read receives one gradient (no torch.cat, no strided copies, no gradient adds); the PE
         # dropouts (p = 0.1 in train mode, D9) are fields applied by the gather kernel before it stores a row
-        seed = dropout.draw_seed()
+        seed = dropout.seed_if(dropout.live(self.tokens_position_emb.dropout), dropout.live(self.audio_position_emb.dropout))
         dr_t = dropout.spec(seed, dropout.site(dropout.PE_TEXT), dropout.live(self.tokens_position_emb.dropout))
         dr_a = dropout.spec(seed, dropout.site(dropout.PE_AUDIO), dropout.live(self.audio_position_emb.dropout))
         dropout.record('tokens_position_emb.dropout', dr_t, b * (tx + t), d)
@@ -167,7 +174,7 @@ class ValleNAR(_Base):
 
     @_on_device
     @torch.inference_mode()
-    def generate_batch(self, texts, prompt_codes, first_layers, greedy: bool = False, seed=None):
+    def generate_batch(self, texts, prompt_codes, first_layers, greedy: bool = False, seed=None, perf_mode: bool = False):
         """Batched NAR decoding of B independent utterances (extension; `generate` is built on it).
         texts[b]: 1-D int64 text ids (prompt + target text); prompt_codes[b]: (Tc_b, Q) int64 acoustic
         prompt; first_layers[b]: (Ty_b,) int64 first-codebook codes of the target (the AR model's
@@ -178,7 +185,9 @@ class ValleNAR(_Base):
         (valle_nar.py:142-160): the target frames carry sum_{j<n} codes_embs[j](out[j]) + PE, one stack
         forward with AdaLN on stage_embs[n-1], head proj_layers[n-1] on the target frames of all rows at
         once, and codebook n is drawn on the device by `vh_categorical_rows` (Categorical(logits /
-        temperature), or the arg-max when greedy)."""
+        temperature), or the arg-max when greedy).
+        perf_mode=True: the seven stack forwards on the bf16 matrix cores (see `stage_logits`); the drawn codes are then not
+        guaranteed to be the parity path's."""
         dev = self._dev()
         cfg = self.config
         q, d = cfg.num_quantizers, cfg.d_model
@@ -219,8 +228,9 @@ class ValleNAR(_Base):
         starts = [0]
         for ty in tys:
             starts.append(starts[-1] + ty)
-        cache = KVCache(cfg.num_layers, B, cfg.n_heads, total, dev)
-        scratch = ForwardScratch(B * total, d, cfg.dim_feedforward, dev)
+        cache = KVCache(cfg.num_layers, B, cfg.n_heads, total, dev, dtype=torch.bfloat16 if perf_mode else torch.float32)
+        scratch = (ForwardScratch16 if perf_mode else ForwardScratch)(B * total, d, cfg.dim_feedforward, dev)
+        forward = transformer_forward_bf16 if perf_mode else transformer_forward
         x = torch.empty_like(base)
         if seed is None:       # drawn from torch's generator, so torch.manual_seed() makes a run repeatable
             seed = 0 if greedy else int(torch.randint(0, 2 ** 62, (1,)).item())
@@ -229,8 +239,8 @@ class ValleNAR(_Base):
             x.copy_(base)
             kernels.embed_sum_pe(out, self._tables(n), pe_a, 0, x, lens=ty_d, row_pos0=tc_d, row_t0=t0_target,
                                  max_pos=max(tc + ty for tc, ty in zip(tcs, tys)))
-            transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
-                                embedding=self.stage_embs[n - 1].weight, scratch=scratch)    # (cached AdaLN table per stage)
+            forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
+                    embedding=self.stage_embs[n - 1].weight, scratch=scratch)                # (cached AdaLN table per stage)
             z = x.view(B * total, d).index_select(0, idx)                      # target frames of every row
             logits = kernels.linear(z, self.proj_layers[n - 1].weight.detach())
             kernels.categorical_rows(logits, toks, temperature=cfg.temperature, greedy=greedy, seed=seed,
