@@ -52,6 +52,7 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32 MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0 # bf16 MFMA DENSE peak (MI355X_MICROARCH.md: ~2.5 PF; the 5 PF headline figure is with 2:1 sparsity)
 
 AR = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm='LayerNorm',
           top_k=1, use_kv_cache=True)
@@ -408,7 +409,8 @@ def default_generate_leg(dev, sd, utt):
     dt = (time.perf_counter() - t0) / reps
     st = model.last_generate_stats
     steps = st['steps_run']
-    per_layer = 2 + (2 if st['n_split'] > 1 else 1) + (2 if st['ffn_fused'] else 3)
+    attn_launches = (2 + (1 if st['n_split'] > 1 else 0)) if st.get('shared_prompt') else (2 if st['n_split'] > 1 else 1)
+    per_layer = 2 + attn_launches + (2 if st['ffn_fused'] else 3)
     out = {'metric': 'generate(prompt_tokens, prompt_codes, target_tokens) at the reference generation defaults '
                      '(num_beams=4, top_k=50, tok_p=1.0, temperature=1.0, max_audio_len=1024), 12L/512d, '
                      f'{utt[0].numel() + utt[2].numel()} text + {utt[1].shape[0]} prompt frames',
@@ -417,8 +419,11 @@ def default_generate_leg(dev, sd, utt):
            'tokens_returned': int(toks.numel()), 'prefill_ms': st['prefill_ms'],
            'decode_us_per_step': st['decode_ms'] / max(1, steps - 1) * 1e3, 'n_split': st['n_split'],
            'launches_per_step': cfg.num_layers * per_layer + 2,
-           'launches': f'per layer: QKV, decode attention x{st["n_split"]} key splits'
-                       + (' + combine' if st['n_split'] > 1 else '') + ', out-projection, FeedForward '
+           'shared_prompt': bool(st.get('shared_prompt')),
+           'launches': 'per layer: QKV, '
+                       + (f'shared-prompt attention (prefix launch + suffix x{st["n_split"]} key splits'
+                          if st.get('shared_prompt') else f'decode attention (x{st["n_split"]} key splits')
+                       + (' + combine)' if st['n_split'] > 1 else ')') + ', out-projection, FeedForward '
                        + ('(one split launch + slab reduce)' if st['ffn_fused'] else '(linear_1, split-K linear_2, reduce)')
                        + '; + head + sample step'}
     del model
@@ -646,6 +651,7 @@ def main():
         x, y = text, frames + 1
         pairs = x * x + y * x + y * (y + 1) // 2                            # unmasked (query, key) pairs per row
         flop = 2.0 * cfg.num_layers * l_pl * rows * (x + y) + 4.0 * cfg.d_model * pairs * cfg.num_layers * rows
+        prefill_flop = flop
         tf = flop / (st['prefill_ms'] * 1e-3) / 1e12
         result['prefill'] = {'ms': st['prefill_ms'], 'flop': flop, 'tflops': tf, 'peak_tflops': MFMA_F32_PEAK_TF,
                              'frac': tf / MFMA_F32_PEAK_TF, 'bound': 'mfma', 'dtype': 'f32',
@@ -717,25 +723,48 @@ def main():
         result['roofline']['decode_algorithmic_bytes_total'] = 4.0 * sum(step_elems)
 
     if rank == 0 and world == 1 and not args.no_beams:       # secondary objects: the N = 1 line only (N > 1 measures scaling)
-        # the reference's own signature (valle_ar.py:136-138): ONE utterance, num_beams = 32 replicated rows, greedy;
-        # rows are never deduplicated, so this costs what the 32-distinct-utterances headline costs
-        log('beams: generate() of one utterance with num_beams=32')
+        # the reference's own signature (valle_ar.py:136-138): ONE utterance, num_beams = 32 replicated rows, greedy.  The
+        # beams share one prompt, so since round 5 generate() runs the prompt pass for ONE row and reads the prompt's K/V
+        # once per decode step for all beams (vh_attn_decode_shared); the beams themselves (their tokens, their own K/V rows,
+        # their scores) are never deduplicated.  `independent_rows`: the same call with the beams decoded as 32 independent
+        # rows (round 4's form, VALLE2_SHARED_PROMPT=0), which costs what the 32-distinct-utterances headline costs.
+        log('beams: generate() of one utterance with num_beams=32 (shared prompt K/V, and as independent rows)')
         utt0 = [u.to(dev) for u in utts[0]]              # inputs resident in HBM, as for the headline
-        model.generate(*utt0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
-            toks = model.generate(*utt0)
-        torch.cuda.synchronize()
-        dtb = (time.perf_counter() - t0) / reps
-        st_b = model.last_generate_stats
+        text0, first0 = torch.cat([utt0[0], utt0[2]]), utt0[1][:, 0]
+        legs = {}
+        for name, shared in (('shared', True), ('independent_rows', False)):
+            model.generate_batch([text0] * rows, [first0] * rows, shared_prompt=shared)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                toks_b = model.generate_batch([text0] * rows, [first0] * rows, shared_prompt=shared)
+            torch.cuda.synchronize()
+            legs[name] = ((time.perf_counter() - t0) / reps, dict(model.last_generate_stats), toks_b)
+        dtb, st_b, toks_b = legs['shared']
+        dti, st_i, toks_i = legs['independent_rows']
+        toks = model.generate(*utt0)                     # the reference's entry point itself (shared by default)
+        assert model.last_generate_stats['shared_prompt'] and torch.equal(toks, toks_b[0, frames + 1:])
+        # algorithmic bytes of the shared form's decode steps: weights + head + the prompt's K/V ONCE + every beam's own rows
+        s0_b = st_b['s0']
+        bytes_b = 4.0 * sum(cfg.num_layers * l_pl + (cfg.num_audio_tokens + 1) * cfg.d_model
+                            + 2 * cfg.num_layers * (s0_b + rows * t) * cfg.d_model
+                            + 2 * cfg.num_layers * rows * cfg.d_model for t in range(1, new))
+        gbs_b = bytes_b / (st_b['decode_ms'] * 1e-3) / 1e9
         result['beams'] = {'metric': 'acoustic tokens/sec, generate(prompt_tokens, prompt_codes, target_tokens) with '
-                                     f'num_beams={rows} (identical rows, not deduplicated)',
+                                     f'num_beams={rows} (one utterance: prompt K/V shared by the beams, beams not deduplicated)',
                            'value': rows * new / dtb, 'unit': 'tokens/s', 'ms_per_generate': dtb * 1e3,
                            'tokens_returned': int(toks.numel()), 'decode_ms': st_b['decode_ms'],
+                           'decode_us_per_step': st_b['decode_ms'] / (new - 1) * 1e3,
                            'prefill_ms': st_b['prefill_ms'],
-                           'vs_distinct_rows': (rows * new / dtb) / (value / world)}
+                           'algorithmic_bytes_total': bytes_b, 'bytes_rule': '4 (L P_L + V d + 2 L (S0 + B t) d + 2 L B d) per step',
+                           'achieved': gbs_b, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s', 'frac': gbs_b / HBM_PEAK_GBS,
+                           'vs_distinct_rows': (rows * new / dtb) / (value / world),
+                           'independent_rows': {'value': rows * new / dti, 'ms_per_generate': dti * 1e3,
+                                                'decode_us_per_step': st_i['decode_ms'] / (new - 1) * 1e3,
+                                                'prefill_ms': st_i['prefill_ms']},
+                           'shared_over_independent': dti / dtb,
+                           'same_tokens_as_independent_rows': bool(torch.equal(toks_b, toks_i))}
 
     if rank == 0 and world == 1 and not args.no_default_generate and not args.small:
         # what a user of the reference calls: generate() with the reference's OWN generation defaults (valle/config.py:
@@ -771,7 +800,15 @@ def main():
             'ms_per_generate': dtp * 1e3, 'decode_ms_per_step': st_p['decode_ms'] / (new - 1),
             'algorithmic_bytes_total': dec_bytes_p, 'achieved': gbs_p, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s',
             'frac': gbs_p / HBM_PEAK_GBS, 'vs_f32_headline': (rows * new / dtp) / (value / world),
-            'greedy_tokens_equal_to_f32_run': float((out_p == out).float().mean())}
+            'greedy_tokens_equal_to_f32_run': float((out_p == out).float().mean()),
+            # the prompt pass of this mode runs on the bf16 matrix cores (round 5): same flop count as `prefill`, priced
+            # against the bf16 dense peak of MI355X_MICROARCH.md (~2.5 PF/s; AMD's 5 PF figure is with 2:1 sparsity)
+            'prefill': {'storage': 'bf16 operands (weights narrowed once per weight set, activations in the producers\' epilogues), '
+                                   'fp32 accumulators, residual stream, LayerNorm statistics, softmax',
+                        'ms': st_p['prefill_ms'], 'prefill_bf16': bool(st_p.get('prefill_bf16')),
+                        'tflops': prefill_flop / (st_p['prefill_ms'] * 1e-3) / 1e12, 'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF,
+                        'frac_of_bf16_peak': prefill_flop / (st_p['prefill_ms'] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
+                        'vs_f32_prefill': st['prefill_ms'] / st_p['prefill_ms']}}
 
     if rank == 0 and world == 1 and not args.no_rows64 and not args.small:
         # A LABELLED SECONDARY line: the same fp32 generate with TWICE the rows BASELINE.json names (64 distinct utterances,
@@ -831,6 +868,21 @@ def main():
                          'value': NAR_B * s / t_stage, 'unit': 'tokens/s', 'ms_per_stage': t_stage * 1e3,
                          'tflops': flop / t_stage / 1e12, 'mfma_f32_peak_tflops': MFMA_F32_PEAK_TF,
                          'frac_of_mfma_peak': flop / t_stage / 1e12 / MFMA_F32_PEAK_TF}
+        if not args.no_perf_mode:
+            # the same stage forward in perf mode (SECONDARY, never the metric): bf16 operands on v_mfma_f32_32x32x16_bf16
+            nar.stage_logits(nb, 3, perf_mode=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(reps):
+                nar.stage_logits(nb, 1 + i, perf_mode=True)
+            torch.cuda.synchronize()
+            t16 = (time.perf_counter() - t0) / reps
+            result['nar']['perf_mode'] = {
+                'label': 'SECONDARY, not the metric: the stage forward with bf16 operands / fp32 accumulators (teacher-forced '
+                         'logits within atol 5e-2 of the reference: tests/test_bf16_gpu.py)',
+                'value': NAR_B * s / t16, 'unit': 'tokens/s', 'ms_per_stage': t16 * 1e3, 'tflops': flop / t16 / 1e12,
+                'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF, 'frac_of_bf16_peak': flop / t16 / 1e12 / MFMA_BF16_PEAK_TF,
+                'vs_f32_stage': t_stage / t16}
         del nar, nb
 
     if not args.no_train:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 120            /* 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 121            /* 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -282,6 +282,21 @@ size_t vh_attn_decode_ws_bytes(int B, int n_heads, int n_split);
 int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vcache, float* out,
                    int ldo, const int32_t* cache_len, int len_bias, int B, int n_heads, int S_max,
                    int n_split, void* partial, void* stream);
+/* ---- decode attention over a shared prompt (the beams of ONE utterance) ------------------------------------------
+ * replaces the same SDPA (valle/models/modules.py:167) for generate()'s num_beams rows, whose first prefix_len keys are the
+ * same bits in every row (valle_ar.py:135-138 replicates one utterance): kprefix / vprefix (1, h, prefix_S, 64) are read
+ * once per step for all B beams (a beam is a lane of the score tile), ksuffix / vsuffix (B, h, S_suf, 64) hold each
+ * beam's generated rows, suffix_len[b] + len_bias of them attended.  Bytes per call: 2 (prefix_len + sum_b suffix) 64 h 4
+ * instead of 2 B (prefix_len + suffix) 64 h 4.  One launch over the prefix (a record per (beam, head, key chunk)), one over
+ * the suffixes that also merges the records when n_split_suffix == 1 (else a third launch merges).  fp32, deterministic
+ * (records are merged in chunk order); results differ from vh_attn_decode's by summation order only.
+ * partial: vh_attn_decode_shared_ws_bytes() bytes, no initialisation needed. */
+size_t vh_attn_decode_shared_ws_bytes(int B, int n_heads, int prefix_len, int n_split_suffix);
+int vh_attn_decode_shared(const float* q, int ldq, const float* kprefix, const float* vprefix, int prefix_len,
+                          int prefix_S, const float* ksuffix, const float* vsuffix, float* out, int ldo,
+                          const int32_t* suffix_len, int len_bias, int B, int n_heads, int S_suf, int n_split_suffix,
+                          void* partial, size_t partial_bytes, void* stream);
+
 /* ---- perf mode of the decode step: bf16 K/V cache (opt-in; never the parity path) ---------------
  * SURVEY.md section 7's "perf mode": the K/V cache — 93 % of the bytes a decode step reads at configs[1] — stored
  * as bf16 (B, h, S_max, 64), everything else (weights, q, softmax, accumulators, residual stream) fp32 as in the parity
@@ -337,6 +352,9 @@ typedef struct {
     /* optional vh_ln_fold outputs for (ln1, wqkv) and (ln2, w1, b1); all NULL → LayerNorm applied in
      * the operand load from ln*_g / ln*_b.  Used by the decode step only. */
     const float *wqkv_f, *qkv_c1, *qkv_c2, *w1_f, *w1_c1, *w1_c2;
+    /* shared-prompt decoding (vh_ar_decoder_desc.prefix_len > 0): this layer's prompt K / V, (1, h, prefix_S, 64), written
+     * once by a one-row prompt pass and read by every beam; kcache / vcache then hold only the beams' generated rows */
+    const float *kprefix, *vprefix;
 } vh_layer;
 
 typedef struct {
@@ -366,6 +384,14 @@ typedef struct {
     /* perf mode (opt-in): nonzero = every layer's kcache / vcache point at bf16 caches (B,h,S_max,64) and the step
      * runs vh_linear_qkv_folded_kv16 + vh_attn_decode_kv16; needs folded weights in every layer and n_split == 1. */
     int kv_bf16;
+    /* shared prompt (the reference's generate(): ONE utterance replicated over num_beams rows, valle_ar.py:135-138 — every
+     * beam's prompt K/V is the same bits).  prefix_len > 0: the first prefix_len keys of every row live ONCE in
+     * layers[i].kprefix / vprefix ((1, h, prefix_S, 64)); layers[i].kcache / vcache are (B, h, S_max, 64) caches of the
+     * GENERATED rows only, cache_len[b] counts those, and the step's attention is vh_attn_decode_shared (n_split = key
+     * splits of the suffix part).  attn_partial must hold vh_attn_decode_shared_ws_bytes(B, n_heads, prefix_len, n_split)
+     * bytes (attn_partial_bytes says how many it holds).  Not with kv_bf16. */
+    int prefix_len, prefix_S;
+    size_t attn_partial_bytes;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

@@ -625,6 +625,46 @@ def test_attn_decode_long_context(K, form, S):
     close(out, ref, atol=2e-5)
 
 
+@pytest.mark.parametrize('B,h,prefix_len,n_split', [(32, 8, 1024, 1), (4, 8, 1024, 8), (8, 16, 626, 2), (40, 2, 31, 1),
+                                                    (64, 4, 1, 1), (3, 2, 2651, 3), (33, 8, 100, 1), (8, 16, 2907, 2)])
+def test_attn_decode_shared_prompt(K, B, h, prefix_len, n_split):
+    """vh_attn_decode_shared: B beams over ONE shared prompt (read once for all beams: a beam is a lane of the score tile) +
+    each beam's own rows, against double-precision attention over the concatenated keys; ragged suffix lengths (one beam
+    with a single own row), NaN / Inf in the prefix cache beyond prefix_len and in the suffix caches beyond every beam's
+    length, beams beyond 32 (second pass of the prefix kernel), key splits of the suffix with the combine launch."""
+    d = 64 * h
+    S_suf = 96
+    prefix_S = (prefix_len + 31) // 32 * 32 + 32
+    gen = g(500 + prefix_len + B)
+    q = torch.randn(B, d, generator=gen)
+    kp = torch.randn(1, h, prefix_S, 64, generator=gen)
+    vp = torch.randn(1, h, prefix_S, 64, generator=gen)
+    ks = torch.randn(B, h, S_suf, 64, generator=gen)
+    vs = torch.randn(B, h, S_suf, 64, generator=gen)
+    slen = torch.tensor([(7 * i) % 90 for i in range(B)], dtype=torch.int32)          # rows in the suffix BEFORE the new one
+    ref = torch.empty(B, d)
+    for b in range(B):
+        n = int(slen[b]) + 1
+        kk = torch.cat([kp[0, :, :prefix_len], ks[b, :, :n]], dim=1).double()
+        vv = torch.cat([vp[0, :, :prefix_len], vs[b, :, :n]], dim=1).double()
+        s = (q[b].double().view(h, 1, 64) @ kk.transpose(-1, -2)) / 8.0
+        ref[b] = (torch.softmax(s, dim=-1) @ vv).reshape(d).float()
+        ks[b, :, n:] = float('nan')
+        vs[b, :, n:] = float('inf')
+    kp[:, :, prefix_len:] = float('nan')
+    vp[:, :, prefix_len:] = float('inf')
+    out = torch.full((B, d), float('nan'), device=DEV)
+    K.attn_decode_shared(q.to(DEV), kp.to(DEV), vp.to(DEV), prefix_len, ks.to(DEV), vs.to(DEV), out, slen.to(DEV), 1,
+                         n_split=n_split)
+    assert bool(torch.isfinite(out).all()), 'garbage beyond a length leaked into the attention output'
+    close(out, ref, atol=2e-5)
+    # deterministic: records are merged in chunk order
+    out2 = torch.empty_like(out)
+    K.attn_decode_shared(q.to(DEV), kp.to(DEV), vp.to(DEV), prefix_len, ks.to(DEV), vs.to(DEV), out2, slen.to(DEV), 1,
+                         n_split=n_split)
+    assert torch.equal(out, out2)
+
+
 def test_linear_qkv_scatter(K):
     B, T, h = 3, 5, 2
     d = 64 * h

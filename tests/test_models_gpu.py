@@ -473,3 +473,57 @@ def test_host_logits_and_module_level_positional_encoding_run_on_the_device():
     from valle2_amd._lib import VhError
     with pytest.raises(VhError, match='max_len'):
         PositionalEncoding(128, max_len=16).to(DEV)(x.to(DEV))
+
+
+@pytest.mark.parametrize('which', ['tiny', 'mid', 'eos'])
+def test_generate_with_a_shared_prompt_matches_the_reference_and_the_independent_rows(which):
+    """generate() replicates one utterance over its beams (valle_ar.py:135-138), so the prompt pass runs
+    for ONE row and every decode step reads the prompt's K/V once for all beams (vh_attn_decode_shared).  Tokens: the REAL
+    reference's (goldens), and the same as decoding the beams as independent rows; graph and eager; EOS stop included."""
+    gold = load_golden({'tiny': 'ar_generate_tiny', 'mid': 'ar_generate_mid', 'eos': 'ar_generate_eos'}[which])
+    kw, sd, utt = C.ar_generate_inputs(which) if which != 'eos' else C.ar_eos_inputs(gold['eos_row'])
+    m = build('ValleAR', kw, sd)
+    beams = kw['num_beams']
+    text = torch.cat([utt[0], utt[2]]).to(DEV)
+    first = utt[1][:, 0].to(DEV)
+    outs = {}
+    for shared in (True, False):
+        for graph in (True, False):
+            rows = m.generate_batch([text] * beams, [first] * beams, shared_prompt=shared, use_graph=graph)
+            assert m.last_generate_stats['shared_prompt'] == shared
+            outs[shared, graph] = rows.cpu()
+    n = utt[1].shape[0] + 1
+    for key, rows in outs.items():
+        assert bool((rows == rows[:1]).all()), f'{key}: identical beams must decode identical tokens under top_k = 1'
+        got = rows[0, n:]
+        got = got[got != m.eos_token]
+        if which == 'eos':
+            assert torch.equal(got, gold['tokens']), key
+        else:
+            tokens_match(got, gold['tokens'], gold['margin'])
+    out = m.generate(*[u.to(DEV) for u in utt])                          # the reference's own entry point: shared by default
+    assert m.last_generate_stats['shared_prompt']
+    if which == 'eos':
+        assert torch.equal(out.cpu(), gold['tokens'])
+    else:
+        tokens_match(out, gold['tokens'], gold['margin'])
+    with pytest.raises(ValueError, match='same text and prompt'):
+        m.generate_batch([text, text.flip(0)], [first, first], shared_prompt=True)
+
+
+def test_shared_prompt_sampling_beams_diverge_and_scores_are_per_beam():
+    """Default sampling (top_k = 50): beams share the prompt's K/V but draw their own tokens — rows differ, every row's
+    sum of log-probabilities is its own, and a fixed torch seed reproduces the run."""
+    kw = dict(C.AR_TINY, top_k=50, num_beams=4, max_audio_len=24)
+    _, sd, utt = C.ar_generate_inputs('tiny')
+    m = build('ValleAR', kw, sd)
+    text = torch.cat([utt[0], utt[2]]).to(DEV)
+    first = utt[1][:, 0].to(DEV)
+    torch.manual_seed(5)
+    a = m.generate_batch([text] * 4, [first] * 4, shared_prompt=True)
+    lp_a = m.last_generate_stats['sum_logprobs'].clone()
+    torch.manual_seed(5)
+    b = m.generate_batch([text] * 4, [first] * 4, shared_prompt=True)
+    assert torch.equal(a, b) and torch.equal(lp_a, m.last_generate_stats['sum_logprobs'])
+    assert len({tuple(r.tolist()) for r in a.cpu()}) > 1, 'sampled beams must not be copies of each other'
+    assert len(set(lp_a.cpu().tolist())) > 1 and bool((lp_a < 0).all())

@@ -711,4 +711,5 @@ def test_a_gradient_hook_that_edits_a_layer_outputs_gradient_in_place_is_honoure
     changed = [n for n in a if 'layers.0.' in n and not torch.allclose(a[n], base[n], rtol=1e-3, atol=1e-9)]
     assert changed, 'the hook must have changed the gradients below it'
     top = [n for n in a if 'layers.2.' in n]
-    assert all(torch.equal(a[n], base[n]) for n in top), 'layers above the hook are untouched'
+    # (compared to rounding: the LayerNorm backward's column sums are fp32 atomics, not bit-reproducible run to run)
+    assert all(torch.allclose(a[n], base[n], rtol=1e-5, atol=1e-8) for n in top), 'layers above the hook are untouched'

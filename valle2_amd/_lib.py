@@ -35,7 +35,7 @@ c_dropp = C.POINTER(VhDropoutSpec)
 class VhLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'ln1_g', 'ln1_b', 'wqkv', 'wo', 'bo', 'ln2_g', 'ln2_b', 'w1', 'b1', 'w2', 'b2',
-        'kcache', 'vcache', 'wqkv_f', 'qkv_c1', 'qkv_c2', 'w1_f', 'w1_c1', 'w1_c2')]
+        'kcache', 'vcache', 'wqkv_f', 'qkv_c1', 'qkv_c2', 'w1_f', 'w1_c1', 'w1_c2', 'kprefix', 'vprefix')]
 
 
 class VhArDecoderDesc(C.Structure):
@@ -52,6 +52,7 @@ class VhArDecoderDesc(C.Structure):
         ('pos_base', C.c_void_p), ('codes', C.c_void_p), ('codes_stride', C.c_int64),
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t), ('kv_bf16', C.c_int),
+        ('prefix_len', C.c_int), ('prefix_S', C.c_int), ('attn_partial_bytes', C.c_size_t),
     ]
 
 
@@ -135,6 +136,9 @@ SIGNATURES = {
     'vh_attn_decode_kv16': (C.c_int, [c_f32p, C.c_int, C.c_void_p, C.c_void_p, c_f32p, C.c_int, c_i32p, C.c_int, C.c_int,
                                       C.c_int, C.c_int, C.c_void_p]),
     'vh_attn_decode_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'vh_attn_decode_shared_ws_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    'vh_attn_decode_shared': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int,
+                                        c_i32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
     'vh_attn_decode': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, c_i32p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,

@@ -1551,3 +1551,265 @@ extern "C" int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache,
     VH_CHECK_LAUNCH("vh_attn_rows_bwd_ws");
     return VH_OK;
 }
+
+// =============================================================================================
+// Decode attention over a SHARED PROMPT (round 5): the reference's own generate() replicates ONE utterance over
+// num_beams rows (valle/models/valle_ar.py:135-138), so every beam's prompt K/V is the same bits.  Here the prompt K/V
+// ("prefix": (1, h, prefix_S, 64) per layer, written once by a one-row prompt pass) is read ONCE per step for all beams
+// and every beam keeps only its own generated rows ("suffix": (B, h, S_suf, 64)).  Bytes per step and layer:
+// 2 (S0 + B t) d instead of 2 B (S0 + t) d.
+//   attn_prefix_kernel   one wave per (key chunk, head): S^T = K Q^T for ALL beams at once — beams are the 32 lanes of a
+//                        32x32x2 MFMA tile (a second pass for beams 32..63) — softmax statistics and the unnormalised
+//                        O^T = V^T P^T of the chunk, written as one split record per (beam, head, chunk);
+//   attn_suffix_kernel   the burst kernel over a beam's own rows; with one suffix split it merges the prefix records of its
+//                        (beam, head) in chunk order and writes the output, else it adds its record and
+//                        attn_decode_combine_kernel merges all of them.
+// Record format and units as the key-split decode kernels' (PART_LD floats: o[64], m, l; scores scaled by log2 e / 8).
+// =============================================================================================
+struct PrefixArgs {
+    const float* q; int ldq;
+    const float* kp; const float* vp;
+    int prefix_len, prefix_S;
+    float* partial;
+    int n_heads, B, n_tot, blocks_per_chunk;
+};
+
+__global__ __launch_bounds__(64) void attn_prefix_kernel(PrefixArgs a) {
+    const int chunk = blockIdx.x, head = blockIdx.y;
+    const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+    const float* kb = a.kp + (int64_t)head * a.prefix_S * HD;
+    const float* vb = a.vp + (int64_t)head * a.prefix_S * HD;
+    const int key_begin = chunk * a.blocks_per_chunk * 32;
+    const int key_end = min(a.prefix_len, key_begin + a.blocks_per_chunk * 32);
+    const float qscale = 0.125f * LOG2E;
+    for (int qb = 0; qb * 32 < a.B; ++qb) {
+        const int b = min(qb * 32 + r, a.B - 1);             // lanes beyond B repeat the last beam (never stored)
+        // Q^T fragment (B operand): lane (r, hh) holds q[beam r][d = 32 hh + j], j = 0..31 — the k index of the product
+        // is only summed over, so both operands simply use the same d per (hh, j)
+        f32x4 qf[8];
+        {
+            const float* qr = a.q + (int64_t)b * a.ldq + head * HD + 32 * hh;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[j] = ld4(qr + 4 * j) * qscale;
+        }
+        float m = NEG_INF, l = 0.f;
+        f32x16 oacc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
+        for (int k0 = key_begin; k0 < key_end; k0 += 32) {
+            // K fragment (A operand): key k0 + r, d = 32 hh + j; rows beyond the prompt repeat its last row (masked below)
+            f32x4 kf[8];
+            {
+                const float* kr = kb + (int64_t)min(k0 + r, a.prefix_len - 1) * HD + 32 * hh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kf[j] = ld4(kr + 4 * j);
+            }
+            f32x16 s;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].x, qf[j].x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].y, qf[j].y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].z, qf[j].z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].w, qf[j].w, s, 0, 0, 0);
+            }
+            // D reg x of lane (r = beam, hh): key k0 + (x & 3) + 8 (x >> 2) + 4 hh
+            float cmax = NEG_INF;
+            const bool whole = k0 + 32 <= a.prefix_len;                        // wave-uniform
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                if (!whole && k0 + (x & 3) + 8 * (x >> 2) + 4 * hh >= a.prefix_len) s[x] = NEG_INF;
+                cmax = fmaxf(cmax, s[x]);
+            }
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));                    // the beam's other key half
+            const float m_new = fmaxf(m, cmax);                               // finite: key k0 < prefix_len is in the block
+            const float alpha = vh_exp2(m - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                s[x] = vh_exp2(s[x] - m_new);
+                psum += s[x];
+            }
+            l = l * alpha + psum;
+            m = m_new;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
+            // O^T += V^T P^T: product x pairs key base(x) (lanes hh = 0) with base(x) + 4 (lanes hh = 1) — exactly the keys
+            // whose weights sit in accumulator register x of the two lane halves, so P^T is the B operand as it lies
+#pragma unroll
+            for (int x = 0; x < 16; ++x) {
+                const int key = min(k0 + (x & 3) + 8 * (x >> 2) + 4 * hh, a.prefix_len - 1);
+                const float* vr = vb + (int64_t)key * HD + r;
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[x], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[x], oacc[1], 0, 0, 0);
+            }
+        }
+        const float l_tot = l + __shfl_xor(l, 32, 64);
+        if (qb * 32 + r < a.B) {
+            float* pr = a.partial + (((int64_t)b * a.n_heads + head) * a.n_tot + chunk) * PART_LD;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4)
+                    st4(pr + 32 * db + 8 * g4 + 4 * hh,
+                        f32x4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]});
+            if (hh == 0) { pr[HD] = m; pr[HD + 1] = l_tot; }
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_suffix_kernel(
+    const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc,
+    float* __restrict__ out, int ldo, const int32_t* __restrict__ suffix_len, int len_bias, int n_heads, int S_suf,
+    int n_split, int n_prefix, float* __restrict__ partial) {
+    __shared__ float s_m[NW], s_l[NW];
+    __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
+    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
+    const int split = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c16 = lane & 15, g = lane >> 4;
+    const int len = suffix_len[b] + len_bias;
+    const int nchunks = (len + 31) >> 5;
+    const int cps = (nchunks + n_split - 1) / n_split;
+    const int c_begin = split * cps, c_end = min(nchunks, c_begin + cps);
+    const float qscale = 0.125f * LOG2E;
+    const f32x4 q4 = ld4(q + (int64_t)b * ldq + head * HD + 4 * c16) * qscale;
+    const float* kb = kc + (int64_t)bh * S_suf * HD + 4 * c16;
+    const float* vb = vc + (int64_t)bh * S_suf * HD + 4 * c16;
+    float m = NEG_INF, l = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = c_begin + w; c < c_end; c += NW) {
+        const int key0 = c * 32 + g;
+        f32x4 kf[8], vf[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int key = key0 + 4 * i;
+            const bool in = key < len;
+            kf[i] = in ? ld4(kb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+            vf[i] = in ? ld4(vb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        float s[8];
+        float cmax = NEG_INF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 t = kf[i] * q4;
+            const float d = row16_sum((t.x + t.y) + (t.z + t.w));
+            s[i] = (key0 + 4 * i < len) ? d : NEG_INF;
+            cmax = fmaxf(cmax, s[i]);
+        }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float m_new = fmaxf(m, cmax);
+        const float alpha = vh_exp2(m - m_new);
+        o *= alpha;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float p = vh_exp2(s[i] - m_new);
+            l += p;
+            o += vf[i] * p;
+        }
+        m = m_new;
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        o.x += __shfl_xor(o.x, sh, 64); o.y += __shfl_xor(o.y, sh, 64);
+        o.z += __shfl_xor(o.z, sh, 64); o.w += __shfl_xor(o.w, sh, 64);
+        l += __shfl_xor(l, sh, 64);
+    }
+    if (lane < 16) st4(&s_o[w][4 * c16], o);
+    if (lane == 0) { s_m[w] = m; s_l[w] = l; }
+    __syncthreads();
+    if (tid >= HD) return;
+    float M = s_m[0];
+#pragma unroll
+    for (int k = 1; k < NW; ++k) M = fmaxf(M, s_m[k]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+        const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);      // (a wave without a chunk; M itself is -inf
+        L += s_l[k] * wgt;                                                    //  only for an empty split of a split launch)
+        O += s_o[k][tid] * wgt;
+    }
+    const int n_tot = n_prefix + n_split;
+    float* pr = partial + (int64_t)bh * n_tot * PART_LD;
+    if (n_split > 1) {                       // the record joins the prefix records; attn_decode_combine_kernel merges all
+        pr[(n_prefix + split) * PART_LD + tid] = O;
+        if (tid == 0) { pr[(n_prefix + split) * PART_LD + HD] = M; pr[(n_prefix + split) * PART_LD + HD + 1] = L; }
+        return;
+    }
+    // one suffix split: merge the prefix records of this (beam, head) in chunk order, then the beam's own rows
+    float Mx = M;
+    for (int k = 0; k < n_prefix; ++k) Mx = fmaxf(Mx, pr[k * PART_LD + HD]);
+    float Lx = 0.f, Ox = 0.f;
+    for (int k = 0; k < n_prefix; ++k) {
+        const float wgt = vh_exp2(pr[k * PART_LD + HD] - Mx);
+        Lx += pr[k * PART_LD + HD + 1] * wgt;
+        Ox += pr[k * PART_LD + tid] * wgt;
+    }
+    const float wgt = M == NEG_INF ? 0.f : vh_exp2(M - Mx);
+    Lx += L * wgt;
+    Ox += O * wgt;
+    out[(int64_t)b * ldo + head * HD + tid] = Ox / Lx;
+}
+
+// key chunks of the prefix: 32-key blocks dealt to at most ~512 / n_heads workgroups per head (one wave each)
+static int prefix_chunks(int prefix_len, int n_heads, int* blocks_per_chunk) {
+    const int blocks = (prefix_len + 31) / 32;
+    const int target = max(1, min(64, 512 / max(n_heads, 1)));
+    const int bpc = (blocks + target - 1) / target;
+    *blocks_per_chunk = bpc;
+    return (blocks + bpc - 1) / bpc;
+}
+
+extern "C" size_t vh_attn_decode_shared_ws_bytes(int B, int n_heads, int prefix_len, int n_split_suffix) {
+    if (B <= 0 || n_heads <= 0 || prefix_len <= 0 || n_split_suffix < 1) return 0;
+    int bpc;
+    const int n_tot = prefix_chunks(prefix_len, n_heads, &bpc) + n_split_suffix;
+    return (size_t)B * n_heads * n_tot * PART_LD * sizeof(float);
+}
+
+extern "C" int vh_attn_decode_shared(const float* q, int ldq, const float* kprefix, const float* vprefix, int prefix_len,
+                                     int prefix_S, const float* ksuffix, const float* vsuffix, float* out, int ldo,
+                                     const int32_t* suffix_len, int len_bias, int B, int n_heads, int S_suf,
+                                     int n_split_suffix, void* partial, size_t partial_bytes, void* stream) {
+    VH_REQUIRE(q && kprefix && vprefix && ksuffix && vsuffix && out && suffix_len && partial, VH_EINVAL,
+               "vh_attn_decode_shared: null pointer");
+    VH_REQUIRE(B > 0 && B <= 64 && n_heads > 0 && prefix_len > 0 && prefix_len <= prefix_S && S_suf > 0 &&
+                   n_split_suffix >= 1 && n_split_suffix <= 64, VH_EINVAL,
+               "vh_attn_decode_shared: bad dims B=%d h=%d prefix=%d/%d S_suf=%d n_split=%d", B, n_heads, prefix_len, prefix_S,
+               S_suf, n_split_suffix);
+    VH_REQUIRE(len_bias == 0 || len_bias == 1, VH_EINVAL, "vh_attn_decode_shared: len_bias=%d", len_bias);
+    VH_REQUIRE(ldq % 4 == 0 && ldq >= n_heads * HD && ldo >= n_heads * HD, VH_EINVAL, "vh_attn_decode_shared: ldq=%d ldo=%d", ldq, ldo);
+    VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kprefix) && vh_aligned16(vprefix) && vh_aligned16(ksuffix) &&
+                   vh_aligned16(vsuffix) && vh_aligned16(partial), VH_EALIGN, "vh_attn_decode_shared: pointers must be 16-byte aligned");
+    VH_REQUIRE(partial_bytes >= vh_attn_decode_shared_ws_bytes(B, n_heads, prefix_len, n_split_suffix), VH_EINVAL,
+               "vh_attn_decode_shared: workspace of %zu bytes, need %zu", partial_bytes,
+               vh_attn_decode_shared_ws_bytes(B, n_heads, prefix_len, n_split_suffix));
+    hipStream_t s = (hipStream_t)stream;
+    int bpc;
+    const int n_prefix = prefix_chunks(prefix_len, n_heads, &bpc);
+    const int n_tot = n_prefix + n_split_suffix;
+    PrefixArgs pa{q, ldq, kprefix, vprefix, prefix_len, prefix_S, (float*)partial, n_heads, B, n_tot, bpc};
+    // (events of vh_ar_decoder_profile_attn bracket the prefix launch: the step's dominant attention kernel in this form)
+    hipExtLaunchKernelGGL(attn_prefix_kernel, dim3(n_prefix, n_heads), dim3(64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, pa);
+    dim3 grid(n_split_suffix, B * n_heads);
+#define SUF(NW) hipLaunchKernelGGL((attn_suffix_kernel<NW>), grid, dim3(NW * 64), 0, s, q, ldq, ksuffix, vsuffix, out, ldo, \
+                                   suffix_len, len_bias, n_heads, S_suf, n_split_suffix, n_prefix, (float*)partial)
+    const int per_split = (S_suf + n_split_suffix - 1) / n_split_suffix;
+    if (per_split <= 640) SUF(4);
+    else if (per_split <= 2048) SUF(8);
+    else SUF(16);
+#undef SUF
+    if (n_split_suffix > 1)
+        hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(B * n_heads), dim3(64), 0, s, (const float*)partial, out, ldo,
+                           n_heads, n_tot);
+    VH_CHECK_LAUNCH("vh_attn_decode_shared");
+    return VH_OK;
+}

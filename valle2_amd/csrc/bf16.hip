@@ -248,8 +248,8 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
     __builtin_amdgcn_s_setprio(0);
     fload(0, 0, 0);
     // One K step = four groups of 4 MFMAs (one per 16-wide k slice).  The other register set is read from LDS one MFMA
-    // into the group; the next slab's DMA is requested in groups 0 - 3 (two pieces each) into the other buffer (free since
-    // the previous step's barrier); the step's barrier sits inside group 3 after this wave's last read of the buffer.
+    // into the group; the next slab's DMA is requested in groups 0 and 1 (four pieces each) into the other buffer (free
+    // since the previous step's barrier); the step's barrier sits inside group 3 after this wave's last read of the buffer.
     auto kstep = [&](int kt, auto cur_c, auto pf) {
         constexpr bool PF = decltype(pf)::value;
         constexpr int cur = decltype(cur_c)::value;
@@ -258,9 +258,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
             const int s = t & 1;
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fw[s][0], acc[0][0], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PF) {
-                dma1(2 * t, cur ^ 1, (kt + 1) * T16K);
-                dma1(2 * t + 1, cur ^ 1, (kt + 1) * T16K);
+            if constexpr (PF) {                           // all eight pieces in the first two groups: a piece requested in
+                if (t < 2) {                              // the last group would be waited for the moment it is issued
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) dma1(4 * t + i, cur ^ 1, (kt + 1) * T16K);
+                }
             }
             if (t < 3) {
                 fload(s ^ 1, cur, t + 1);

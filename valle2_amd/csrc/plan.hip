@@ -65,6 +65,7 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                    d->logits && d->cache_len && d->audio_pos && d->eos_count && d->codes,
                VH_EINVAL, "vh_ar_decoder: null buffer in desc");
     VH_REQUIRE(d->n_split == 1 || d->attn_partial, VH_EINVAL, "vh_ar_decoder: n_split>1 needs attn_partial");
+    VH_REQUIRE(d->prefix_len >= 0, VH_EINVAL, "vh_ar_decoder: prefix_len=%d", d->prefix_len);
     if (d->ffn_ws) {
         VH_REQUIRE(d->ffn_ws_bytes >= vh_ffn_decode_ws_bytes(d->B, d->d_model, d->dff) && d->ffn_ws_bytes > 0, VH_EINVAL,
                    "vh_ar_decoder: ffn_ws needs vh_ffn_decode_ws_bytes() bytes");
@@ -77,6 +78,17 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
                    d->n_split);
         for (int i = 0; i < d->n_layers; ++i)
             VH_REQUIRE(d->layers[i].wqkv_f, VH_EINVAL, "vh_ar_decoder: the bf16 K/V cache needs folded weights (layer %d)", i);
+    }
+    if (d->prefix_len > 0) {
+        VH_REQUIRE(!d->kv_bf16, VH_EUNSUPPORTED, "vh_ar_decoder: the shared prompt has no bf16 form");
+        VH_REQUIRE(d->prefix_len <= d->prefix_S && d->attn_partial &&
+                       d->attn_partial_bytes >= vh_attn_decode_shared_ws_bytes(d->B, d->n_heads, d->prefix_len, d->n_split),
+                   VH_EINVAL, "vh_ar_decoder: shared prompt of %d / %d keys needs attn_partial of %zu bytes (got %zu)",
+                   d->prefix_len, d->prefix_S, vh_attn_decode_shared_ws_bytes(d->B, d->n_heads, d->prefix_len, d->n_split),
+                   d->attn_partial_bytes);
+        for (int i = 0; i < d->n_layers; ++i)
+            VH_REQUIRE(d->layers[i].kprefix && d->layers[i].vprefix, VH_EINVAL,
+                       "vh_ar_decoder: shared prompt needs kprefix / vprefix in every layer (layer %d)", i);
     }
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
@@ -123,6 +135,10 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         if (d.kv_bf16)
             return vh_attn_decode_kv16(d.q, D, (const uint16_t*)L.kcache, (const uint16_t*)L.vcache, d.attn, D, d.cache_len,
                                        1, B, d.n_heads, d.S_max, s);
+        if (d.prefix_len > 0)        // the beams of one utterance: prompt K/V read once, each beam's own rows after it
+            return vh_attn_decode_shared(d.q, D, L.kprefix, L.vprefix, d.prefix_len, d.prefix_S, L.kcache, L.vcache, d.attn, D,
+                                         d.cache_len, 1, B, d.n_heads, d.S_max, d.n_split, d.attn_partial,
+                                         d.attn_partial_bytes, s);
         return vh_attn_decode(d.q, D, L.kcache, L.vcache, d.attn, D, d.cache_len, 1, B, d.n_heads, d.S_max, d.n_split,
                               d.attn_partial, s);
     };

@@ -396,7 +396,10 @@ class ArDecoder:
     per row per step, the whole step enqueued natively and replayed as a hipGraph."""
 
     def __init__(self, model, batch, s_max, codes, cache: KVCache, cache_len, audio_pos, pos_base,
-                 n_split=None, use_graph=True, seed=0):
+                 n_split=None, use_graph=True, seed=0, prefix: KVCache | None = None, prefix_len=0):
+        """prefix / prefix_len: SHARED-PROMPT decoding (the beams of ONE utterance, valle_ar.py:135-138): `prefix` is a
+        one-row cache holding the prompt's K/V (its first prefix_len rows), `cache` then holds only the generated rows of
+        every beam (s_max = its capacity) and cache_len counts those."""
         cfg = model.config
         dev = cache.buf.device
         d, dff, V = cfg.d_model, cfg.dim_feedforward, cfg.num_audio_tokens + 1
@@ -409,7 +412,13 @@ class ArDecoder:
         self.attn = torch.empty(batch, d, **f32)
         self.hidden = torch.empty(batch, dff, **f32)
         self.logits = torch.zeros(batch, self.ldl, **f32)
-        self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
+        self.prefix, self.prefix_len = prefix, int(prefix_len)
+        if prefix is not None:
+            if prefix.bf16 or cache.bf16 or prefix.batch != 1 or prefix.n_layers != cfg.num_layers or not 0 < prefix_len <= prefix.s_max:
+                raise _lib.VhError('shared-prompt decoding: a one-row fp32 prefix cache holding prefix_len rows')
+            self.partial = kernels.attn_decode_shared_ws(batch, cfg.n_heads, self.prefix_len, self.n_split, dev)
+        else:
+            self.partial = kernels.attn_decode_ws(batch, cfg.n_heads, self.n_split, dev)
         ws_bytes = _lib.lib().vh_linear_ws_bytes(batch, d, dff)
         self.gemm_ws = torch.empty(max(ws_bytes, 16) // 4, **f32) if ws_bytes else None
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
@@ -426,6 +435,9 @@ class ArDecoder:
         ffn_bytes = _lib.lib().vh_ffn_decode_ws_bytes(batch, d, dff) if self._folded is not None else 0
         self.ffn_ws = torch.empty(ffn_bytes // 4, **f32) if ffn_bytes else None
         self._table = layer_table(model.transformer, cache, self._folded)
+        if prefix is not None:
+            for i in range(cfg.num_layers):
+                self._table[i].kprefix, self._table[i].vprefix = ptr(prefix.k(i)), ptr(prefix.v(i))
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(),
                       model.audio_position_emb.pe)
         desc = VhArDecoderDesc(
@@ -439,7 +451,9 @@ class ArDecoder:
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
             sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes,
-            kv_bf16=int(self.kv_bf16))
+            kv_bf16=int(self.kv_bf16), prefix_len=self.prefix_len if prefix is not None else 0,
+            prefix_S=prefix.s_max if prefix is not None else 0,
+            attn_partial_bytes=self.partial.numel() * 4 if self.partial is not None else 0)
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:

@@ -362,6 +362,29 @@ def attn_decode(q, kcache, vcache, out, cache_len, len_bias, n_split=1, partial=
     return out
 
 
+def attn_decode_shared_ws(B, n_heads, prefix_len, n_split, device):
+    """Record workspace of `attn_decode_shared` (vh_attn_decode_shared_ws_bytes), as a float32 tensor."""
+    n = _lib.lib().vh_attn_decode_shared_ws_bytes(B, n_heads, prefix_len, n_split)
+    return torch.empty(max(n, 16) // 4, device=device, dtype=torch.float32)
+
+
+def attn_decode_shared(q, kprefix, vprefix, prefix_len, ksuffix, vsuffix, out, suffix_len, len_bias, n_split=1, partial=None):
+    """One-query attention of B beams over a SHARED prompt (kprefix / vprefix (1, h, prefix_S, 64), first `prefix_len` rows)
+    followed by each beam's own rows (ksuffix / vsuffix (B, h, S_suf, 64), suffix_len[b] + len_bias of them)."""
+    B, n_heads, S_suf, hd = ksuffix.shape
+    if hd != HEAD_DIM or tuple(kprefix.shape[:2]) != (1, n_heads) or kprefix.shape[3] != HEAD_DIM or q.shape[0] != B:
+        raise _lib.VhError(f'attn_decode_shared: prefix {tuple(kprefix.shape)} suffix {tuple(ksuffix.shape)} q {tuple(q.shape)}')
+    if suffix_len.dtype != torch.int32 or suffix_len.numel() != B:
+        raise _lib.VhError('attn_decode_shared: suffix_len must be int32 (B)')
+    if partial is None:
+        partial = attn_decode_shared_ws(B, n_heads, prefix_len, n_split, q.device)
+    check(_lib.lib().vh_attn_decode_shared(
+        _dev_f32(q, 'q'), q.stride(0), ptr(kprefix), ptr(vprefix), prefix_len, kprefix.shape[2], ptr(ksuffix), ptr(vsuffix),
+        _dev_f32(out, 'out'), out.stride(0), ptr(suffix_len), len_bias, B, n_heads, S_suf, n_split, ptr(partial),
+        partial.numel() * 4, stream()), 'vh_attn_decode_shared')
+    return out
+
+
 def attn_decode_kv16(q, kcache16, vcache16, out, cache_len, len_bias):
     """attn_decode over a bf16 K/V cache (perf mode); one (row, head) per workgroup."""
     B, n_heads, S_max, hd = kcache16.shape

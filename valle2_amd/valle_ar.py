@@ -9,6 +9,8 @@ step (valle_ar.py:169-170).
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 from torch import optim
@@ -29,6 +31,13 @@ except Exception:  # pragma: no cover - lightning is absent in this image
 
 EOS_POLL = 32
 MAX_DECODE_ROWS = 64      # rows per decode launch (vh_ar_decoder: 1..64)
+# generate(): the beams of one utterance share its prompt K/V (read once per step for all beams).  VALLE2_SHARED_PROMPT=0
+# decodes the beams as independent rows (round 4's form: the A/B arm, and what generate_batch does for distinct rows).
+SHARED_PROMPT = os.environ.get('VALLE2_SHARED_PROMPT', '1') != '0'
+
+
+class _Run:
+    """Shapes and modes of one generate_batch call, handed between its helpers."""
 
 
 class ValleAR(_Base):
@@ -154,14 +163,19 @@ class ValleAR(_Base):
     @torch.inference_mode()
     def generate(self, prompt_tokens, prompt_codes, target_tokens=None):
         """valle_ar.py:92-180 — one utterance replicated over `num_beams` rows; returns the 1-D
-        int64 first-codebook tokens of the best beam with EOS stripped."""
+        int64 first-codebook tokens of the best beam with EOS stripped.
+
+        The beams share one prompt, so (SHARED_PROMPT, default on) the prompt pass runs for ONE row and its K/V are read
+        once per decode step for all beams (`generate_batch(..., shared_prompt=True)`); the beams themselves — their
+        sampled tokens, their own K/V rows, the per-beam log-probabilities — are never deduplicated."""
         assert prompt_tokens.dim() == 1, 'Prompt tokens should be 1D tensor.'
         assert prompt_codes.dim() == 2, 'Prompt codes should be 2D tensor.'
         if target_tokens is not None:
             assert target_tokens.dim() == 1, 'Target tokens should be 1D tensor.'
         beams = self.config.num_beams
         text = prompt_tokens if target_tokens is None else torch.cat((prompt_tokens, target_tokens), dim=0)
-        rows = self.generate_batch([text] * beams, [prompt_codes[..., 0]] * beams)
+        shared = SHARED_PROMPT and self.config.use_kv_cache and self.config.d_model == self.config.n_heads * kernels.HEAD_DIM
+        rows = self.generate_batch([text] * beams, [prompt_codes[..., 0]] * beams, shared_prompt=shared and beams <= MAX_DECODE_ROWS)
         # beams → one sequence (valle_ar.py:174-180); with top_k=1 every log-prob is exactly 0
         sum_logprobs = self.last_generate_stats['sum_logprobs']
         prompt_len = prompt_codes.shape[0] + 1
@@ -169,10 +183,143 @@ class ValleAR(_Base):
         best = best[prompt_len:]
         return best[best != self.eos_token]
 
+    def _generate_in_groups(self, texts, first_codes, max_new, use_graph, perf_mode):
+        """More rows than one decode launch serves (64: 4 MFMA row tiles): consecutive groups of 64 rows; rows are
+        independent, so the result is what one pass would give."""
+        B, dev = len(texts), self.device
+        parts, stats = [], []
+        for r0 in range(0, B, MAX_DECODE_ROWS):
+            parts.append(self.generate_batch(texts[r0:r0 + MAX_DECODE_ROWS], first_codes[r0:r0 + MAX_DECODE_ROWS],
+                                             max_new=max_new, use_graph=use_graph, perf_mode=perf_mode))
+            stats.append(self.last_generate_stats)
+        width = max(p.shape[1] for p in parts)
+        out = torch.full((B, width), self.eos_token, device=dev, dtype=torch.int64)
+        r = 0
+        for p in parts:
+            out[r:r + p.shape[0], :p.shape[1]] = p
+            r += p.shape[0]
+        merged = dict(stats[-1])
+        merged['prompt_lens'] = [x for st in stats for x in st['prompt_lens']]
+        merged['sum_logprobs'] = torch.cat([st['sum_logprobs'] for st in stats])
+        merged['tokens_appended'] = max(st['tokens_appended'] for st in stats)
+        self.last_generate_stats = merged
+        return out
+
+    def _prompt_pass(self, run, texts, first_codes, codes):
+        """Step 0 (valle_ar.py:143-155 at kv_cache=None): embed and run the whole prompt.  Row b is laid out
+        [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.  Returns the K/V cache the decode
+        steps continue on (None without one), the shared-prompt prefix cache (or None) and the last hidden row of every
+        decode row.  `run`: the _Run record of generate_batch (shapes, modes)."""
+        cfg, dev, d = self.config, self.device, self.config.d_model
+        B, s0, s_max = run.B, run.s0, run.s_max
+        i32 = dict(device=dev, dtype=torch.int32)
+        prefix = None
+        if run.any_head_dim:
+            cache = None
+        elif run.shared:
+            # ONE row through the prompt pass: its K/V are the prefix every beam reads; the beams' cache holds generated rows only
+            prefix = KVCache(cfg.num_layers, 1, cfg.n_heads, (s0 + 31) // 32 * 32, dev)
+            cache = KVCache(cfg.num_layers, B, cfg.n_heads, (run.max_new + 1 + 31) // 32 * 32, dev)
+        elif run.perf_prefill:
+            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev, dtype=torch.bfloat16)
+        else:
+            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s0 if run.perf_mode else s_max, dev)
+        rows = 1 if run.shared else B
+        if not run.ragged:
+            run.text_ids = torch.stack(texts[:rows])
+            codes[:, 1:run.pl_max] = torch.stack(first_codes)
+            x = torch.empty(rows, s0, d, device=dev, dtype=torch.float32)
+            self._embed_rows(run.text_ids, codes[:rows, :run.pl_max], x)
+            run.fwd = dict(x_len=run.txs[0])
+        else:
+            x = torch.zeros(B, s0, d, device=dev, dtype=torch.float32)
+            for b in range(B):
+                codes[b, 1:run.pls[b]] = first_codes[b]
+                self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :run.pls[b]], x[b:b + 1])
+            run.lens = torch.tensor([t + p for t, p in zip(run.txs, run.pls)], **i32)
+            run.fwd = dict(x_len_dev=torch.tensor(run.txs, **i32), kv_len=run.lens)
+        if run.perf_prefill:
+            transformer_forward_bf16(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
+                                     scratch=ForwardScratch16(B * s0, d, cfg.dim_feedforward, dev), **run.fwd)
+        else:
+            scratch = None if run.any_head_dim else ForwardScratch(rows * s0, d, cfg.dim_feedforward, dev)
+            transformer_forward(self.transformer, x, prefix if run.shared else cache, mode=kernels.MASK_PREFIX,
+                                scratch=scratch, **run.fwd)
+        if run.ragged:
+            last = x[torch.arange(B, device=dev), run.lens.long() - 1]
+        elif run.shared:
+            last = x[:, -1].expand(B, d)                  # every beam starts from the one prompt row's last hidden state
+        else:
+            last = x[:, -1]
+        if run.perf_mode and not run.perf_prefill:
+            cache = cache.narrowed(s_max)                 # fp32 prompt K/V -> the bf16 cache of the decode steps
+        return cache, prefix, last.contiguous()
+
+    def _decode_forced(self, run, dec, codes, forced, keep_logits):
+        """TEACHER FORCING (tolerance tests): after every step replace the sampled token and its embedding by the given one;
+        returns the logits the head produced at the steps listed in keep_logits."""
+        dev, d = self.device, self.config.d_model
+        forced = forced.to(dev)
+        if run.ragged or forced.numel() < run.max_new:
+            raise ValueError('forced: one token per step, equal-length rows')
+        pe, kept = self.audio_position_emb.pe, {}
+        for t in range(run.max_new):
+            if t:
+                dec.run(1)
+            if t in keep_logits:
+                kept[t] = dec.logits[:, : dec.V].clone()
+            codes[:, run.pl_max + t] = forced[t]
+            kernels.embed_sum_pe(codes[:, run.pl_max + t:run.pl_max + t + 1], [self.audio_emb.weight.detach()], pe,
+                                 run.pl_max + t, dec.x.view(run.B, 1, d))
+        return kept
+
+    def _decode_recompute(self, run, dec, texts, codes, cache):
+        """config.use_kv_cache = False (valle_ar.py:132,150-155 — the reference's branch raises, D2; build-defined here as
+        what the flag says): every step embeds the WHOLE sequence again and runs the full stack over it under the prefix
+        mask — no state is carried from step to step except the tokens — and samples from its last row with the same head /
+        sample kernels.  O(S^2) per token; it exists so that the flag works and as an independent check of the cached
+        decoder (same tokens, tests/test_models_gpu.py).  Returns the number of steps run."""
+        cfg, dev, d = self.config, self.device, self.config.d_model
+        B, s0 = run.B, run.s0
+        scratch = None if run.any_head_dim else ForwardScratch(B * (s0 + run.max_new), d, cfg.dim_feedforward, dev)
+        rows_idx = torch.arange(B, device=dev)
+        done = 1
+        while done < run.max_new:
+            t = done
+            xs = (torch.zeros if run.ragged else torch.empty)(B, s0 + t, d, device=dev, dtype=torch.float32)
+            if not run.ragged:
+                self._embed_rows(run.text_ids, codes[:, :run.pl_max + t], xs)
+                transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch, **run.fwd)
+                last = xs[:, -1]
+            else:
+                for b in range(B):
+                    self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :run.pls[b] + t], xs[b:b + 1])
+                transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch,
+                                    x_len_dev=run.fwd['x_len_dev'], kv_len=run.lens + t)
+                last = xs[rows_idx, run.lens.long() + t - 1]
+            dec.sample_from(last.contiguous())
+            done += 1
+            if done % EOS_POLL == 0 and bool((dec.eos_count[:done] == B).any()):
+                break
+        return done
+
+    @staticmethod
+    def _decode_cached(run, dec, done):
+        """Steps done .. max_new-1 on the cached decoder, EOS polled every EOS_POLL steps (valle_ar.py:169-170 breaks when
+        every beam has emitted EOS).  Returns (steps run, step at which every row had finished or None)."""
+        while done < run.max_new:
+            n = min(EOS_POLL, run.max_new - done)
+            dec.run(n)
+            done += n
+            full = (dec.eos_count[:done] == run.B).nonzero()
+            if full.numel():
+                return done, int(full[0])
+        return done, None
+
     @_on_device
     @torch.inference_mode()
     def generate_batch(self, texts, first_codes, max_new=None, use_graph=True, profile_attn=False, perf_mode=False,
-                       forced=None, keep_logits=()):
+                       forced=None, keep_logits=(), shared_prompt=False):
         """Batched greedy decoding of B independent rows (extension; `generate` is built on it).
         texts[b]: 1-D int64 text ids; first_codes[b]: 1-D int64 first-codebook prompt (no BOS).
         Rows may differ in text and prompt length.  Returns codes (B, max_prompt_len + n_new) int64
@@ -188,180 +335,100 @@ class ValleAR(_Base):
         reference's (teacher-forced logits agree to 5e-2).
         forced (max_new,) int64 + keep_logits (step indices): TEACHER FORCING for the tolerance tests — step t appends
         forced[t] whatever the head says (steps run eagerly, one at a time) and the logits (B, V) the head produced at
-        the steps listed in keep_logits are left in `last_generate_stats['logits']`."""
+        the steps listed in keep_logits are left in `last_generate_stats['logits']`.
+        shared_prompt=True: the caller vouches that every row has the SAME text and prompt (the beams of one utterance,
+        valle_ar.py:135-138; checked: equal lengths and equal ids) — the prompt pass then runs for one row and every decode
+        step reads the prompt's K/V once for all rows (vh_attn_decode_shared); rows still sample, append and score
+        independently.  fp32 (no perf_mode), cached decoder only."""
         self._require_layernorm()
         cfg = self.config
-        # a head width other than 64 (modules.py:109-111 allows it; no configuration of the path has it): the native
-        # decoder and its KV-cache kernels are built for 64, so such a model decodes by recomputation on the general kernels
-        any_head_dim = cfg.d_model != cfg.n_heads * kernels.HEAD_DIM
-        no_cache = not cfg.use_kv_cache or any_head_dim
-        if no_cache and (perf_mode or profile_attn or forced is not None):
-            raise ValueError('use_kv_cache=False (or a head width other than 64) recomputes every step from scratch: '
-                             'perf_mode / profile_attn / forced belong to the cached decoder')
         dev = self.device
         B = len(texts)
         if B == 0 or len(first_codes) != B:
             raise ValueError('generate_batch: texts and first_codes must be non-empty lists of equal length')
-        max_new = cfg.max_audio_len if max_new is None else max_new
+        run = _Run()
+        run.B, run.max_new = B, cfg.max_audio_len if max_new is None else max_new
+        # a head width other than 64 (modules.py:109-111 allows it; no configuration of the path has it): the native
+        # decoder and its KV-cache kernels are built for 64, so such a model decodes by recomputation on the general kernels
+        run.any_head_dim = cfg.d_model != cfg.n_heads * kernels.HEAD_DIM
+        no_cache = not cfg.use_kv_cache or run.any_head_dim
+        if no_cache and (perf_mode or profile_attn or forced is not None or shared_prompt):
+            raise ValueError('use_kv_cache=False (or a head width other than 64) recomputes every step from scratch: '
+                             'perf_mode / profile_attn / forced / shared_prompt belong to the cached decoder')
         if B > MAX_DECODE_ROWS:
-            # the decode kernels serve up to 64 rows per launch (4 MFMA row tiles): larger batches run as consecutive
-            # groups of 64 rows; rows are independent, so the result is what one pass would give
-            parts, stats = [], []
-            for s0 in range(0, B, MAX_DECODE_ROWS):
-                parts.append(self.generate_batch(texts[s0:s0 + MAX_DECODE_ROWS], first_codes[s0:s0 + MAX_DECODE_ROWS],
-                                                 max_new=max_new, use_graph=use_graph, perf_mode=perf_mode))
-                stats.append(self.last_generate_stats)
-            width = max(p.shape[1] for p in parts)
-            out = torch.full((B, width), self.eos_token, device=dev, dtype=torch.int64)
-            r = 0
-            for p in parts:
-                out[r:r + p.shape[0], :p.shape[1]] = p
-                r += p.shape[0]
-            merged = dict(stats[-1])
-            merged['prompt_lens'] = [x for st in stats for x in st['prompt_lens']]
-            merged['sum_logprobs'] = torch.cat([st['sum_logprobs'] for st in stats])
-            merged['tokens_appended'] = max(st['tokens_appended'] for st in stats)
-            self.last_generate_stats = merged
-            return out
-        txs = [int(t.shape[0]) for t in texts]
-        pls = [int(c.shape[0]) + 1 for c in first_codes]                  # BOS + prompt
-        ragged = len(set(txs)) > 1 or len(set(pls)) > 1
-        tx_max, pl_max = max(txs), max(pls)
-        s0 = max(t + p for t, p in zip(txs, pls))                           # longest row's context
-        s_max = (s0 + max_new + 31) // 32 * 32          # whole 32-key chunks per (row, head) block (the ring kernel reads ahead in chunks of 32 keys)
-        if pl_max + max_new > self.audio_position_emb.pe.shape[0] or tx_max > self.tokens_position_emb.pe.shape[0]:
+            if shared_prompt or forced is not None:
+                raise ValueError(f'shared_prompt / forced serve at most {MAX_DECODE_ROWS} rows')
+            return self._generate_in_groups(texts, first_codes, run.max_new, use_graph, perf_mode)
+        run.txs = [int(t.shape[0]) for t in texts]
+        run.pls = [int(c.shape[0]) + 1 for c in first_codes]              # BOS + prompt
+        run.ragged = len(set(run.txs)) > 1 or len(set(run.pls)) > 1
+        tx_max, run.pl_max = max(run.txs), max(run.pls)
+        run.s0 = max(t + p for t, p in zip(run.txs, run.pls))               # longest row's context
+        run.s_max = (run.s0 + run.max_new + 31) // 32 * 32   # whole 32-key chunks per (row, head) block (the ring kernel reads ahead in chunks of 32 keys)
+        if run.pl_max + run.max_new > self.audio_position_emb.pe.shape[0] or tx_max > self.tokens_position_emb.pe.shape[0]:
             raise _lib.VhError('sequence exceeds the positional table (max_len 5000)')
-        codes = torch.full((B, pl_max + max_new), self.eos_token, device=dev, dtype=torch.int64)
+        run.perf_mode = perf_mode
+        run.perf_prefill = bool(perf_mode) and perf_mode != 'kv' and perf_forward_supported(cfg)
+        run.shared = bool(shared_prompt)
+        if run.shared and (perf_mode or run.ragged):
+            raise ValueError('shared_prompt: identical rows, fp32')
+        codes = torch.full((B, run.pl_max + run.max_new), self.eos_token, device=dev, dtype=torch.int64)
         codes[:, 0] = self.bos_token                                   # valle_ar.py:115-117
-        d = cfg.d_model
-        i32 = dict(device=dev, dtype=torch.int32)
-
-        # ---- step 0: prefill the whole prompt (valle_ar.py:143-155 at kv_cache=None).  Row b is laid
-        # out [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.
-        # (perf mode: the prompt pass needs its fp32 cache only as long as the prompt; the bf16 cache holds the run)
-        perf_prefill = bool(perf_mode) and perf_mode != 'kv' and perf_forward_supported(cfg)
-        if any_head_dim:
-            cache = None
-        elif perf_prefill:
-            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev, dtype=torch.bfloat16)
-        else:
-            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s0 if perf_mode else s_max, dev)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # prefill | decode phase times
         marks[0].record()
         texts = [kernels.ids_to_device(t, dev, cfg.vocab_size, 'text ids') for t in texts]
         first_codes = [kernels.ids_to_device(c, dev, cfg.num_audio_tokens, 'prompt codes') for c in first_codes]
-        if not ragged:
-            text_ids = torch.stack(texts)
-            codes[:, 1:pl_max] = torch.stack(first_codes)
-            x = torch.empty(B, s0, d, device=dev, dtype=torch.float32)
-            self._embed_rows(text_ids, codes[:, :pl_max], x)
-            fwd = dict(x_len=txs[0])
-            last = x[:, -1]
-        else:
-            x = torch.zeros(B, s0, d, device=dev, dtype=torch.float32)
-            for b in range(B):
-                codes[b, 1:pls[b]] = first_codes[b]
-                self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :pls[b]], x[b:b + 1])
-            lens = torch.tensor([t + p for t, p in zip(txs, pls)], **i32)
-            fwd = dict(x_len_dev=torch.tensor(txs, **i32), kv_len=lens)
+        if run.shared and any(t is not texts[0] and not torch.equal(t, texts[0]) for t in texts[1:]) or \
+                run.shared and any(c is not first_codes[0] and not torch.equal(c, first_codes[0]) for c in first_codes[1:]):
+            raise ValueError('shared_prompt: every row must carry the same text and prompt ids')
         # (the decode loop's small state goes up BEFORE the prompt pass is enqueued: a host->device copy behind it
         # would hold the host until the pass has finished, and the decoder is built and captured during the pass)
-        cache_len = _lib.to_device_async(torch.tensor([t + p - 1 for t, p in zip(txs, pls)], dtype=torch.int32), dev)
-        audio_pos = _lib.to_device_async(torch.tensor(pls, dtype=torch.int32), dev)   # cache_len: +1 by the sample step
+        # cache_len: rows in the cache the decode steps append to (+1 by the sample step); shared prompt: generated rows only
+        first_len = [-1] * B if run.shared else [t + p - 1 for t, p in zip(run.txs, run.pls)]
+        cache_len = _lib.to_device_async(torch.tensor(first_len, dtype=torch.int32), dev)
+        audio_pos = _lib.to_device_async(torch.tensor(run.pls, dtype=torch.int32), dev)
         pos_base = audio_pos.clone()
-        if perf_prefill:
-            transformer_forward_bf16(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
-                                     scratch=ForwardScratch16(B * s0, d, cfg.dim_feedforward, dev), **fwd)
-        else:
-            transformer_forward(self.transformer, x, cache, mode=kernels.MASK_PREFIX,
-                                scratch=None if any_head_dim else ForwardScratch(B * s0, d, cfg.dim_feedforward, dev), **fwd)
-        if ragged:
-            last = x[torch.arange(B, device=dev), lens.long() - 1]
+        cache, prefix, last = self._prompt_pass(run, texts, first_codes, codes)
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
-        if perf_mode and not perf_prefill:
-            cache = cache.narrowed(s_max)                 # fp32 prompt K/V -> the bf16 cache of the decode steps
-        if any_head_dim:
+        if run.any_head_dim:
             dec = StepSampler(self, B, codes, cache_len, audio_pos, pos_base, seed=seed)
         else:
-            dec = ArDecoder(self, B, s_max, codes, cache, cache_len, audio_pos, pos_base,
-                            use_graph=use_graph and not no_cache, seed=seed)
+            dec = ArDecoder(self, B, cache.s_max, codes, cache, cache_len, audio_pos, pos_base,
+                            use_graph=use_graph and not no_cache, seed=seed, prefix=prefix, prefix_len=run.s0)
         try:
             dec.capture()                                 # (a no-op without a graph: the no-cache path only borrows the sampler)
-            dec.sample_from(last.contiguous())
+            dec.sample_from(last)
             marks[1].record()
-            del x, last
-            kept = {}
-            if forced is not None:
-                # teacher forcing: after every step replace the sampled token and its embedding by the given one
-                forced = forced.to(dev)
-                if ragged or forced.numel() < max_new:
-                    raise ValueError('forced: one token per step, equal-length rows')
-                pe = self.audio_position_emb.pe
-                for t in range(max_new):
-                    if t:
-                        dec.run(1)
-                    if t in keep_logits:
-                        kept[t] = dec.logits[:, : dec.V].clone()
-                    codes[:, pl_max + t] = forced[t]
-                    kernels.embed_sum_pe(codes[:, pl_max + t:pl_max + t + 1], [self.audio_emb.weight.detach()], pe,
-                                         pl_max + t, dec.x.view(B, 1, d))
-            # ---- steps 1 .. max_new-1, EOS polled every EOS_POLL steps
-            done, stop = (max_new if forced is not None else 1), None
-            if no_cache:
-                # config.use_kv_cache = False (valle_ar.py:132,150-155 — the reference's branch raises, D2; build-defined
-                # here as what the flag says): every step embeds the WHOLE sequence again and runs the full stack over it
-                # under the prefix mask — no state is carried from step to step except the tokens — and samples from
-                # its last row with the same head / sample kernels.  O(S^2) per token; it exists so that the flag works
-                # and as an independent check of the cached decoder (same tokens, tests/test_models_gpu.py).
-                scratch = None if any_head_dim else ForwardScratch(B * (s0 + max_new), d, cfg.dim_feedforward, dev)
-                rows_idx = torch.arange(B, device=dev)
-                while done < max_new:
-                    t = done
-                    xs = (torch.zeros if ragged else torch.empty)(B, s0 + t, d, device=dev, dtype=torch.float32)
-                    if not ragged:
-                        self._embed_rows(text_ids, codes[:, :pl_max + t], xs)
-                        transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch, **fwd)
-                        last = xs[:, -1]
-                    else:
-                        for b in range(B):
-                            self._embed_rows(texts[b].unsqueeze(0), codes[b:b + 1, :pls[b] + t], xs[b:b + 1])
-                        transformer_forward(self.transformer, xs, cache, mode=kernels.MASK_PREFIX, scratch=scratch,
-                                            x_len_dev=fwd['x_len_dev'], kv_len=lens + t)
-                        last = xs[rows_idx, lens.long() + t - 1]
-                    dec.sample_from(last.contiguous())
-                    done += 1
-                    if done % EOS_POLL == 0 and bool((dec.eos_count[:done] == B).any()):
-                        break
+            del last
+            kept, done, stop = {}, 1, None
             attn_ms = attn_floor_ms = attn_kernel_ms = None
-            if profile_attn and max_new > 1:
-                attn_ms, attn_floor_ms, attn_kernel_ms = dec.profile_attn(max_new - 1)
-                done = max_new
-            while done < max_new and not no_cache:
-                n = min(EOS_POLL, max_new - done)
-                dec.run(n)
-                done += n
-                full = (dec.eos_count[:done] == B).nonzero()
-                if full.numel():
-                    stop = int(full[0])
-                    break
+            if forced is not None:
+                kept, done = self._decode_forced(run, dec, codes, forced, keep_logits), run.max_new
+            elif no_cache:
+                done = self._decode_recompute(run, dec, texts, codes, cache)
+            elif profile_attn and run.max_new > 1:
+                attn_ms, attn_floor_ms, attn_kernel_ms = dec.profile_attn(run.max_new - 1)
+                done = run.max_new
+            else:
+                done, stop = self._decode_cached(run, dec, done)
             marks[2].record()
             if stop is None:
                 full = (dec.eos_count[:done] == B).nonzero()
                 stop = int(full[0]) if full.numel() else None
-            n_new = max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
+            n_new = run.max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             marks[2].synchronize()
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
-                                        'ffn_fused': dec.ffn_ws is not None and d <= 512, 'kv_bf16': dec.kv_bf16, 'prefill_bf16': perf_prefill,
-                                        'logits': kept,
+                                        'ffn_fused': dec.ffn_ws is not None and cfg.d_model <= 512, 'kv_bf16': dec.kv_bf16,
+                                        'prefill_bf16': run.perf_prefill, 'shared_prompt': run.shared, 'logits': kept,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
-                                        'attn_kernel_ms': attn_kernel_ms, 's0': s0,
-                                        'prompt_lens': pls,
+                                        'attn_kernel_ms': attn_kernel_ms, 's0': run.s0,
+                                        'prompt_lens': run.pls,
                                         'sum_logprobs': dec.sum_logprobs.clone()}
-            return codes[:, : pl_max + n_new].clone()
+            return codes[:, : run.pl_max + n_new].clone()
         finally:
             dec.close()
 
