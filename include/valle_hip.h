@@ -287,9 +287,10 @@ int vh_attn_decode(const float* q, int ldq, const float* kcache, const float* vc
  * same bits in every row (valle_ar.py:135-138 replicates one utterance): kprefix / vprefix (1, h, prefix_S, 64) are read
  * once per step for all B beams (a beam is a lane of the score tile), ksuffix / vsuffix (B, h, S_suf, 64) hold each
  * beam's generated rows, suffix_len[b] + len_bias of them attended.  Bytes per call: 2 (prefix_len + sum_b suffix) 64 h 4
- * instead of 2 B (prefix_len + suffix) 64 h 4.  One launch over the prefix (a record per (beam, head, key chunk)), one over
- * the suffixes that also merges the records when n_split_suffix == 1 (else a third launch merges).  fp32, deterministic
- * (records are merged in chunk order); results differ from vh_attn_decode's by summation order only.
+ * instead of 2 B (prefix_len + suffix) 64 h 4.  Two launches: one whose workgroups take either four 32-key blocks of the
+ * prefix for all beams or one (beam, head, key split) of the suffixes — a split record each — and one that merges the
+ * records of every (beam, head).  fp32, deterministic (fixed merge order); results differ from vh_attn_decode's by
+ * summation order only.  ceil(prefix_len / 32) + n_split_suffix <= 256.
  * partial: vh_attn_decode_shared_ws_bytes() bytes, no initialisation needed. */
 size_t vh_attn_decode_shared_ws_bytes(int B, int n_heads, int prefix_len, int n_split_suffix);
 int vh_attn_decode_shared(const float* q, int ldq, const float* kprefix, const float* vprefix, int prefix_len,

@@ -1,12 +1,12 @@
 // Host side of libvalle_hip.so under AddressSanitizer + UndefinedBehaviorSanitizer ("ASan/UBSan build
-// of the C-ABI host shim").  CPU only: the library is compiled with --offload-host-only (no device code,
-// no GPU sanitizer, no XNACK) and this driver calls everything that needs no device:
+// of the C-ABI host shim").  CPU only: the library's HOST code is compiled with -fsanitize=address,undefined and
+// -fno-gpu-sanitize (device code untouched: no GPU sanitizer, no XNACK) and this driver calls everything that needs no device:
 //   * every entry point with null / misaligned / out-of-range arguments — each must refuse (negative code, a reason in
 //     vh_last_error, nothing launched) without reading a byte behind a pointer it was given;
 //   * every workspace planner (vh_*_ws_bytes, vh_attn_rows_bwd_chunks) over a grid of shapes, degenerate ones included;
 //   * the decoder life-cycle on bad descriptors (create refuses, destroy(NULL), replay before capture, capture on the null
 //     stream) and on a descriptor whose pointers are never dereferenced on the host;
-//   * vh_set_tuning bounds, the thread-local error string from two threads.
+//   * vh_set_tuning bounds, the thread-local error string from eight threads.
 // Exit code 0 and "asan_host: N checks passed" = clean; a sanitizer report aborts the process (-fno-sanitize-recover).
 #include <stdint.h>
 #include <stdio.h>
@@ -119,6 +119,12 @@ int main() {
     REFUSED(vh_attn_decode(P, 128, P, P, P, 128, I32, 1, 1, 2, 8, 2, nullptr, S));                 // split without workspace
     REFUSED(vh_attn_decode(P, 128, P, P, P, 128, I32, 1, 1, 2, 8, 65, P, S));
     REFUSED(vh_attn_decode(P, 128, MIS, P, P, 128, I32, 1, 1, 2, 8, 1, nullptr, S));
+    REFUSED(vh_attn_decode_shared(nullptr, 128, P, P, 64, 64, P, P, P, 128, I32, 1, 4, 2, 32, 1, P, 1 << 20, S));
+    REFUSED(vh_attn_decode_shared(P, 128, P, P, 65, 64, P, P, P, 128, I32, 1, 4, 2, 32, 1, P, 1 << 20, S));        // prefix_len > prefix_S
+    REFUSED(vh_attn_decode_shared(P, 128, P, P, 64, 64, P, P, P, 128, I32, 1, 65, 2, 32, 1, P, 1 << 24, S));       // B > 64
+    REFUSED(vh_attn_decode_shared(P, 128, P, P, 64, 64, P, P, P, 128, I32, 1, 4, 2, 32, 1, P, 64, S));             // workspace too small
+    REFUSED(vh_attn_decode_shared(P, 128, P, P, 64, 64, P, P, P, 128, I32, 1, 4, 2, 32, 1, nullptr, 1 << 20, S));
+    REFUSED(vh_attn_decode_shared(P, 128, P, MIS, 64, 64, P, P, P, 128, I32, 1, 4, 2, 32, 1, P, 1 << 20, S));
     REFUSED(vh_kv_to_bf16(nullptr, W16, 1, 1, 4, 4, S));
     REFUSED(vh_kv_to_bf16(P, W16, 1, 8, 4, 4, S));                                                 // rows > S
     REFUSED(vh_attn_decode_kv16(nullptr, 128, P16, P16, P, 128, I32, 1, 1, 2, 8, S));
@@ -216,6 +222,17 @@ int main() {
                 EXPECT(ns <= 1 ? w == 0 : w >= (size_t)B * h * 4, "decode workspace B=%d h=%d n_split=%d: %zu", B, h, ns, w);
             }
 
+    for (int B : {0, 1, 4, 32, 64})
+        for (int h : {1, 8, 16})
+            for (int pl : {0, 1, 31, 626, 1024, 2907, 5000})
+                for (int ns : {0, 1, 8}) {
+                    const size_t w = vh_attn_decode_shared_ws_bytes(B, h, pl, ns);
+                    const bool live = B > 0 && pl > 0 && ns >= 1;
+                    // one PART_LD = 72-float record per 32-key block of the prefix and per suffix split
+                    EXPECT(live ? w == (size_t)B * h * ((pl + 31) / 32 + ns) * 288 : w == 0,
+                           "shared-prompt workspace B=%d h=%d prefix=%d n_split=%d: %zu", B, h, pl, ns, w);
+                }
+
     // ---- composites: descriptors ------------------------------------------------------------------------------------
     REFUSED(vh_transformer_forward(nullptr, S));
     vh_forward_desc fd;
@@ -262,6 +279,25 @@ int main() {
     bad = dd; bad.ffn_ws = P; bad.ffn_ws_bytes = 1 << 26; EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "folded"), "ffn workspace without folded weights");
     bad = dd; bad.kv_bf16 = 1;   EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "folded"), "bf16 cache without folded weights");
     bad = dd; bad.top_k = 50; bad.temperature = 0.f; EXPECT(vh_ar_decoder_create(&bad) == nullptr, "sampling at temperature 0");
+    bad = dd; bad.prefix_len = -3; EXPECT(vh_ar_decoder_create(&bad) == nullptr, "negative prefix");
+    bad = dd; bad.prefix_len = 100; bad.prefix_S = 128; bad.attn_partial = P; bad.attn_partial_bytes = 1 << 24;
+    EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "kprefix"), "shared prompt without prefix caches");
+    {
+        vh_layer pl[2];
+        memcpy(pl, layers, sizeof pl);
+        pl[0].kprefix = pl[0].vprefix = pl[1].kprefix = pl[1].vprefix = P;
+        bad.layers = pl;
+        bad.attn_partial_bytes = 16;
+        EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "attn_partial"), "shared prompt with a small workspace");
+        bad.attn_partial_bytes = 1 << 24; bad.prefix_S = 64;
+        EXPECT(vh_ar_decoder_create(&bad) == nullptr, "prefix_len > prefix_S");
+        bad.prefix_S = 128; bad.kv_bf16 = 1;
+        EXPECT(vh_ar_decoder_create(&bad) == nullptr, "shared prompt with a bf16 cache");
+        bad.kv_bf16 = 0;
+        vh_ar_decoder* ok = vh_ar_decoder_create(&bad);
+        EXPECT(ok != nullptr, "a well-formed shared-prompt descriptor");
+        vh_ar_decoder_destroy(ok);
+    }
     std::vector<vh_ar_decoder*> decs;
     for (int i = 0; i < 64; ++i) {                           // the descriptor and its layer array are COPIED: mutate / free the originals
         vh_layer* tmp = (vh_layer*)malloc(2 * sizeof(vh_layer));

@@ -1557,165 +1557,176 @@ extern "C" int vh_attn_rows_bwd_ws(const float* q, int ldq, const float* kcache,
 // num_beams rows (valle/models/valle_ar.py:135-138), so every beam's prompt K/V is the same bits.  Here the prompt K/V
 // ("prefix": (1, h, prefix_S, 64) per layer, written once by a one-row prompt pass) is read ONCE per step for all beams
 // and every beam keeps only its own generated rows ("suffix": (B, h, S_suf, 64)).  Bytes per step and layer:
-// 2 (S0 + B t) d instead of 2 B (S0 + t) d.
-//   attn_prefix_kernel   one wave per (key chunk, head): S^T = K Q^T for ALL beams at once — beams are the 32 lanes of a
-//                        32x32x2 MFMA tile (a second pass for beams 32..63) — softmax statistics and the unnormalised
-//                        O^T = V^T P^T of the chunk, written as one split record per (beam, head, chunk);
-//   attn_suffix_kernel   the burst kernel over a beam's own rows; with one suffix split it merges the prefix records of its
-//                        (beam, head) in chunk order and writes the output, else it adds its record and
-//                        attn_decode_combine_kernel merges all of them.
+// 2 (S0 + B t) d instead of 2 B (S0 + t) d.  Two launches:
+//   attn_shared_kernel   workgroups of 4 waves in two roles.  PREFIX role (blocks of 4 x 32 prompt keys, per head): a wave
+//                        takes one 32-key block and computes S^T = K Q^T for ALL beams at once — beams are the 32 lanes of a
+//                        32x32x2 MFMA tile (a second pass for beams 32..63) — the block's softmax statistics and unnormalised
+//                        O^T = V^T P^T, one split record per (beam, head, key block).  SUFFIX role ((beam, head), key split):
+//                        the burst kernel over the beam's own rows, one record per split.  The roles share nothing and run
+//                        side by side.
+//   attn_records_merge_kernel   per (beam, head): all records merged — weights by one parallel pass over the (m, l) pairs,
+//                        the o vectors summed by four thread groups over interleaved records, partials added in group
+//                        order (deterministic).  (The serial loop of attn_decode_combine_kernel is fine for <= 16 splits;
+//                        here there are up to 157 + 64 records, each load a trip beyond the L1.)
 // Record format and units as the key-split decode kernels' (PART_LD floats: o[64], m, l; scores scaled by log2 e / 8).
 // =============================================================================================
-struct PrefixArgs {
+struct SharedArgs {
     const float* q; int ldq;
-    const float* kp; const float* vp;
+    const float* kp; const float* vp;            // prefix (1, h, prefix_S, 64)
     int prefix_len, prefix_S;
+    const float* ks; const float* vs;            // suffix (B, h, S_suf, 64)
+    const int32_t* suffix_len; int len_bias;
+    int S_suf, n_split;
     float* partial;
-    int n_heads, B, n_tot, blocks_per_chunk;
+    int n_heads, B, n_pb, n_tot, prefix_wgs;     // n_pb: 32-key blocks of the prefix; prefix_wgs = ceil(n_pb / 4) * n_heads
 };
 
-__global__ __launch_bounds__(64) void attn_prefix_kernel(PrefixArgs a) {
-    const int chunk = blockIdx.x, head = blockIdx.y;
-    const int lane = threadIdx.x, r = lane & 31, hh = lane >> 5;
+__device__ __forceinline__ void shared_prefix_role(const SharedArgs& a, int wg, int lane, int w) {
+    const int head = wg % a.n_heads, blk = (wg / a.n_heads) * 4 + w;
+    if (blk >= a.n_pb) return;                               // (wave-uniform; no barrier in this role)
+    const int r = lane & 31, hh = lane >> 5;
     const float* kb = a.kp + (int64_t)head * a.prefix_S * HD;
     const float* vb = a.vp + (int64_t)head * a.prefix_S * HD;
-    const int key_begin = chunk * a.blocks_per_chunk * 32;
-    const int key_end = min(a.prefix_len, key_begin + a.blocks_per_chunk * 32);
+    const int k0 = blk * 32;
     const float qscale = 0.125f * LOG2E;
+    // K fragment (A operand): key k0 + r, d = 32 hh + j; rows beyond the prompt repeat its last row (masked below).  The k
+    // index of the product is only summed over, so both operands simply use the same d per (hh, j).
+    f32x4 kf[8];
+    {
+        const float* kr = kb + (int64_t)min(k0 + r, a.prefix_len - 1) * HD + 32 * hh;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[j] = ld4(kr + 4 * j);
+    }
+    // V^T operand values: product x pairs key base(x) (lanes hh = 0) with base(x) + 4 (lanes hh = 1), base(x) = (x & 3) +
+    // 8 (x >> 2) — exactly the keys whose weights sit in accumulator register x of the two lane halves
+    float vf[2][16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+        const int key = min(k0 + (x & 3) + 8 * (x >> 2) + 4 * hh, a.prefix_len - 1);
+        vf[0][x] = vb[(int64_t)key * HD + r];
+        vf[1][x] = vb[(int64_t)key * HD + 32 + r];
+    }
+    const bool whole = k0 + 32 <= a.prefix_len;              // wave-uniform
     for (int qb = 0; qb * 32 < a.B; ++qb) {
         const int b = min(qb * 32 + r, a.B - 1);             // lanes beyond B repeat the last beam (never stored)
-        // Q^T fragment (B operand): lane (r, hh) holds q[beam r][d = 32 hh + j], j = 0..31 — the k index of the product
-        // is only summed over, so both operands simply use the same d per (hh, j)
-        f32x4 qf[8];
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
         {
             const float* qr = a.q + (int64_t)b * a.ldq + head * HD + 32 * hh;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qf[j] = ld4(qr + 4 * j) * qscale;
-        }
-        float m = NEG_INF, l = 0.f;
-        f32x16 oacc[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
-        for (int k0 = key_begin; k0 < key_end; k0 += 32) {
-            // K fragment (A operand): key k0 + r, d = 32 hh + j; rows beyond the prompt repeat its last row (masked below)
-            f32x4 kf[8];
-            {
-                const float* kr = kb + (int64_t)min(k0 + r, a.prefix_len - 1) * HD + 32 * hh;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) kf[j] = ld4(kr + 4 * j);
-            }
-            f32x16 s;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = 0.f;
-#pragma unroll
             for (int j = 0; j < 8; ++j) {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].x, qf[j].x, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].y, qf[j].y, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].z, qf[j].z, s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].w, qf[j].w, s, 0, 0, 0);
-            }
-            // D reg x of lane (r = beam, hh): key k0 + (x & 3) + 8 (x >> 2) + 4 hh
-            float cmax = NEG_INF;
-            const bool whole = k0 + 32 <= a.prefix_len;                        // wave-uniform
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                if (!whole && k0 + (x & 3) + 8 * (x >> 2) + 4 * hh >= a.prefix_len) s[x] = NEG_INF;
-                cmax = fmaxf(cmax, s[x]);
-            }
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));                    // the beam's other key half
-            const float m_new = fmaxf(m, cmax);                               // finite: key k0 < prefix_len is in the block
-            const float alpha = vh_exp2(m - m_new);
-            float psum = 0.f;
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                s[x] = vh_exp2(s[x] - m_new);
-                psum += s[x];
-            }
-            l = l * alpha + psum;
-            m = m_new;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
-            // O^T += V^T P^T: product x pairs key base(x) (lanes hh = 0) with base(x) + 4 (lanes hh = 1) — exactly the keys
-            // whose weights sit in accumulator register x of the two lane halves, so P^T is the B operand as it lies
-#pragma unroll
-            for (int x = 0; x < 16; ++x) {
-                const int key = min(k0 + (x & 3) + 8 * (x >> 2) + 4 * hh, a.prefix_len - 1);
-                const float* vr = vb + (int64_t)key * HD + r;
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[x], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[x], oacc[1], 0, 0, 0);
+                const f32x4 qf = ld4(qr + 4 * j) * qscale;
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].x, qf.x, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].y, qf.y, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].z, qf.z, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].w, qf.w, s, 0, 0, 0);
             }
         }
-        const float l_tot = l + __shfl_xor(l, 32, 64);
+        // D reg x of lane (r = beam, hh): key k0 + (x & 3) + 8 (x >> 2) + 4 hh
+        float m = NEG_INF;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            if (!whole && k0 + (x & 3) + 8 * (x >> 2) + 4 * hh >= a.prefix_len) s[x] = NEG_INF;
+            m = fmaxf(m, s[x]);
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));                 // the beam's other key half; finite: key k0 < prefix_len
+        float l = 0.f;
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {
+            s[x] = vh_exp2(s[x] - m);
+            l += s[x];
+        }
+        l += __shfl_xor(l, 32, 64);
+        f32x16 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o0[e] = 0.f; o1[e] = 0.f; }
+#pragma unroll
+        for (int x = 0; x < 16; ++x) {                       // O^T += V^T P^T: P^T is the B operand as it lies
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[0][x], s[x], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[1][x], s[x], o1, 0, 0, 0);
+        }
         if (qb * 32 + r < a.B) {
-            float* pr = a.partial + (((int64_t)b * a.n_heads + head) * a.n_tot + chunk) * PART_LD;
+            float* pr = a.partial + (((int64_t)b * a.n_heads + head) * a.n_tot + blk) * PART_LD;
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4)
-                    st4(pr + 32 * db + 8 * g4 + 4 * hh,
-                        f32x4{oacc[db][4 * g4], oacc[db][4 * g4 + 1], oacc[db][4 * g4 + 2], oacc[db][4 * g4 + 3]});
-            if (hh == 0) { pr[HD] = m; pr[HD + 1] = l_tot; }
+            for (int g4 = 0; g4 < 4; ++g4) {
+                st4(pr + 8 * g4 + 4 * hh, f32x4{o0[4 * g4], o0[4 * g4 + 1], o0[4 * g4 + 2], o0[4 * g4 + 3]});
+                st4(pr + 32 + 8 * g4 + 4 * hh, f32x4{o1[4 * g4], o1[4 * g4 + 1], o1[4 * g4 + 2], o1[4 * g4 + 3]});
+            }
+            if (hh == 0) { pr[HD] = m; pr[HD + 1] = l; }
         }
     }
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_suffix_kernel(
-    const float* __restrict__ q, int ldq, const float* __restrict__ kc, const float* __restrict__ vc,
-    float* __restrict__ out, int ldo, const int32_t* __restrict__ suffix_len, int len_bias, int n_heads, int S_suf,
-    int n_split, int n_prefix, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void attn_shared_kernel(SharedArgs a) {
+    constexpr int NW = 4;
     __shared__ float s_m[NW], s_l[NW];
     __shared__ __attribute__((aligned(16))) float s_o[NW][HD];
-    const int bh = blockIdx.y, b = bh / n_heads, head = bh - b * n_heads;
-    const int split = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if ((int)blockIdx.x < a.prefix_wgs) {                    // workgroup-uniform
+        shared_prefix_role(a, blockIdx.x, lane, w);
+        return;
+    }
+    // ---- suffix role: (beam, head) x key split over the beam's own rows (the burst kernel's body)
+    const int unit = blockIdx.x - a.prefix_wgs;
+    const int split = unit % a.n_split, bh = unit / a.n_split;
+    const int b = bh / a.n_heads, head = bh - b * a.n_heads;
     const int c16 = lane & 15, g = lane >> 4;
-    const int len = suffix_len[b] + len_bias;
+    const int len = a.suffix_len[b] + a.len_bias;
     const int nchunks = (len + 31) >> 5;
-    const int cps = (nchunks + n_split - 1) / n_split;
+    const int cps = (nchunks + a.n_split - 1) / a.n_split;
     const int c_begin = split * cps, c_end = min(nchunks, c_begin + cps);
     const float qscale = 0.125f * LOG2E;
-    const f32x4 q4 = ld4(q + (int64_t)b * ldq + head * HD + 4 * c16) * qscale;
-    const float* kb = kc + (int64_t)bh * S_suf * HD + 4 * c16;
-    const float* vb = vc + (int64_t)bh * S_suf * HD + 4 * c16;
+    const f32x4 q4 = ld4(a.q + (int64_t)b * a.ldq + head * HD + 4 * c16) * qscale;
+    const float* kb = a.ks + (int64_t)bh * a.S_suf * HD + 4 * c16;
+    const float* vb = a.vs + (int64_t)bh * a.S_suf * HD + 4 * c16;
     float m = NEG_INF, l = 0.f;
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-    for (int c = c_begin + w; c < c_end; c += NW) {
+    // two register sets: the next chunk of the wave is requested before the current one is reduced (rows beyond the length
+    // are clamped to the row's last key and masked below: no load is predicated)
+    f32x4 kf[2][8], vf[2][8];
+    auto load = [&](int c, f32x4 (&kq)[8], f32x4 (&vq)[8]) {
         const int key0 = c * 32 + g;
-        f32x4 kf[8], vf[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int key = key0 + 4 * i;
-            const bool in = key < len;
-            kf[i] = in ? ld4(kb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
-            vf[i] = in ? ld4(vb + (int64_t)key * HD) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const int key = min(key0 + 4 * i, len - 1);
+            kq[i] = ld4(kb + (int64_t)key * HD);
+            vq[i] = ld4(vb + (int64_t)key * HD);
         }
-        float s[8];
+    };
+    auto reduce = [&](int c, const f32x4 (&kq)[8], const f32x4 (&vq)[8]) {
+        const int key0 = c * 32 + g;
+        float sc[8];
         float cmax = NEG_INF;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const f32x4 t = kf[i] * q4;
+            const f32x4 t = kq[i] * q4;
             const float d = row16_sum((t.x + t.y) + (t.z + t.w));
-            s[i] = (key0 + 4 * i < len) ? d : NEG_INF;
-            cmax = fmaxf(cmax, s[i]);
+            sc[i] = (key0 + 4 * i < len) ? d : NEG_INF;
+            cmax = fmaxf(cmax, sc[i]);
         }
         cmax = fmaxf(cmax, __shfl_xor(cmax, 16, 64));
         cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-        const float m_new = fmaxf(m, cmax);
+        const float m_new = fmaxf(m, cmax);                  // finite: chunk c < nchunks holds >= 1 valid key
         const float alpha = vh_exp2(m - m_new);
         o *= alpha;
         l *= alpha;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float p = vh_exp2(s[i] - m_new);
+            const float p = vh_exp2(sc[i] - m_new);          // 0 for a masked key (its clamped V row is finite)
             l += p;
-            o += vf[i] * p;
+            o += vq[i] * p;
         }
         m = m_new;
+    };
+    if (c_begin + w < c_end) load(c_begin + w, kf[0], vf[0]);
+    for (int c = c_begin + w; c < c_end; c += 2 * NW) {
+        if (c + NW < c_end) load(c + NW, kf[1], vf[1]);
+        reduce(c, kf[0], vf[0]);
+        if (c + NW < c_end) {
+            if (c + 2 * NW < c_end) load(c + 2 * NW, kf[0], vf[0]);
+            reduce(c + NW, kf[1], vf[1]);
+        }
     }
 #pragma unroll
     for (int sh = 16; sh <= 32; sh <<= 1) {
@@ -1734,44 +1745,60 @@ __global__ __launch_bounds__(NW * 64) void attn_suffix_kernel(
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
         const float wgt = s_m[k] == NEG_INF ? 0.f : vh_exp2(s_m[k] - M);      // (a wave without a chunk; M itself is -inf
-        L += s_l[k] * wgt;                                                    //  only for an empty split of a split launch)
+        L += s_l[k] * wgt;                                                    //  only for an empty split)
         O += s_o[k][tid] * wgt;
     }
-    const int n_tot = n_prefix + n_split;
-    float* pr = partial + (int64_t)bh * n_tot * PART_LD;
-    if (n_split > 1) {                       // the record joins the prefix records; attn_decode_combine_kernel merges all
-        pr[(n_prefix + split) * PART_LD + tid] = O;
-        if (tid == 0) { pr[(n_prefix + split) * PART_LD + HD] = M; pr[(n_prefix + split) * PART_LD + HD + 1] = L; }
-        return;
-    }
-    // one suffix split: merge the prefix records of this (beam, head) in chunk order, then the beam's own rows
-    float Mx = M;
-    for (int k = 0; k < n_prefix; ++k) Mx = fmaxf(Mx, pr[k * PART_LD + HD]);
-    float Lx = 0.f, Ox = 0.f;
-    for (int k = 0; k < n_prefix; ++k) {
-        const float wgt = vh_exp2(pr[k * PART_LD + HD] - Mx);
-        Lx += pr[k * PART_LD + HD + 1] * wgt;
-        Ox += pr[k * PART_LD + tid] * wgt;
-    }
-    const float wgt = M == NEG_INF ? 0.f : vh_exp2(M - Mx);
-    Lx += L * wgt;
-    Ox += O * wgt;
-    out[(int64_t)b * ldo + head * HD + tid] = Ox / Lx;
+    float* pr = a.partial + ((int64_t)bh * a.n_tot + a.n_pb + split) * PART_LD;
+    pr[tid] = O;
+    if (tid == 0) { pr[HD] = M; pr[HD + 1] = L; }
 }
 
-// key chunks of the prefix: 32-key blocks dealt to at most ~512 / n_heads workgroups per head (one wave each)
-static int prefix_chunks(int prefix_len, int n_heads, int* blocks_per_chunk) {
-    const int blocks = (prefix_len + 31) / 32;
-    const int target = max(1, min(64, 512 / max(n_heads, 1)));
-    const int bpc = (blocks + target - 1) / target;
-    *blocks_per_chunk = bpc;
-    return (blocks + bpc - 1) / bpc;
+// out[b, head] = merge of the n_tot records of (b, head).  256 threads: one parallel pass over the (m, l) pairs gives the
+// weights and the denominator; thread group g = tid >> 6 then sums records g, g + 4, ... of column tid & 63 (independent
+// loads, issued back to back) and the four partial sums are added in group order.
+__global__ __launch_bounds__(256) void attn_records_merge_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                                 int ldo, int n_heads, int n_tot) {
+    __shared__ float s_w[256], s_red[8], s_part[4][HD];
+    const int bh = blockIdx.x, b = bh / n_heads, head = bh - b * n_heads;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* pr = partial + (int64_t)bh * n_tot * PART_LD;
+    // ONE memory round trip: the (m, l) pair of record tid and the first eight o values of this thread's column (records
+    // w, w + 4, ..., w + 28) are requested together — the o values do not depend on the weights
+    const bool have = tid < n_tot;
+    const float mk = have ? pr[tid * PART_LD + HD] : NEG_INF;
+    const float lk = have ? pr[tid * PART_LD + HD + 1] : 0.f;
+    float a8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a8[j] = pr[min(w + 4 * j, n_tot - 1) * PART_LD + lane];
+    const float wm = wave_max(mk);
+    if (lane == 0) s_red[w] = wm;
+    __syncthreads();
+    const float M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));   // finite: the prefix holds >= 1 key
+    const float wk = mk == NEG_INF ? 0.f : vh_exp2(mk - M);
+    s_w[tid] = wk;                                           // (0 beyond n_tot: the clamped loads above weigh nothing)
+    const float ws = wave_sum(lk * wk);
+    if (lane == 0) s_red[4 + w] = ws;
+    __syncthreads();
+    const float L = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += a8[j] * s_w[w + 4 * j];
+    for (int k = w + 32; k < n_tot; k += 16) {               // longer prompts: four more independent loads per pass
+        const float a0 = pr[k * PART_LD + lane], a1 = pr[min(k + 4, n_tot - 1) * PART_LD + lane];
+        const float a2 = pr[min(k + 8, n_tot - 1) * PART_LD + lane], a3 = pr[min(k + 12, n_tot - 1) * PART_LD + lane];
+        acc += a0 * s_w[k];
+        acc += a1 * s_w[min(k + 4, 255)];
+        acc += a2 * s_w[min(k + 8, 255)];
+        acc += a3 * s_w[min(k + 12, 255)];
+    }
+    s_part[w][lane] = acc;
+    __syncthreads();
+    if (tid < HD) out[(int64_t)b * ldo + head * HD + tid] = ((s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid])) / L;
 }
 
 extern "C" size_t vh_attn_decode_shared_ws_bytes(int B, int n_heads, int prefix_len, int n_split_suffix) {
     if (B <= 0 || n_heads <= 0 || prefix_len <= 0 || n_split_suffix < 1) return 0;
-    int bpc;
-    const int n_tot = prefix_chunks(prefix_len, n_heads, &bpc) + n_split_suffix;
+    const int n_tot = (prefix_len + 31) / 32 + n_split_suffix;
     return (size_t)B * n_heads * n_tot * PART_LD * sizeof(float);
 }
 
@@ -1785,6 +1812,9 @@ extern "C" int vh_attn_decode_shared(const float* q, int ldq, const float* kpref
                    n_split_suffix >= 1 && n_split_suffix <= 64, VH_EINVAL,
                "vh_attn_decode_shared: bad dims B=%d h=%d prefix=%d/%d S_suf=%d n_split=%d", B, n_heads, prefix_len, prefix_S,
                S_suf, n_split_suffix);
+    const int n_pb = (prefix_len + 31) / 32, n_tot = n_pb + n_split_suffix;
+    VH_REQUIRE(n_tot <= 256, VH_EUNSUPPORTED, "vh_attn_decode_shared: %d prefix blocks + %d splits exceed the 256 records one merge serves",
+               n_pb, n_split_suffix);
     VH_REQUIRE(len_bias == 0 || len_bias == 1, VH_EINVAL, "vh_attn_decode_shared: len_bias=%d", len_bias);
     VH_REQUIRE(ldq % 4 == 0 && ldq >= n_heads * HD && ldo >= n_heads * HD, VH_EINVAL, "vh_attn_decode_shared: ldq=%d ldo=%d", ldq, ldo);
     VH_REQUIRE(vh_aligned16(q) && vh_aligned16(kprefix) && vh_aligned16(vprefix) && vh_aligned16(ksuffix) &&
@@ -1793,23 +1823,14 @@ extern "C" int vh_attn_decode_shared(const float* q, int ldq, const float* kpref
                "vh_attn_decode_shared: workspace of %zu bytes, need %zu", partial_bytes,
                vh_attn_decode_shared_ws_bytes(B, n_heads, prefix_len, n_split_suffix));
     hipStream_t s = (hipStream_t)stream;
-    int bpc;
-    const int n_prefix = prefix_chunks(prefix_len, n_heads, &bpc);
-    const int n_tot = n_prefix + n_split_suffix;
-    PrefixArgs pa{q, ldq, kprefix, vprefix, prefix_len, prefix_S, (float*)partial, n_heads, B, n_tot, bpc};
-    // (events of vh_ar_decoder_profile_attn bracket the prefix launch: the step's dominant attention kernel in this form)
-    hipExtLaunchKernelGGL(attn_prefix_kernel, dim3(n_prefix, n_heads), dim3(64), 0, s, g_attn_ev[0], g_attn_ev[1], 0, pa);
-    dim3 grid(n_split_suffix, B * n_heads);
-#define SUF(NW) hipLaunchKernelGGL((attn_suffix_kernel<NW>), grid, dim3(NW * 64), 0, s, q, ldq, ksuffix, vsuffix, out, ldo, \
-                                   suffix_len, len_bias, n_heads, S_suf, n_split_suffix, n_prefix, (float*)partial)
-    const int per_split = (S_suf + n_split_suffix - 1) / n_split_suffix;
-    if (per_split <= 640) SUF(4);
-    else if (per_split <= 2048) SUF(8);
-    else SUF(16);
-#undef SUF
-    if (n_split_suffix > 1)
-        hipLaunchKernelGGL(attn_decode_combine_kernel, dim3(B * n_heads), dim3(64), 0, s, (const float*)partial, out, ldo,
-                           n_heads, n_tot);
+    const int prefix_wgs = (n_pb + 3) / 4 * n_heads;
+    SharedArgs a{q, ldq, kprefix, vprefix, prefix_len, prefix_S, ksuffix, vsuffix, suffix_len, len_bias, S_suf, n_split_suffix,
+                 (float*)partial, n_heads, B, n_pb, n_tot, prefix_wgs};
+    // (the events of vh_ar_decoder_profile_attn bracket this launch: the step's attention kernel in this form)
+    hipExtLaunchKernelGGL(attn_shared_kernel, dim3(prefix_wgs + n_split_suffix * B * n_heads), dim3(256), 0, s, g_attn_ev[0],
+                          g_attn_ev[1], 0, a);
+    hipLaunchKernelGGL(attn_records_merge_kernel, dim3(B * n_heads), dim3(256), 0, s, (const float*)partial, out, ldo, n_heads,
+                       n_tot);
     VH_CHECK_LAUNCH("vh_attn_decode_shared");
     return VH_OK;
 }
