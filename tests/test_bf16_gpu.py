@@ -144,6 +144,30 @@ def test_attn_rows_bf16(K, B, h, T, mode):
     torch.testing.assert_close(out.cpu().double(), ref, atol=6e-3, rtol=2 ** -7)
 
 
+def test_attn_rows_bf16_per_row_text_lengths(K):
+    """A ragged batch (ValleAR.generate_batch with perf_mode: per-row text length x_len_dev AND per-row key length kv_len):
+    row b's prefix-LM mask is build_attn_mask(xl[b], .) over its own kv_len[b] keys."""
+    from oracle.valle_oracle import build_attn_mask
+    B, h, T = 4, 2, 200
+    d = 64 * h
+    q = torch.randn(B, T, d, generator=g(47)).bfloat16()
+    k = torch.randn(B, h, T, 64, generator=g(48)).bfloat16()
+    v = torch.randn(B, h, T, 64, generator=g(49)).bfloat16()
+    xl = torch.tensor([10, 64, 1, 130], dtype=torch.int32)
+    kvl = torch.tensor([200, 150, 77, 131], dtype=torch.int32)
+    out = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+    K.attn_rows_bf16(q.view(B * T, d).to(DEV), k.to(DEV), v.to(DEV), out, B, h, T, T, mode=K.MASK_PREFIX, x_len_dev=xl.to(DEV),
+                     kv_len=kvl.to(DEV))
+    out = out.cpu().double().view(B, T, d)
+    for b in range(B):
+        n = int(kvl[b])
+        masked = build_attn_mask(int(xl[b]), T - int(xl[b])) | (torch.arange(T)[None, :] >= n)
+        qh = q[b].view(T, h, 64).permute(1, 0, 2).double()
+        ref = F.scaled_dot_product_attention(qh[None], k[b:b + 1].double(), v[b:b + 1].double(), attn_mask=~masked[None, None])
+        ref = ref[0].permute(1, 0, 2).reshape(T, d)
+        torch.testing.assert_close(out[b, :n], ref[:n], atol=6e-3, rtol=2 ** -7)          # rows beyond the row's length: don't care
+
+
 def test_attn_rows_bf16_peaked_softmax(K):
     """|q.k| in the hundreds at a late tile: the online-softmax rescale branch."""
     B, h, T = 1, 2, 200
@@ -207,3 +231,25 @@ def test_perf_mode_nar_big_logits_within_tolerance_of_the_reference():
         err = float((got - gold[f'logits_{stage}']).abs().max())
         print(f'perf-mode NAR stage {stage} (configs[4], 24L/1024d, 2875 positions): max |logit error| = {err:.2e}')
         assert err < 5e-2, err
+
+
+def test_perf_mode_generate_batch_ragged_rows_decode_like_the_parity_path():
+    """generate_batch(perf_mode=True) on RAGGED rows (per-row text / prompt lengths through the bf16 prompt pass, then decode
+    over the bf16 cache it wrote): on the well-separated goldens' model the greedy tokens equal the fp32 run's for (almost)
+    every row and step; the stats say which prompt pass ran."""
+    from valle2_amd import synth
+    kw = dict(C.MID, norm='LayerNorm', num_beams=1, top_k=1, max_audio_len=24)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=5, rich=True), cfg)
+    m = build('ValleAR', kw, sd)
+    utts = [synth.synth_utterance(cfg, 5 + 3 * i, 4 + i, 20 + 7 * i, seed=40 + i) for i in range(32)]     # 32 rows x 8 heads: one (row, head) per CU
+    texts = [torch.cat([u[0], u[2]]).to(DEV) for u in utts]
+    firsts = [u[1][:, 0].to(DEV) for u in utts]
+    a = m.generate_batch(texts, firsts)
+    assert not m.last_generate_stats['prefill_bf16']
+    b = m.generate_batch(texts, firsts, perf_mode=True)
+    st = m.last_generate_stats
+    assert st['prefill_bf16'] and st['kv_bf16']
+    agree = float((a == b).float().mean())
+    print(f'ragged perf-mode generate: {agree:.4f} of the tokens equal the fp32 run')
+    assert agree > 0.9

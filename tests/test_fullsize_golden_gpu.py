@@ -66,14 +66,19 @@ def test_config4_ar_leg_greedy_tokens_match_the_reference():
     kw, sd, utt = C.ar_generate_inputs('big')
     assert kw['num_layers'] == 24 and kw['d_model'] == 1024 and utt[1].shape[0] == 225 and int(gold['steps']) == 48
     m = build('ValleAR', kw, sd)
-    out = m.generate(*[u.to(DEV) for u in utt])
+    out = m.generate(*[u.to(DEV) for u in utt])       # the reference's entry point: the 8 beams share the prompt's K/V (round 5)
     st = m.last_generate_stats
-    assert st['n_split'] == 2 and st['s0'] == 626 and not st['ffn_fused']
+    assert st['shared_prompt'] and st['n_split'] == 4 and st['s0'] == 626 and not st['ffn_fused']
     tokens_match(out, gold['tokens'], gold['margin'])
     assert torch.equal(out.cpu(), gold['tokens'])
+    text = torch.cat([utt[0], utt[2]]).to(DEV)
+    # ... and the same beams as 8 independent rows: the key-split decode attention + combine launch
+    rows = m.generate_batch([text] * 8, [utt[1][:, 0].to(DEV)] * 8, max_new=48)
+    st = m.last_generate_stats
+    assert not st['shared_prompt'] and st['n_split'] == 2
+    assert torch.equal(rows[:, 226:].cpu(), gold['tokens'][None].expand(8, -1))
     # the logits the decoder's head produced on the reference's trajectory, at the steps the fixture keeps
     steps = list(range(0, 48, 6))
-    text = torch.cat([utt[0], utt[2]]).to(DEV)
     m.generate_batch([text] * 8, [utt[1][:, 0].to(DEV)] * 8, max_new=48, forced=gold['tokens'], keep_logits=steps)
     got = torch.stack([m.last_generate_stats['logits'][t][0] for t in steps]).cpu()
     torch.testing.assert_close(got, gold['logits_row0'], atol=2e-4, rtol=1e-4)

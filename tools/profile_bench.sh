@@ -7,7 +7,11 @@ set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_bench
 mkdir -p $OUT
+# the raw profiler output is large (gpurun copies at most 64 MiB back): whatever path the script leaves by, only summaries stay
+trap 'rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/mfma $OUT/train $OUT/tt $OUT/beams $OUT/bf16 $OUT/bf16m $OUT/bf16l' EXIT
 cd $R
+PART=${1:-all}          # "1": the bench line + its kernel statistics + the PMC passes; "2": the beams / perf-mode / training passes
+if [ "$PART" != "2" ]; then
 timeout -k 10 700 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 P="--no-cpu-baseline --no-traffic --no-config5 --no-beams --no-perf-mode --no-rows64"
@@ -22,6 +26,10 @@ python3 $R/tools/summarize_prof.py $OUT/write $OUT/pmc_write_size.md "rocprofv3 
 U="--steps 1 --warmup 0 --no-roofline --no-train $P --no-rows64"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/mfma -o pmc --output-format csv -- python3 $R/bench.py $U > $OUT/mfma.json 2> $OUT/mfma.err
 python3 $R/tools/summarize_prof.py $OUT/mfma $OUT/pmc_mfma_busy.md "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py $U"
+fi
+if [ "$PART" = "1" ]; then exit 0; fi
+cd /tmp && export TMPDIR=/tmp
+P="--no-cpu-baseline --no-traffic --no-config5 --no-beams --no-perf-mode --no-rows64"
 # round 5: the shared-prompt decode (the `beams` leg: generate() of one utterance with 32 beams) under the kernel trace ...
 W="--steps 1 --warmup 0 --no-nar --no-roofline --no-train --no-cpu-baseline --no-traffic --no-config5 --no-perf-mode --no-rows64 --no-default-generate"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats -d $OUT/beams -o stats --output-format csv -- python3 $R/bench.py $W > $OUT/beams.json 2> $OUT/beams.err

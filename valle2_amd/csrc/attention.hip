@@ -1690,8 +1690,8 @@ __global__ __launch_bounds__(256) void attn_shared_kernel(SharedArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int key = min(key0 + 4 * i, len - 1);
-            kq[i] = ld4(kb + (int64_t)key * HD);
-            vq[i] = ld4(vb + (int64_t)key * HD);
+            kq[i] = ld4_stream(kb + (int64_t)key * HD);      // (non-temporal: the beams' rows must not evict the weights)
+            vq[i] = ld4_stream(vb + (int64_t)key * HD);
         }
     };
     auto reduce = [&](int c, const f32x4 (&kq)[8], const f32x4 (&vq)[8]) {

@@ -406,6 +406,11 @@ class ArDecoder:
         self.B, self.V, self.d = batch, V, d
         self.ldl = (V + 3) // 4 * 4
         self.n_split = n_split or pick_n_split(batch * cfg.n_heads)
+        if prefix is not None and n_split is None:
+            # shared prompt: the beams' own rows are short streams — two workgroups per CU keep twice the loads in flight
+            # (32 beams x 8 heads: 436.8 us per step with one split, 420.9 with two, 426.9 with four;
+            # profiles/r5_ab_shared_prompt.log).  VALLE2_SHARED_SPLIT: the A/B knob.
+            self.n_split = int(os.environ.get('VALLE2_SHARED_SPLIT') or min(16, -(-512 // (batch * cfg.n_heads))))
         f32 = dict(device=dev, dtype=torch.float32)
         self.x = torch.empty(batch, d, **f32)
         self.q = torch.empty(batch, d, **f32)
