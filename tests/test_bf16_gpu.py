@@ -26,6 +26,15 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
+@pytest.fixture(params=[1, 2], ids=['two_slabs_k64', 'ring_k32'])
+def gemm_form(request):
+    """Both tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / a ring of three slabs of 32 k."""
+    from valle2_amd import _lib
+    _lib.lib().vh_set_tuning(15, request.param)
+    yield request.param
+    _lib.lib().vh_set_tuning(15, 0)
+
+
 def test_to_bf16_rounds_to_nearest_even(K):
     x = torch.randn(37, 264, generator=g(1)) * 3
     x[0, :4] = torch.tensor([1.0 + 2 ** -8, 1.0 + 3 * 2 ** -8, -0.0, 65280.0])       # exact ties, signed zero
@@ -50,8 +59,9 @@ def test_layernorm_bf16(K, rows, d, ada):
 
 @pytest.mark.parametrize('M,N,K_,out16,act,res', [
     (128, 128, 64, False, 0, False), (300, 256, 128, False, 0, True), (1000, 512, 512, True, 1, False),
-    (77, 1536, 512, False, 1, True), (4096, 512, 2048, False, 0, True), (129, 2048, 512, True, 1, False), (1, 128, 64, False, 0, False)])
-def test_linear_bf16(K, M, N, K_, out16, act, res):
+    (77, 1536, 512, False, 1, True), (4096, 512, 2048, False, 0, True), (129, 2048, 512, True, 1, False), (1, 128, 64, False, 0, False),
+    (200, 128, 192, False, 0, True), (333, 256, 320, True, 0, False)])        # K / 32 = 6, 10: every tail length of the ring
+def test_linear_bf16(K, gemm_form, M, N, K_, out16, act, res):
     a = torch.randn(M, K_, generator=g(10)).bfloat16()
     w = (0.05 * torch.randn(N, K_, generator=g(11))).bfloat16()
     bias = torch.randn(N, generator=g(12))
@@ -71,7 +81,7 @@ def test_linear_bf16(K, M, N, K_, out16, act, res):
         torch.testing.assert_close(out.cpu().double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5)
 
 
-def test_linear_bf16_integer_operands_are_exact(K):
+def test_linear_bf16_integer_operands_are_exact(K, gemm_form):
     """Small integers are exact in bf16 and their products / sums exact in fp32: any operand-layout or accumulator-map
     error shows as a wrong integer.  Asymmetric data (a[m][k] depends on m and k differently than w[n][k] on n and k)."""
     M, N, K_ = 260, 256, 192
@@ -95,7 +105,7 @@ def test_linear_bf16_refuses_shapes_outside_the_tile_kernel(K):
 
 
 @pytest.mark.parametrize('B,T,h,with_len', [(2, 5, 2, False), (3, 150, 4, True), (1, 1000, 8, False), (40, 7, 2, True)])
-def test_linear_qkv_bf16_scatter(K, B, T, h, with_len):
+def test_linear_qkv_bf16_scatter(K, gemm_form, B, T, h, with_len):
     d = 64 * h
     S_max = T + 20
     a = torch.randn(B * T, d, generator=g(20)).bfloat16()
@@ -205,6 +215,23 @@ def test_perf_mode_prefill_logits_within_tolerance_of_the_reference():
     print(f'perf-mode prefill (configs[1], 12L/512d): max |logit error| vs the reference = {err:.2e} '
           f'(parity path {float((exact[:, pos.to(DEV)].cpu() - gold["logits"]).abs().max()):.2e})')
     assert err < 5e-2, err
+
+
+def test_both_gemm_forms_give_the_same_stack_output():
+    """The two tile machines accumulate k in the same order (32x32x16 MFMAs over ascending k): the whole stack's output is
+    bit-identical between them."""
+    from valle2_amd import _lib
+    kw, sd, batch = C.nar_inputs()
+    m = build('ValleNAR', kw, sd)
+    outs = []
+    for form in (1, 2):
+        _lib.lib().vh_set_tuning(15, form)
+        try:
+            with torch.no_grad():
+                outs.append(m.stage_logits(batch, 3, perf_mode=True)[0].clone())
+        finally:
+            _lib.lib().vh_set_tuning(15, 0)
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_perf_mode_nar_stage_logits_within_tolerance_of_the_reference():
