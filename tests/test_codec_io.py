@@ -117,6 +117,8 @@ def test_model_dict_resolves_encodec_pip_lazily(monkeypatch):
     monkeypatch.setitem(sys.modules, 'encodec', fake)                  # "installed"
     cls = valle2_amd.get_model_class('EncodecPip')
     assert cls is CIO.EncodecPip
+    import valle.models
+    assert valle.models.EncodecPip is cls                              # `from valle.models import EncodecPip`, as the reference exports it
     pip = cls()                                                        # the reference's constructor: 24 kHz model at 6 kbps
     assert pip.model.bandwidth == 6.0 and pip.sampling_rate == 24000
     valle2_amd.MODEL_DICT.pop('EncodecPip', None)

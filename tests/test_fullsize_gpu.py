@@ -102,10 +102,19 @@ def test_config5_shape_24_layers_1024d():
     trace = {}
     ref = O.ar_generate(sd, cfg, *utt, trace=trace)                 # CPU oracle on the short case
     out = m.generate(*[u.to(DEV) for u in utt]).cpu()
-    assert m.last_generate_stats['n_split'] == 2                     # 8 x 16 heads → split-KV + combine
+    st = m.last_generate_stats                                       # generate(): the 8 beams share the prompt's K/V (round 5)
+    assert st['shared_prompt'] and st['n_split'] == 4                # 8 x 16 (beam, head) pairs -> 4 key splits of the beams' rows
     n = min(len(out), len(ref))
     bad = (out[:n] != ref[:n]).nonzero()
     assert len(out) == len(ref) and (bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4)
+    # the same beams as 8 independent rows: 8 x 16 heads -> split-KV decode attention + combine
+    text, first = torch.cat([utt[0], utt[2]]).to(DEV), utt[1][:, 0].to(DEV)
+    rows = m.generate_batch([text] * 8, [first] * 8).cpu()
+    assert not m.last_generate_stats['shared_prompt'] and m.last_generate_stats['n_split'] == 2
+    got = rows[0, 31:]
+    got = got[got != cfg.eos_token]
+    bad = (got[:n] != ref[:n]).nonzero()
+    assert len(got) == len(ref) and (bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4)
     # configs[4] as worded: 400 text + BOS + 225 prompt frames + 2250 new tokens → context 626 → 2876 (PE table 5000)
     texts, firsts = utterances(cfg, 8, 400, 225, 8000)
     g = m.generate_batch(texts, firsts, max_new=2250)

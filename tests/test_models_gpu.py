@@ -527,3 +527,41 @@ def test_shared_prompt_sampling_beams_diverge_and_scores_are_per_beam():
     assert torch.equal(a, b) and torch.equal(lp_a, m.last_generate_stats['sum_logprobs'])
     assert len({tuple(r.tolist()) for r in a.cpu()}) > 1, 'sampled beams must not be copies of each other'
     assert len(set(lp_a.cpu().tolist())) > 1 and bool((lp_a < 0).all())
+
+
+def test_derived_weights_live_beside_the_module_and_can_be_invalidated():
+    """Round-4 advisor finding: the AdaLN table / folded-LayerNorm caches sat in `transformer.__dict__` (weak references:
+    `torch.save(model)` failed after the first generate) and nothing told them about writes through `p.data`.  They live
+    in a WeakKeyDictionary beside the module now; `engine.invalidate_derived()` / `bump_weights_epoch()` is the hook for
+    out-of-band weight writes (an EMA swap by `p.data.copy_`)."""
+    import io
+    import pickle
+    from valle2_amd import engine
+    kw, sd, batch = C.nar_inputs()
+    m = build('ValleNAR', kw, sd)
+    with torch.no_grad():
+        a, _ = m.stage_logits(batch, 3)
+    assert '_vh_ada' not in m.transformer.__dict__ and '_vh_folded' not in m.transformer.__dict__
+    pickle.dumps(m)                                                   # (weak references in the module would raise here)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    assert m.transformer in engine._DERIVED and 'ada' in engine._DERIVED[m.transformer]
+    # an out-of-band write: p.data moves neither the tensor's identity nor its version counter
+    proj = m.transformer.layers[0].norm1.project_layer
+    v0 = proj.weight._version
+    proj.weight.data.mul_(1.5)
+    assert proj.weight._version == v0
+    with torch.no_grad():
+        stale, _ = m.stage_logits(batch, 3)
+        engine.invalidate_derived(m.transformer)
+        fresh, _ = m.stage_logits(batch, 3)
+    assert torch.equal(stale, a), 'the cache cannot see a p.data write (documented): same table, same logits'
+    assert not torch.equal(fresh, a), 'after invalidate_derived the table is rebuilt from the new weights'
+    ref = build('ValleNAR', kw, {k: (v * 1.5 if k == 'transformer.layers.0.norm1.project_layer.weight' else v) for k, v in sd.items()})
+    with torch.no_grad():
+        want, _ = ref.stage_logits(batch, 3)
+    assert torch.equal(fresh, want)
+    del m
+    import gc
+    gc.collect()
+    assert all(k is not None for k in list(engine._DERIVED.keys()))     # entries die with their modules
