@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 121            /* 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 122            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -331,6 +331,19 @@ int vh_greedy_step(const float* logits, int ldl, int V, int eos, int64_t* codes,
                    const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len,
                    float* x_next, int B, int d, void* stream);
 
+/* ---- K11 + K12/K13 in ONE launch (opt-in; DESIGN.md 3.20 has the A/B) -----------------------------
+ * logits[b,:V] = x[b,:] . proj_w^T (the head: no bias, valle_ar.py:29,158) and, in the same launch, everything
+ * vh_greedy_step does with them: every 16-column workgroup publishes its (largest logit, lowest column) per row, the
+ * last workgroup to arrive per group of rows picks the tokens, does the EOS bookkeeping and builds x_next.  Same
+ * results as vh_linear + vh_greedy_step bit for bit (the logits are the same sums, the arg-max has the same tie rule).
+ * B <= 64, d in {128, 256, 512, 1024}; x_next may be x.  workspace: vh_head_greedy_ws_bytes(B, V) bytes, 16-byte
+ * aligned, ZEROED once before the first call (the launches leave it zeroed where it matters). */
+size_t vh_head_greedy_ws_bytes(int B, int V);
+int vh_head_greedy(const float* x, int ldx, const float* proj_w, float* logits, int ldl, int V, int eos,
+                   int64_t* codes, int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
+                   const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len, float* x_next,
+                   int B, int d, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- K12 (stochastic): temperature / top-k / top-p sampling + the same state update ----------
  * replaces topk_sampling (valle/models/utils.py:46-68) incl. the published semantics of
  * transformers==4.38.2 top_k_top_p_filtering (top-k keeps ties of the k-th score, top_k <= 0 keeps
@@ -395,6 +408,10 @@ typedef struct {
      * bytes (attn_partial_bytes says how many it holds).  Not with kv_bf16. */
     int prefix_len, prefix_S;
     size_t attn_partial_bytes;
+    /* optional (opt-in): zeroed workspace of vh_head_greedy_ws_bytes(B, V) bytes; with it and top_k == 1 the head and the
+     * greedy step are ONE launch (vh_head_greedy) instead of vh_linear + vh_greedy_step. */
+    void *head_ws;
+    size_t head_ws_bytes;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

@@ -132,6 +132,16 @@ int main() {
     REFUSED(vh_greedy_step(nullptr, 8, 8, 7, I64, 4, I32, nullptr, P, P, I32, I32, P, 1, 64, S));
     REFUSED(vh_greedy_step(P, 4, 8, 7, I64, 4, I32, nullptr, P, P, I32, I32, P, 1, 64, S));       // ldl < V
     REFUSED(vh_greedy_step(P, 8, 8, 7, I64, 4, I32, nullptr, P, MIS, I32, I32, P, 1, 64, S));
+    REFUSED(vh_head_greedy(nullptr, 128, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 128, P, 1 << 20, S));
+    REFUSED(vh_head_greedy(P, 128, P, P, 1024, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 128, P, 1 << 20, S));   // ldl < V
+    REFUSED(vh_head_greedy(P, 192, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 192, P, 1 << 20, S));   // d = 192
+    REFUSED(vh_head_greedy(P, 128, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 65, 128, P, 1 << 20, S));  // B > 64
+    REFUSED(vh_head_greedy(P, 128, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 128, P, 256, S));       // workspace too small
+    REFUSED(vh_head_greedy(P, 128, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 128, nullptr, 1 << 20, S));
+    REFUSED(vh_head_greedy(P, 128, P, P, 1028, 1025, 1024, I64, 80, I32, nullptr, P, P, I32, I32, P, 4, 128, MIS, 1 << 20, S)); // workspace alignment
+    for (int B : {-1, 0, 1, 32, 64})
+        for (int V : {0, 1, 16, 17, 1025, 2048})
+            EXPECT(vh_head_greedy_ws_bytes(B, V) == (B > 0 && V > 0 ? 256 + (size_t)B * ((V + 15) / 16) * 8 : 0), "head workspace B=%d V=%d", B, V);
     REFUSED(vh_sample_step(nullptr, 8, 8, 7, 5, 1.f, 1.f, 1, I64, 4, I32, nullptr, P, P, P, I32, I32, P, 1, 64, S));
     REFUSED(vh_sample_step(P, 8, 8, 7, 5, 1.f, 0.f, 1, I64, 4, I32, nullptr, P, P, P, I32, I32, P, 1, 64, S));      // temperature 0
     REFUSED(vh_sample_step(P, 4096, 4096, 7, 5, 1.f, 1.f, 1, I64, 4, I32, nullptr, P, P, P, I32, I32, P, 1, 64, S)); // V > 2048
@@ -279,6 +289,8 @@ int main() {
     bad = dd; bad.ffn_ws = P; bad.ffn_ws_bytes = 1 << 26; EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "folded"), "ffn workspace without folded weights");
     bad = dd; bad.kv_bf16 = 1;   EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "folded"), "bf16 cache without folded weights");
     bad = dd; bad.top_k = 50; bad.temperature = 0.f; EXPECT(vh_ar_decoder_create(&bad) == nullptr, "sampling at temperature 0");
+    bad = dd; bad.head_ws = P; bad.head_ws_bytes = 64; EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "head_ws"), "head workspace too small");
+    bad = dd; bad.head_ws = P; bad.head_ws_bytes = 1 << 20; bad.top_k = 50; EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "head_ws"), "head workspace with sampling");
     bad = dd; bad.prefix_len = -3; EXPECT(vh_ar_decoder_create(&bad) == nullptr, "negative prefix");
     bad = dd; bad.prefix_len = 100; bad.prefix_S = 128; bad.attn_partial = P; bad.attn_partial_bytes = 1 << 24;
     EXPECT(vh_ar_decoder_create(&bad) == nullptr && strstr(vh_last_error(), "kprefix"), "shared prompt without prefix caches");

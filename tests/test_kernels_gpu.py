@@ -731,6 +731,50 @@ def test_greedy_step(K):
     assert torch.equal(x.cpu(), emb[exp] + pe[4, 0])
 
 
+@pytest.mark.parametrize('B,d,V', [(1, 512, 1025), (5, 128, 1025), (16, 512, 1025), (17, 256, 1025), (24, 512, 1025), (32, 512, 1025),
+                                   (32, 1024, 1025), (40, 512, 1025), (64, 512, 1025), (7, 128, 37), (32, 512, 2048)])
+def test_head_greedy_one_launch_equals_head_then_greedy_step(K, B, d, V):
+    """vh_head_greedy (the head product with the greedy step in the same launch, valle_ar.py:158-171) against vh_linear +
+    vh_greedy_step on the same operands: logits, tokens, counters, positions and the next input rows bit for bit — over three
+    consecutive steps in place (x_next = x, as the decoder runs it; the arrival counters must come back to zero), with tied
+    logits (duplicate head rows: the lowest column wins), a row that emits EOS and a row that had already finished."""
+    eos = V - 1
+    gen = g(900 + B + d + V)
+    w = 0.05 * torch.randn(V, d, generator=gen)
+    if V > 900:
+        w[900] = w[7]                               # columns 7 and 900 tie in every row
+    emb = torch.randn(V + 1, d, generator=gen)
+    from valle2_amd.synth import sinusoid_table
+    pe = sinusoid_table(d, 64)[:, 0].contiguous()
+    x0 = torch.randn(B, d, generator=gen)
+    if B > 2:
+        x0[2] = 40.0 * w[eos] / w[eos].norm()       # row 2 emits EOS at the first step
+    codes = torch.zeros(B, 20, dtype=torch.int64)
+    codes[:, :4] = torch.randint(0, V - 1, (B, 4), generator=gen)
+    if B > 3:
+        codes[3, 3] = eos                           # an already finished row keeps EOS
+    ldl = (V + 3) // 4 * 4
+
+    def state():
+        return dict(x=x0.clone().to(DEV), logits=torch.zeros(B, ldl, device=DEV), codes=codes.clone().to(DEV),
+                    cnt=torch.zeros(21, dtype=torch.int32, device=DEV), apos=torch.full((B,), 4, dtype=torch.int32, device=DEV),
+                    clen=(10 + torch.arange(B, dtype=torch.int32)).to(DEV))
+    wd, embd, ped = w.to(DEV), emb.to(DEV), pe.to(DEV)
+    a, b = state(), state()
+    ws = K.head_greedy_ws(B, V, DEV)
+    for step in range(3):
+        K.linear(a['x'], wd, None, out=a['logits'][:, :V])
+        K.greedy_step(a['logits'], V, eos, a['codes'], a['cnt'], embd, ped, a['apos'], a['clen'], a['x'])
+        K.head_greedy(b['x'], wd, b['logits'], V, eos, b['codes'], b['cnt'], embd, ped, b['apos'], b['clen'], b['x'], ws)
+        for k in a:
+            assert torch.equal(a[k][:, :V] if k == 'logits' else a[k], b[k][:, :V] if k == 'logits' else b[k]), (step, k)
+        assert int(ws[:64].abs().sum()) == 0, 'arrival counters not reset'
+    if V > 900:
+        assert not (b['codes'][:, 4:7] == 900).any()
+    if B > 3:
+        assert b['codes'][2, 4:7].tolist() == [eos] * 3 and b['codes'][3, 4:7].tolist() == [eos] * 3
+
+
 def _ffn_ref(x, gm, bt, w1, b1, w2, b2):
     return x + F.linear(F.gelu(F.linear(F.layer_norm(x, (x.shape[1],), gm, bt, 1e-5), w1, b1)), w2, b2)
 

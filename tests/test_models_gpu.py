@@ -257,6 +257,46 @@ def test_ar_generate_golden_every_decode_engine(fold, fused):
         _lib.lib().vh_set_tuning(5, 0)
 
 
+@pytest.mark.parametrize('graph', [True, False])
+def test_head_and_greedy_step_in_one_launch_same_tokens(monkeypatch, graph):
+    """VALLE2_HEAD_FUSED=1 (vh_head_greedy: the head's 16-column workgroups publish their candidates, the last arriver does
+    the greedy step): the reference's greedy tokens on every ar_generate_* golden (shared prompt), and
+    ragged independent rows equal to the two-launch form token for token."""
+    from valle2_amd import synth
+    monkeypatch.setenv('VALLE2_HEAD_FUSED', '1')
+    for which in ('tiny', 'mid'):
+        gold = load_golden(f'ar_generate_{which}')
+        kw, sd, utt = C.ar_generate_inputs(which)
+        m = build('ValleAR', kw, sd)
+        if graph:
+            out = m.generate(*[u.to(DEV) for u in utt])
+        else:
+            beams = m.config.num_beams
+            rows = m.generate_batch([torch.cat(utt[0::2])] * beams, [utt[1][:, 0]] * beams, use_graph=False)
+            out = rows[0, utt[1].shape[0] + 1:]
+        assert m.last_generate_stats['head_fused']
+        tokens_match(out, gold['tokens'], gold['margin'])
+    gold = load_golden('ar_generate_eos')
+    kw, sd, utt = C.ar_eos_inputs(gold['eos_row'])
+    m = build('ValleAR', kw, sd)
+    assert torch.equal(m.generate(*[u.to(DEV) for u in utt]).cpu(), gold['tokens'])
+    assert m.last_generate_stats['head_fused'] and m.last_generate_stats['tokens_appended'] == int(gold['steps']) - 1
+    kw = dict(d_model=256, n_heads=4, dim_feedforward=1024, num_layers=3, dropout=0.0, norm='LayerNorm', num_beams=1, top_k=1,
+              max_audio_len=24)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=17, rich=True, std=0.15), cfg)
+    utts = [synth.synth_utterance(cfg, 5 + r % 4, 6 + r % 5, 21, seed=950 + r) for r in range(40)]
+    m = build('ValleAR', kw, sd)
+    texts = [torch.cat([u[0], u[2]]).to(DEV) for u in utts]
+    prompts = [u[1][:, 0].to(DEV) for u in utts]
+    fused = m.generate_batch(texts, prompts, use_graph=graph)
+    assert m.last_generate_stats['head_fused']
+    monkeypatch.setenv('VALLE2_HEAD_FUSED', '0')
+    plain = m.generate_batch(texts, prompts, use_graph=graph)
+    assert not m.last_generate_stats['head_fused']
+    assert torch.equal(fused, plain)
+
+
 @pytest.mark.parametrize('rows', [5, 40])
 def test_fused_feedforward_same_tokens_graph_and_eager(rows):
     """vh_ffn_decode against the three-launch FeedForward inside the decoder: ragged rows, graph replay and eager

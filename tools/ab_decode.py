@@ -26,6 +26,7 @@ def main(rounds=8):
     # name -> {tuning knob: value} (include/valle_hip.h: 5 = FeedForward fused / three launches, 7 = slice width,
     # 8 = rows per workgroup, 0 = decode attention variant)
     forms = {'default': {},
+             'head + greedy step in one launch': {'env': {'VALLE2_HEAD_FUSED': '1'}},
              'perf mode (bf16 K/V cache)': {'perf': 1},
              'ffn three launches': {5: 1},
              'qkv statistics from row loads': {9: 1},
@@ -41,16 +42,32 @@ def main(rounds=8):
         for name, knobs in forms.items():
             for k in (0, 5, 7, 8, 9):
                 lib.vh_set_tuning(k, knobs.get(k, 0))
+            os.environ.update(knobs.get('env', {}))
             out = m.generate_batch(texts, firsts, perf_mode=bool(knobs.get('perf')))
             torch.cuda.synchronize()
             if r:
                 res[name].append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
             outs[name] = out
+            if 'head' in name:                       # the same A/B for the beams of ONE utterance (generate(): shared prompt)
+                sh = m.generate_batch([texts[0]] * 32, [firsts[0]] * 32, shared_prompt=True)
+                torch.cuda.synchronize()
+                if r:
+                    res.setdefault(name + ' | shared prompt', []).append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
+                outs[name + ' | shared prompt'] = sh
+            for k in knobs.get('env', {}):
+                os.environ.pop(k)
+            if name == 'default':
+                sh = m.generate_batch([texts[0]] * 32, [firsts[0]] * 32, shared_prompt=True)
+                torch.cuda.synchronize()
+                if r:
+                    res.setdefault('default | shared prompt', []).append(m.last_generate_stats['decode_ms'] / 511 * 1e3)
+                outs['default | shared prompt'] = sh
     for k in (0, 5, 7, 8, 9):
         lib.vh_set_tuning(k, 0)
     for name, v in res.items():
         print(f'{name:46s} decode step {statistics.median(v):7.2f} us (min {min(v):7.2f}, max {max(v):7.2f}, n={len(v)})')
-    print('same tokens:', all(bool(torch.equal(outs['default'], o)) for o in outs.values()))
+    print('same tokens:', all(bool(torch.equal(outs['default | shared prompt' if 'shared' in k else 'default'], o))
+                              for k, o in outs.items()))
 
 
 if __name__ == '__main__':

@@ -53,6 +53,7 @@ class VhArDecoderDesc(C.Structure):
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t), ('kv_bf16', C.c_int),
         ('prefix_len', C.c_int), ('prefix_S', C.c_int), ('attn_partial_bytes', C.c_size_t),
+        ('head_ws', C.c_void_p), ('head_ws_bytes', C.c_size_t),
     ]
 
 
@@ -143,6 +144,10 @@ SIGNATURES = {
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'vh_greedy_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
                                  c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    'vh_head_greedy_ws_bytes': (C.c_size_t, [C.c_int, C.c_int]),
+    'vh_head_greedy': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_i64p, C.c_int64, c_i32p,
+                                 c_i32p, c_f32p, c_f32p, c_i32p, c_i32p, c_f32p, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
                                  C.c_void_p]),
     'vh_sample_step': (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_uint64,
                                  c_i64p, C.c_int64, c_i32p, c_i32p, c_f32p, c_f32p, c_f32p, c_i32p, c_i32p,

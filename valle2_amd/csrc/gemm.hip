@@ -61,8 +61,28 @@ struct GemmArgs {
 #endif
 
 enum { EPI_PLAIN = 0, EPI_QKV = 1, EPI_PARTIAL = 2,
-       EPI_QKV16 = 3 /* EPI_QKV with the K / V rows appended as bf16 (perf mode of the decode step; skinny kernels only) */ };
+       EPI_QKV16 = 3 /* EPI_QKV with the K / V rows appended as bf16 (perf mode of the decode step; skinny kernels only) */,
+       EPI_HEAD = 4  /* the AR head with the greedy step in the same launch (vh_head_greedy; gemm_skinny_fast, MT = 1 only) */ };
 #define IS_QKV(E) ((E) == EPI_QKV || (E) == EPI_QKV16)
+
+// What the greedy step needs beside the head product (vh_head_greedy): the operands of greedy_step_kernel
+// (elementwise.hip) + the hand-over area of the launch — one (logit, column) candidate per (row, 16-column block)
+// and one arrival counter per row group.
+struct HeadStep {
+    uint64_t* cand;          // [rows][gridDim.x] (float bits << 32 | column), written and read at agent scope
+    int* counters;           // [gridDim.z], zero between launches (the last arriver of a group resets its own)
+    int V, eos;
+    int64_t* codes;
+    int64_t codes_stride;
+    int32_t* eos_count;
+    const int32_t* pos_base;
+    const float* audio_emb;
+    const float* pe;
+    int32_t* audio_pos;
+    int32_t* cache_len;
+    float* x_next;
+    int d;
+};
 
 // fp32 -> bf16, round to nearest even (finite inputs)
 __device__ __forceinline__ uint32_t vh_bf16_bits(float x) {
@@ -880,7 +900,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //         fresh data of the previous launch, written on other XCDs, and every KB a workgroup pulls of them costs
 //         (profiles/r3_probe_launch_floor.log: ~16 GB/s per CU); one-pass sums about the row's first element.
 template <int MT, int NW, int EPI, int PW, int LN, int NJ>
-__device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
+__device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadStep* hs = nullptr) {
+    const int hr0 = (EPI == EPI_HEAD && gridDim.z > 1) ? (int)blockIdx.z * a.rg_rows : 0;   // first row of this group
     // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
     // pulls the same weights but only its share of the activation rows through its L1 (the rows are two
     // thirds of the bytes a 16-column workgroup loads).  Implemented by rebasing the row pointers.
@@ -1067,7 +1088,29 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
             sacc = (sacc - mu * e_c1) * rs;  // e_bias = c2 is added below
             if (IS_QKV(EPI)) sacc += e_bias;
         }
-        if (!fin || EPI == EPI_PARTIAL) {
+        if constexpr (EPI == EPI_HEAD) {
+            // the logits (no bias, activation or residual: valle_ar.py:29,158) and this workgroup's candidate per row:
+            // the largest of its 16 columns, lowest column on ties (greedy_step_kernel's rule); -0 counts as +0
+            float bv = -INFINITY;
+            int bi = 0x7fffffff;
+            if (em < a.M) {
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    if (en + jj < a.N) {
+                        a.out[(int64_t)em * a.ldo + en + jj] = sacc[jj];
+                        if (sacc[jj] > bv) { bv = sacc[jj]; bi = en + jj; }
+                    }
+            }
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {               // the four column quads of row i sit in lanes i + 16 g
+                const float ov = __shfl_xor(bv, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (g == 0 && em < a.M)
+                __hip_atomic_store(hs->cand + (int64_t)(hr0 + em) * gridDim.x + blockIdx.x,
+                                   ((uint64_t)__float_as_uint(bv) << 32) | (uint32_t)bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (!fin || EPI == EPI_PARTIAL) {
             store4<EPI>(a, em, en, sacc);          // ragged last column group / raw partial
         } else if (EPI == EPI_PLAIN) {
             sacc += e_bias;
@@ -1096,6 +1139,58 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln) {
         }
     }
     STAMP(5);
+    if constexpr (EPI == EPI_HEAD) {
+        // The greedy step without a second launch: every workgroup has published its candidates (write-through stores,
+        // counted in vmcnt) and takes a ticket on its row group's counter; the LAST one to arrive picks every row's token
+        // from the gridDim.x candidates, does the EOS bookkeeping and the append, and builds the next step's input rows
+        // (what greedy_step_kernel does).  Nobody waits for anybody.  x_next may be the operand A itself: a row group's
+        // rows are read by its own workgroups only, and all of them are past their loads once the last ticket is taken.
+        static_assert(MT == 1 && NW == 8, "head + greedy step: 16 rows x 32 threads");
+        __shared__ int s_ticket, s_tok[16], s_pos[16];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) s_ticket = atomicAdd(hs->counters + blockIdx.z, 1);
+        __syncthreads();
+        if (s_ticket != (int)gridDim.x - 1) return;
+        if (tid == 0) hs->counters[blockIdx.z] = 0;          // ready for the next launch (graph replay)
+        const int row = tid >> 5, j = tid & 31;
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        if (row < a.M)
+            for (int c = j; c < (int)gridDim.x; c += 32) {
+                const uint64_t p = __hip_atomic_load(hs->cand + (int64_t)(hr0 + row) * gridDim.x + c, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+                const float v = __uint_as_float((uint32_t)(p >> 32));
+                const int idx = (int)(uint32_t)p;
+                if (v > bv || (v == bv && idx < bi)) { bv = v; bi = idx; }
+            }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (j == 0 && row < a.M) {
+            const int b = hr0 + row;
+            const int pos = hs->audio_pos[b];
+            int64_t* crow = hs->codes + (int64_t)b * hs->codes_stride;
+            int tok = min(bi, hs->V - 1);                     // a row of NaNs has no candidate: stay inside the table
+            if (crow[pos - 1] == (int64_t)hs->eos) tok = hs->eos;   // valle_ar.py:168
+            crow[pos] = tok;                                  // valle_ar.py:171
+            if (tok == hs->eos) atomicAdd(&hs->eos_count[pos - (hs->pos_base ? hs->pos_base[b] : 0)], 1);
+            s_tok[row] = tok;
+            s_pos[row] = pos;
+            hs->audio_pos[b] = pos + 1;
+            hs->cache_len[b] += 1;
+        }
+        __syncthreads();
+        const int q4 = hs->d >> 2;
+        for (int c = tid; c < a.M * q4; c += NW * 64) {       // valle_ar.py:143-144 for the next step (modules.py:337)
+            const int r = c / q4, cc = (c - r * q4) * 4;
+            st4(hs->x_next + (int64_t)(hr0 + r) * hs->d + cc,
+                ld4(hs->audio_emb + (int64_t)s_tok[r] * hs->d + cc) + ld4(hs->pe + (int64_t)s_pos[r] * hs->d + cc));
+        }
+    }
 }
 
 
@@ -1107,6 +1202,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, con
     // weight / activation loads are issued without first waiting for a kernarg s_load round trip.
     a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
     skinny_body<MT, NW, EPI, PW, LN, NJ>(a, ln);
+}
+
+// The AR head + greedy step (EPI_HEAD): same body, the step's operands as one more by-value argument.
+template <int PW>
+__global__ __launch_bounds__(512) void gemm_head_greedy_kernel(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
+                                                               int hM, int hN, GemmArgs a, HeadStep hs) {
+    a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
+    LnFuse none{};
+    skinny_body<1, 8, EPI_HEAD, PW, 0, 1>(a, none, &hs);
 }
 // =============================================================================================
 // Split-K for the wide-K skinny GEMM (linear_2: K = dff).  One workgroup can pull only ~20-30 GB/s
@@ -1493,6 +1597,49 @@ static int check_folded(const char* name, const GemmArgs& a, const LnFuse& ln) {
                "%s: folded LayerNorm is the decode path: M <= 64, N %% 16 == 0, K in {128,256,512,1024} "
                "(M=%d N=%d K=%d)", name, a.M, a.N, a.K);
     VH_REQUIRE(vh_aligned16(ln.c1) && vh_aligned16(ln.c2), VH_EALIGN, "%s: c1/c2 must be 16-byte aligned", name);
+    return VH_OK;
+}
+
+// ---- the AR head with the greedy step in the same launch (EPI_HEAD) ----
+#define HEAD_WS_COUNTERS 64               // ints in front of the candidates (one per row group)
+extern "C" size_t vh_head_greedy_ws_bytes(int B, int V) {
+    if (B <= 0 || V <= 0) return 0;
+    return HEAD_WS_COUNTERS * sizeof(int) + (size_t)B * ((V + 15) / 16) * sizeof(uint64_t);
+}
+
+extern "C" int vh_head_greedy(const float* x, int ldx, const float* proj_w, float* logits, int ldl, int V, int eos,
+                              int64_t* codes, int64_t codes_stride, int32_t* eos_count, const int32_t* pos_base,
+                              const float* audio_emb, const float* pe, int32_t* audio_pos, int32_t* cache_len, float* x_next,
+                              int B, int d, void* workspace, size_t workspace_bytes, void* stream) {
+    VH_REQUIRE(x && proj_w && logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next && workspace,
+               VH_EINVAL, "vh_head_greedy: null pointer");
+    VH_REQUIRE(B > 0 && V > 0 && ldl >= V && ldx >= d && ldx % 4 == 0, VH_EINVAL,
+               "vh_head_greedy: bad dims B=%d V=%d ldl=%d d=%d ldx=%d", B, V, ldl, d, ldx);
+    VH_REQUIRE(B <= 64 && (d == 128 || d == 256 || d == 512 || d == 1024), VH_EUNSUPPORTED,
+               "vh_head_greedy: B <= 64 rows and d_model in {128, 256, 512, 1024} (B=%d d=%d); use vh_linear + vh_greedy_step",
+               B, d);
+    VH_REQUIRE(vh_aligned16(x) && vh_aligned16(proj_w) && vh_aligned16(audio_emb) && vh_aligned16(pe) && vh_aligned16(x_next) &&
+                   vh_aligned16(workspace),
+               VH_EALIGN, "vh_head_greedy: x/proj_w/audio_emb/pe/x_next and the workspace must be 16-byte aligned");
+    VH_REQUIRE(workspace_bytes >= vh_head_greedy_ws_bytes(B, V), VH_EINVAL, "vh_head_greedy: workspace of %zu bytes, %zu needed",
+               workspace_bytes, vh_head_greedy_ws_bytes(B, V));
+    GemmArgs a{};
+    a.A = x; a.lda = ldx; a.W = proj_w; a.out = logits; a.ldo = ldl; a.M = B; a.N = V; a.K = d; a.act = VH_ACT_NONE; a.k_len = d;
+    dim3 grid((V + 15) / 16);
+    if (B > 16) {                          // row groups as launch_gemm chooses them: 8 rows while the grid stays within the CUs
+        a.rg_rows = ((int)grid.x * ((B + 7) / 8) <= 256) ? 8 : 16;
+        grid.z = (B + a.rg_rows - 1) / a.rg_rows;
+    }
+    HeadStep hs{};
+    hs.counters = (int*)workspace;
+    hs.cand = (uint64_t*)((char*)workspace + HEAD_WS_COUNTERS * sizeof(int));
+    hs.V = V; hs.eos = eos; hs.codes = codes; hs.codes_stride = codes_stride; hs.eos_count = eos_count; hs.pos_base = pos_base;
+    hs.audio_emb = audio_emb; hs.pe = pe; hs.audio_pos = audio_pos; hs.cache_len = cache_len; hs.x_next = x_next; hs.d = d;
+    hipStream_t s = (hipStream_t)stream;
+    if (d % 512 == 0) hipLaunchKernelGGL(gemm_head_greedy_kernel<4>, grid, dim3(512), 0, s, SKINNY_ARGS(a), a, hs);
+    else if (d == 256) hipLaunchKernelGGL(gemm_head_greedy_kernel<2>, grid, dim3(512), 0, s, SKINNY_ARGS(a), a, hs);
+    else hipLaunchKernelGGL(gemm_head_greedy_kernel<1>, grid, dim3(512), 0, s, SKINNY_ARGS(a), a, hs);
+    VH_CHECK_LAUNCH("vh_head_greedy");
     return VH_OK;
 }
 

@@ -92,6 +92,13 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
     }
     VH_REQUIRE(d->top_k == 1 || d->temperature > 0.f, VH_EINVAL,
                "vh_ar_decoder: sampling (top_k=%d) needs temperature > 0", d->top_k);
+    if (d->head_ws) {
+        VH_REQUIRE(d->top_k == 1 && d->B <= 64 && d->d_model <= 1024, VH_EUNSUPPORTED,
+                   "vh_ar_decoder: head_ws (head + greedy step in one launch) is for top_k == 1, B <= 64, d_model <= 1024");
+        VH_REQUIRE(d->head_ws_bytes >= vh_head_greedy_ws_bytes(d->B, d->V) && vh_aligned16(d->head_ws), VH_EINVAL,
+                   "vh_ar_decoder: head_ws needs vh_head_greedy_ws_bytes() = %zu bytes, 16-byte aligned (got %zu)",
+                   vh_head_greedy_ws_bytes(d->B, d->V), d->head_ws_bytes);
+    }
     return VH_OK;
 }
 
@@ -195,6 +202,11 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                          d.gemm_ws_bytes, s));
     }
     // head (no bias, no final norm: valle_ar.py:29,158) then sampling + state update
+    if (d.top_k == 1 && d.head_ws) {      // opt-in: one launch for both (the descriptor check made sure the shape is served)
+        TRY(vh_head_greedy(d.x, D, d.proj_w, d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count, d.pos_base,
+                           d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, d.head_ws, d.head_ws_bytes, s));
+        return VH_OK;
+    }
     TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
                   nullptr, nullptr, nullptr, nullptr, 0.f, s));
     if (d.top_k == 1)

@@ -439,6 +439,10 @@ class ArDecoder:
         # FeedForward of a layer as one launch split over dim_feedforward + the slab reduce (vh_ffn_decode)
         ffn_bytes = _lib.lib().vh_ffn_decode_ws_bytes(batch, d, dff) if self._folded is not None else 0
         self.ffn_ws = torch.empty(ffn_bytes // 4, **f32) if ffn_bytes else None
+        # opt-in (VALLE2_HEAD_FUSED=1): head + greedy step as one launch (vh_head_greedy; DESIGN.md 3.20 has the A/B)
+        self.head_ws = None
+        if os.environ.get('VALLE2_HEAD_FUSED') == '1' and self.sampling[0] == 1 and batch <= 64 and d in (128, 256, 512, 1024):
+            self.head_ws = kernels.head_greedy_ws(batch, V, dev)
         self._table = layer_table(model.transformer, cache, self._folded)
         if prefix is not None:
             for i in range(cfg.num_layers):
@@ -458,7 +462,8 @@ class ArDecoder:
             sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes,
             kv_bf16=int(self.kv_bf16), prefix_len=self.prefix_len if prefix is not None else 0,
             prefix_S=prefix.s_max if prefix is not None else 0,
-            attn_partial_bytes=self.partial.numel() * 4 if self.partial is not None else 0)
+            attn_partial_bytes=self.partial.numel() * 4 if self.partial is not None else 0,
+            head_ws=ptr(self.head_ws), head_ws_bytes=self.head_ws.numel() * 4 if self.head_ws is not None else 0)
         self._desc = desc
         self._h = _lib.lib().vh_ar_decoder_create(C.byref(desc))
         if not self._h:

@@ -486,6 +486,20 @@ def greedy_step(logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cach
         stream()), 'vh_greedy_step')
 
 
+def head_greedy_ws(B, V, device):
+    """Zeroed workspace of vh_head_greedy (arrival counters + one candidate per row and 16-column block)."""
+    return torch.zeros(_lib.lib().vh_head_greedy_ws_bytes(B, V) // 4, device=device, dtype=torch.int32)
+
+
+def head_greedy(x, proj_w, logits, V, eos, codes, eos_count, audio_emb, pe, audio_pos, cache_len, x_next, ws, pos_base=None):
+    """The AR head and the greedy step in ONE launch: logits = x @ proj_w.T, then what greedy_step does with them."""
+    B, d = x.shape
+    check(_lib.lib().vh_head_greedy(
+        ptr(_f32(x, 'x')), x.stride(0), ptr(_f32(proj_w, 'proj_w')), ptr(_f32(logits, 'logits')), logits.stride(0), V, eos,
+        ptr(codes), codes.stride(0), ptr(eos_count), ptr(pos_base), ptr(audio_emb), ptr(pe), ptr(audio_pos), ptr(cache_len),
+        ptr(_f32(x_next, 'x_next')), B, d, ptr(ws), ws.numel() * 4, stream()), 'vh_head_greedy')
+
+
 def sample_step(logits, V, eos, top_k, top_p, temperature, seed, codes, eos_count, sum_logprobs, audio_emb,
                 pe, audio_pos, cache_len, x_next, pos_base=None):
     B = logits.shape[0]

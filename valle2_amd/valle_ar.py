@@ -421,6 +421,7 @@ class ValleAR(_Base):
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
                                         'ffn_fused': dec.ffn_ws is not None and cfg.d_model <= 512, 'kv_bf16': dec.kv_bf16,
+                                        'head_fused': dec.head_ws is not None,
                                         'prefill_bf16': run.perf_prefill, 'shared_prompt': run.shared, 'logits': kept,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
                                         'decode_ms': marks[1].elapsed_time(marks[2]),
