@@ -26,9 +26,10 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(params=[1, 2], ids=['two_slabs_k64', 'ring_k32'])
+@pytest.fixture(params=[1, 2, 3], ids=['two_slabs_k64', 'ring_k32', 'one_slab_4wg'])
 def gemm_form(request):
-    """Both tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / a ring of three slabs of 32 k."""
+    """The tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / a ring of three slabs of 32 k / one slab of
+    64 k with four workgroups per CU."""
     from valle2_amd import _lib
     _lib.lib().vh_set_tuning(15, request.param)
     yield request.param
@@ -218,20 +219,20 @@ def test_perf_mode_prefill_logits_within_tolerance_of_the_reference():
 
 
 def test_both_gemm_forms_give_the_same_stack_output():
-    """The two tile machines accumulate k in the same order (32x32x16 MFMAs over ascending k): the whole stack's output is
-    bit-identical between them."""
+    """The tile machines accumulate k in the same order (32x32x16 MFMAs over ascending k): the whole stack's output is
+    bit-identical between them — the default (a form per output type) and each form forced everywhere."""
     from valle2_amd import _lib
     kw, sd, batch = C.nar_inputs()
     m = build('ValleNAR', kw, sd)
     outs = []
-    for form in (1, 2):
+    for form in (0, 1, 2, 3):
         _lib.lib().vh_set_tuning(15, form)
         try:
             with torch.no_grad():
                 outs.append(m.stage_logits(batch, 3, perf_mode=True)[0].clone())
         finally:
             _lib.lib().vh_set_tuning(15, 0)
-    assert torch.equal(outs[0], outs[1])
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
 
 
 def test_perf_mode_nar_stage_logits_within_tolerance_of_the_reference():

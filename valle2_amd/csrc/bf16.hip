@@ -176,11 +176,26 @@ struct Gemm16Args {
     int T, S_max, d_model, n_heads;
 };
 
+#ifdef VH_TILE_PROBE16
+// Phase stamps (tools/probe_tile16.hip only): 100 MHz wall clock at entry | first slab landed | main loop done | image
+// written | stores issued | stores acknowledged, + the hardware id, per workgroup.
+__device__ long long vh_probe16[16384 * 8];
+__device__ unsigned vh_hwid16[16384 * 2];
+#define VH_P16(k) do { if (threadIdx.x == 0 && blockIdx.x < 16384) vh_probe16[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#define VH_P16_END() do { VH_P16(4); __builtin_amdgcn_s_waitcnt(0x0F70); VH_P16(5); \
+        if (threadIdx.x == 0 && blockIdx.x < 16384) { vh_hwid16[blockIdx.x * 2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)); \
+                                                       vh_hwid16[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)); } } while (0)
+#else
+#define VH_P16(k) do { } while (0)
+#define VH_P16_END() do { } while (0)
+#endif
+
 template <int OUT>
 __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int tiles_m, int tiles_n) {
     // [buf][A | W][128 rows][128 B] for the main loop (64 KB); the epilogue re-uses it as a 128 x 132 fp32 image
     __shared__ __attribute__((aligned(16))) char lds[T16M * EPI16_LD * 4];
     __builtin_amdgcn_s_setprio(3);
+    VH_P16(0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wm = w >> 1, wn = w & 1;
@@ -229,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
     for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
     __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0)
     __syncthreads();
+    VH_P16(1);
 
     // fragment addresses in buffer 0: row (wm | wn) * 64 + r, chunk (2 t + h) ^ swz — one ds_read_b128 per fragment
     const int swz = (r >> 1) & 7;
@@ -294,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
     }
     __syncthreads();                                        // every wave has read its last fragments: LDS is free
     __builtin_amdgcn_s_setprio(3);
+    VH_P16(2);
 
     // ---- epilogue: accumulators transposed through LDS so that a lane owns consecutive columns of one row ----
     float* ct = (float*)lds;
@@ -317,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
                     cw[(mt * 32 + (x & 3) + 8 * (x >> 2)) * EPI16_LD + nt * 32] = acc[mt][nt][x];
     }
     __syncthreads();
+    VH_P16(3);
     if (OUT == G16_F32) {
         // thread = (column group of 4: tid & 31, row tid >> 5 + 8 it): whole 512-B rows per wave-instruction
         const int ec4 = tid & 31, erow = tid >> 5, en = n0 + 4 * ec4;
@@ -335,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
             else if (a.res) v += ld4(a.res + (int64_t)m * a.ldr + en);
             st4(out + (int64_t)m * a.ldo + en, v);
         }
+        VH_P16_END();
         return;
     }
     // bf16 outputs: thread = (column group of 8: tid & 15, row tid >> 4 + 16 it): 256-B row segments, 16 B per lane
@@ -384,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
             stq(dst + (int64_t)m * dstride, pk);
         }
     }
+    VH_P16_END();
 }
 
 // =============================================================================================
@@ -589,10 +609,166 @@ __global__ __launch_bounds__(256, 3) void gemm16_ring_kernel(Gemm16Args a, int t
     }
 }
 
+// =============================================================================================
+// Occupancy variant of the bf16 tile GEMM (round 5, third form): ONE slab pair of K step 64 (32 KB of LDS), no software
+// pipeline at all — request the slab, wait, barrier, 16 MFMAs per wave, barrier — and FOUR workgroups per CU (<= 128 VGPRs)
+// whose phases interleave by themselves: while one workgroup waits for its slab the other three multiply.
+// Why (tools/probe_tile16.hip, profiles/r5_probe_tile16.log): in the two-slab form a K step lasts 0.8 - 1.15 us against
+// 0.21 us of MFMA work — the step is the latency of the ONE slab it has in flight — and a CU holds two such workgroups
+// (64 KB in flight); here it holds four slabs in flight (128 KB) behind half the LDS, and the prologue / epilogue of a
+// tile hide under three neighbours instead of one.  (cdna_hip_programming.md section 5: the plain two-barrier 128^2
+// structure at >= 3 blocks per CU is the best of its class; explicit double buffering does not beat it.)
+// Epilogue: the 32 KB hold half of the tile's fp32 image — two passes of 64 rows (the waves of row half wm = pass hand
+// over), rows of 128 floats, columns XOR-ed with 32 on every other group of four rows (the two row halves of a 32x32
+// accumulator block, rows r and r + 4, would otherwise share their banks).
+// =============================================================================================
+template <int OUT>
+__global__ __launch_bounds__(256, 4) void gemm16_occ_kernel(Gemm16Args a, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * SLAB16];    // [A | W][128 rows][128 B]; epilogue: 64 x 128 floats
+    VH_P16(0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
+    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
+    const int m0 = (tile / tiles_n) * T16M, n0 = (tile % tiles_n) * T16N;
+
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const char* baseA = (const char*)(a.A + (int64_t)m0 * a.lda);
+    const char* baseW = (const char*)(a.W + (int64_t)n0 * a.K);
+    uint32_t voff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = ws * 8 + i, row = (q & 15) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        voff[i] = q < 16 ? (uint32_t)(min(row, a.M - 1 - m0) * a.lda + 8 * c) * 2u
+                         : (uint32_t)(min(row, a.N - 1 - n0) * a.K + 8 * c) * 2u;
+    }
+    auto dma1 = [&](int i, int k0) {
+        const int q = ws * 8 + i;
+        const char* base = (q < 16 ? baseA : baseW) + (int64_t)k0 * 2;
+        const uint32_t dst = (uint32_t)(uintptr_t)(lds + (q >> 4) * SLAB16 + (q & 15) * 1024);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(voff[i]), "s"(base) : "memory");
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int swz = (r >> 1) & 7;
+    const char* fA = lds + (wm * 64 + r) * 128;
+    const char* fW = lds + SLAB16 + (wn * 64 + r) * 128;
+    const int nk = a.K / T16K;
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dma1(i, kt * T16K);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                 // vmcnt(0): this wave's pieces have landed
+        __syncthreads();
+        if (kt == 0) VH_P16(1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int off = ((2 * t + h) ^ swz) << 4;
+            const bf16x8 a0 = __builtin_bit_cast(bf16x8, ldq(fA + off)), a1 = __builtin_bit_cast(bf16x8, ldq(fA + off + 32 * 128));
+            const bf16x8 w0 = __builtin_bit_cast(bf16x8, ldq(fW + off)), w1 = __builtin_bit_cast(bf16x8, ldq(fW + off + 32 * 128));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();                                    // every wave has read the slab: it may be overwritten
+    }
+
+    VH_P16(2);
+    // ---- epilogue: two passes of 64 rows through the 32 KB ----
+    float* ct = (float*)lds;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // per-thread constants of the store side
+    const int ec4 = tid & 31, erow4 = tid >> 5;             // fp32 output: column group of 4, rows erow4 + 8 it
+    const int ec8 = tid & 15, erow8 = tid >> 4;             // bf16 outputs: column group of 8, rows erow8 + 16 it
+    f32x4 b0 = zero4, b1 = zero4;
+    if (OUT == G16_F32 && a.bias) b0 = ld4(a.bias + n0 + 4 * ec4);
+    if (OUT == G16_BF16 && a.bias) { b0 = ld4(a.bias + n0 + 8 * ec8); b1 = ld4(a.bias + n0 + 8 * ec8 + 4); }
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        const int mp = m0 + 64 * pass;
+        if (wm == pass) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int x = 0; x < 16; ++x) {
+                        const int lrow = mt * 32 + (x & 3) + 8 * (x >> 2) + 4 * h;      // (lrow >> 2) & 1 == h
+                        ct[lrow * 128 + ((wn * 64 + nt * 32 + r) ^ (h << 5))] = acc[mt][nt][x];
+                    }
+        }
+        __syncthreads();
+        if (pass == 0) VH_P16(3);
+        if (OUT == G16_F32) {
+            float* out = (float*)a.out;
+            const int en = n0 + 4 * ec4;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int lrow = erow4 + 8 * it, m = mp + lrow;
+                if (m >= a.M) break;
+                f32x4 v = ld4(ct + lrow * 128 + ((4 * ec4) ^ (((lrow >> 2) & 1) << 5))) + b0;
+                if (a.act == VH_ACT_GELU_ERF) {
+                    const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
+                    v = f32x4{g0.x, g0.y, g1.x, g1.y};
+                }
+                if (a.res) v += ld4(a.res + (int64_t)m * a.ldr + en);      // (no early request: three neighbours hide it)
+                st4(out + (int64_t)m * a.ldo + en, v);
+            }
+        } else {
+            const int en = n0 + 8 * ec8;
+            const int which = OUT == G16_QKV ? en / a.d_model : 0, c = en - which * a.d_model;   // a tile lies in one of q | K | V
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int lrow = erow8 + 16 * it, m = mp + lrow;
+                if (m >= a.M) break;
+                const float* cr = ct + lrow * 128 + ((8 * ec8) ^ (((lrow >> 2) & 1) << 5));
+                f32x4 v0 = ld4(cr) + b0, v1 = ld4(cr + 4) + b1;
+                if (OUT == G16_BF16 && a.act == VH_ACT_GELU_ERF) {
+                    const vh_f32x2 g0 = gelu16_2(vh_f32x2{v0.x, v0.y}), g1 = gelu16_2(vh_f32x2{v0.z, v0.w});
+                    const vh_f32x2 g2 = gelu16_2(vh_f32x2{v1.x, v1.y}), g3 = gelu16_2(vh_f32x2{v1.z, v1.w});
+                    v0 = f32x4{g0.x, g0.y, g1.x, g1.y};
+                    v1 = f32x4{g2.x, g2.y, g3.x, g3.y};
+                }
+                const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
+                if (OUT == G16_QKV && which != 0) {
+                    const int b = m / a.T, t = m - b * a.T;
+                    const int cl = a.cache_len ? a.cache_len[b] : 0;
+                    uint16_t* base = (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
+                    stq(base + ((int64_t)b * a.n_heads * a.S_max + cl + t) * VH_HEAD_DIM, pk);
+                } else {
+                    stq((uint16_t*)a.out + (int64_t)m * a.ldo + (OUT == G16_QKV ? c : en), pk);
+                }
+            }
+        }
+        if (pass == 0) __syncthreads();                     // the image is read before the second half overwrites it
+    }
+    VH_P16_END();
+}
+
 // which tile machine a launch takes: VH_TUNE_BF16_GEMM = 1 the two-slab K-64 kernel, 2 the three-slab K-32 ring, 0 the default
 static bool use_ring16() {
     const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
     return knob == 0 ? VH_BF16_RING_DEFAULT : knob == 2;
+}
+// default (set by measurement, tools/bench_bf16.py + tools/probe_tile16.hip): the one-slab / four-workgroup form for the
+// bf16 outputs (QKV scatter, linear_1 + GELU: -10 ... -25 %), the two-slab form with its early residual request for the
+// fp32 output + residual GEMMs (HBM-bound at 3.7 - 4.8 TB/s in both forms)
+static bool use_occ16(bool bf16_out) {
+    const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
+    return knob == 0 ? bf16_out : knob == 3;
 }
 
 static int check_gemm16(const char* name, const Gemm16Args& a) {
@@ -619,7 +795,10 @@ extern "C" int vh_linear_bf16(const uint16_t* A, int lda, const uint16_t* W, con
                "vh_linear_bf16: ldo=%d (bf16 output: ldo %% 8 == 0, no residual)", ldo);
     const int tm = (M + T16M - 1) / T16M, tn = N / T16N;
     hipStream_t s = (hipStream_t)stream;
-    if (use_ring16()) {
+    if (use_occ16(out_bf16 != 0)) {
+        if (out_bf16) hipLaunchKernelGGL(gemm16_occ_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
+        else hipLaunchKernelGGL(gemm16_occ_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
+    } else if (use_ring16()) {
         if (out_bf16) hipLaunchKernelGGL(gemm16_ring_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
         else hipLaunchKernelGGL(gemm16_ring_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
     } else {
@@ -644,7 +823,8 @@ extern "C" int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wq
     VH_REQUIRE(ldq % 8 == 0 && ldq >= d_model && vh_aligned16(kcache16) && vh_aligned16(vcache16), VH_EALIGN,
                "vh_linear_qkv_bf16: ldq=%d / cache alignment", ldq);
     const int tm = (a.M + T16M - 1) / T16M, tn = a.N / T16N;
-    if (use_ring16()) hipLaunchKernelGGL(gemm16_ring_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
+    if (use_occ16(true)) hipLaunchKernelGGL(gemm16_occ_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
+    else if (use_ring16()) hipLaunchKernelGGL(gemm16_ring_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     else hipLaunchKernelGGL(gemm16_tile_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     VH_CHECK_LAUNCH("vh_linear_qkv_bf16");
     return VH_OK;

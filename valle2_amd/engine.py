@@ -370,7 +370,7 @@ class StepSampler:
         self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
         self.codes, self.cache_len, self.audio_pos, self.pos_base = codes, cache_len, audio_pos, pos_base
         self._keep = (model.proj.weight.detach(), model.audio_emb.weight.detach(), model.audio_position_emb.pe)
-        self.n_split, self.ffn_ws, self.kv_bf16 = 0, None, False
+        self.n_split, self.ffn_ws, self.kv_bf16, self.head_ws = 0, None, False, None
 
     def sample_from(self, hidden_last):
         m = self._keep
