@@ -24,6 +24,15 @@ def test_library_exports_every_declared_symbol():
     assert int(re.search(r'#define VH_VERSION (\d+)', header).group(1)) == lib.vh_version()
 
 
+def test_graft_entry_build_runs_and_checks_the_version_against_the_header(capsys):
+    """The driver's "does it build" check: make for gfx950 (a no-op when the tree is built), dlopen, every symbol, and the
+    library's version equal to the header's — not to a literal that a version bump leaves behind."""
+    import __graft_entry__
+    __graft_entry__.build()
+    assert 'vh_version=' in capsys.readouterr().out
+    assert 'vh_version() ==' not in (REPO / '__graft_entry__.py').read_text().replace('vh_version() == declared', '')
+
+
 def test_no_cpu_fallback_anywhere():
     from valle2_amd import _lib
     from valle2_amd.modules import FeedForward, MultiHeadAttention, TokenEmbedding, Transformer
