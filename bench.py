@@ -22,7 +22,8 @@ bound), `prefill` (event-timed prompt pass against the fp32 MFMA peak), `decode_
 decode step against the HBM peak, all algorithmic bytes of the step), `train` (configs[3] forward +
 backward + gradient all-reduce + clip/AdamW step time, AR and NAR, on every rank: the RCCL leg),
 `cpu_baseline` (the oracle timed on this box's host cores on a bounded sample; rank 0, N=1 only),
-`nar` (one NAR stage forward of configs[2], secondary metric), `beams` (the reference's own signature:
+`nar` (configs[2]: one NAR stage forward, B S / t_stage, and `all_stages`, the seven stages as generate() chains them,
+B T_target 7 / t_all — SURVEY 8d's two forms of the metric), `beams` (the reference's own signature:
 `generate()` of ONE utterance with num_beams=32, timed beside the 32-distinct-utterances headline),
 `config5` (configs[4]'s AR leg: 24L/1024d, 8 rows, decode at context ~2.7 k against the HBM peak).
 `roofline.traffic` is measured in this run: after the timed region a FRESH child process runs one
@@ -901,6 +902,34 @@ def main():
                 'value': NAR_B * s / t16, 'unit': 'tokens/s', 'ms_per_stage': t16 * 1e3, 'tflops': flop / t16 / 1e12,
                 'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF, 'frac_of_bf16_peak': flop / t16 / 1e12 / MFMA_BF16_PEAK_TF,
                 'vs_f32_stage': t_stage / t16}
+        # the same configuration as the reference's generate() runs it (valle_nar.py:107-165): the seven stages one after the
+        # other, every stage feeding the next its codes — SURVEY 8(d)'s second form of the metric, B T_target 7 / t_all
+        log('nar: the seven stages of configs[2] (generate_batch)')
+        g = torch.Generator().manual_seed(4321)
+        prefix, target = 150, NAR_FRAMES - 150
+        g_texts = [torch.randint(0, ncfg.vocab_size, (NAR_TEXT,), generator=g).to(dev) for _ in range(NAR_B)]
+        g_prompts = [torch.randint(0, ncfg.num_audio_tokens, (prefix, ncfg.num_quantizers), generator=g).to(dev) for _ in range(NAR_B)]
+        g_firsts = [torch.randint(0, ncfg.num_audio_tokens, (target,), generator=g).to(dev) for _ in range(NAR_B)]
+        stages = ncfg.num_quantizers - 1
+        all_stages = {}
+        for mode in ([False] if args.no_perf_mode else [False, True]):
+            nar.generate_batch(g_texts, g_prompts, g_firsts, greedy=True, perf_mode=mode)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            codes = nar.generate_batch(g_texts, g_prompts, g_firsts, greedy=True, perf_mode=mode)
+            torch.cuda.synchronize()
+            t_all = time.perf_counter() - t0
+            assert len(codes) == NAR_B and tuple(codes[0].shape) == (target, ncfg.num_quantizers)
+            entry = {'ms_total': t_all * 1e3, 'value': NAR_B * target * stages / t_all, 'unit': 'codec tokens/s',
+                     'tflops': stages * flop / t_all / 1e12}
+            if mode:
+                all_stages['perf_mode'] = dict(entry, label='SECONDARY, not the metric: bf16 operands / fp32 accumulators',
+                                               vs_f32=all_stages['ms_total'] / entry['ms_total'])
+            else:
+                all_stages = dict(entry, workload='configs[2] as generate() runs it: 64 rows x (256 text + 150-frame prompt + 618 '
+                                                  'target frames), codebooks 2..8 (7 stages, greedy), fp32',
+                                  frac_of_mfma_peak=stages * flop / t_all / 1e12 / MFMA_F32_PEAK_TF)
+        result['nar']['all_stages'] = all_stages
         del nar, nb
 
     if not args.no_train:
