@@ -6,7 +6,8 @@
  *   2. prompt pass:  vh_embed_sum_pe (text, audio) -> vh_transformer_forward (prefix-LM mask, K/V into the cache)
  *                    -> vh_linear (head on the last row) -> vh_greedy_step;
  *   3. decode:       vh_ln_fold per layer, vh_ar_decoder_create -> 5 eager vh_ar_decoder_step -> vh_ar_decoder_capture
- *                    -> vh_ar_decoder_replay for the rest -> vh_ar_decoder_destroy;
+ *                    -> vh_ar_decoder_replay for half of the rest -> vh_ar_decoder_destroy; a second decoder with the
+ *                    one-launch head (head_ws -> vh_head_greedy) continues on the same caller-owned state to the end;
  *   4. asserts the tokens of every beam row equal the reference's (up to the first step whose reference margin is
  *      below 1e-4, as the Python parity tests do);
  *   5. vh_attn_rows (prefix mask, ragged key lengths) and vh_attn_decode (no split, 3 key splits) against a
@@ -211,13 +212,27 @@ static int decode_against_the_reference(const char* path) {
     CHECK(dec, "vh_ar_decoder_create: %s", vh_last_error());
     CHECK(vh_ar_decoder_replay(dec, 1, s) == VH_ESTATE, "replay before capture must be VH_ESTATE");
     CHECK(vh_ar_decoder_capture(dec, NULL) == VH_EINVAL, "capture needs a non-null stream");
-    const int eager = 5;
+    const int eager = 5, first = (n_new - 1 - eager) / 2, rest = n_new - 1 - eager - first;
     for (int i = 0; i < eager; ++i) VH(vh_ar_decoder_step(dec, s));                 /* steps 1..5 eagerly */
     VH(vh_ar_decoder_capture(dec, cap));
-    VH(vh_ar_decoder_replay(dec, n_new - 1 - eager, s));                            /* the rest as graph replays */
+    VH(vh_ar_decoder_replay(dec, first, s));                                        /* half of the rest as graph replays */
     HIP(hipStreamSynchronize(s));
     vh_ar_decoder_destroy(dec);
     vh_ar_decoder_destroy(NULL);
+    /* a SECOND decoder continues on the same caller-owned state (codes, positions, caches, residual rows) — this one with
+     * the head and the greedy step as one launch (vh_head_greedy, opt-in through head_ws) */
+    dd.head_ws_bytes = vh_head_greedy_ws_bytes(B, V);
+    CHECK(dd.head_ws_bytes == 256 + (size_t)B * ((V + 15) / 16) * 8, "vh_head_greedy_ws_bytes = %zu", dd.head_ws_bytes);
+    dd.head_ws = dev_alloc(dd.head_ws_bytes, NULL);                                 /* zeroed */
+    bad = dd;
+    bad.head_ws_bytes = 64;
+    CHECK(vh_ar_decoder_create(&bad) == NULL && strstr(vh_last_error(), "head_ws"), "small head workspace: '%s'", vh_last_error());
+    dec = vh_ar_decoder_create(&dd);
+    CHECK(dec, "vh_ar_decoder_create (one-launch head): %s", vh_last_error());
+    VH(vh_ar_decoder_capture(dec, cap));
+    VH(vh_ar_decoder_replay(dec, rest, s));
+    HIP(hipStreamSynchronize(s));
+    vh_ar_decoder_destroy(dec);
 
     HIP(hipMemcpy(h_all, codes, sizeof(int64_t) * B * codes_stride, hipMemcpyDeviceToHost));
     int32_t flag = 0;
@@ -234,6 +249,7 @@ static int decode_against_the_reference(const char* path) {
               first_bad, margin[first_bad], (long long)h_all[n_prompt + first_bad], (long long)gold[first_bad]);
     printf("c_abi_decode: %d greedy tokens x %d beams equal the reference's (%s; n_split %d, %d eager + %d replayed steps)\n",
            first_bad < 0 ? n_new : first_bad, B, first_bad < 0 ? "all" : "up to a near-tie", n_split, eager, n_new - 1 - eager);
+    printf("c_abi_decode: a second decoder (vh_head_greedy: head + greedy step in one launch) took over after step %d\n", eager + first);
     return 0;
 }
 

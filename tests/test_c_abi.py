@@ -65,4 +65,5 @@ def test_c_program_drives_the_decoder_through_the_abi(tmp_path):
     out = subprocess.run([str(exe), str(path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert 'all checks passed' in out.stdout and 'equal the reference' in out.stdout
+    assert 'a second decoder (vh_head_greedy' in out.stdout        # the one-launch head continued on the caller-owned state
     print(out.stdout)
