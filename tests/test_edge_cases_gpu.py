@@ -1,0 +1,155 @@
+"""Edges of the path's input space against the CPU oracle (the reference's op sequence): the smallest inputs the
+reference's signatures admit, the largest the positional table admits, and inputs the reference refuses.
+
+  generate():  no target text, one text token, a one-frame acoustic prompt, one beam, one / two new tokens, an EOS at the first
+               step, a context that ends exactly at the last row of the positional table (max_len 5000, modules.py:56);
+  NAR:         one- to four-frame utterances (the prefix rule min(T // 3, 150) gives a prefix of 0 or 1 frame), one text token;
+  refusals:    ranks the reference asserts on (valle_ar.py:109-112), ids outside their tables (IndexError, as nn.Embedding), a
+               sequence beyond the table.
+"""
+import pytest
+import torch
+
+from tests.golden import cases as C
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+KW = dict(d_model=128, n_heads=2, dim_feedforward=512, num_layers=2, dropout=0.0)
+
+
+def _ar(seed=5, **over):
+    from valle2_amd import get_model_class, synth
+    kw = dict(KW, norm='LayerNorm', num_beams=4, top_k=1, max_audio_len=12)
+    kw.update(over)
+    cfg = C.cfg_of(kw)
+    sd = synth.silence_eos(synth.make_state_dict(cfg, 'ValleAR', seed=seed, rich=True, std=0.15), cfg)
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    return cfg, sd, m.to(DEV).eval()
+
+
+def _same_tokens(m, sd, cfg, utt):
+    from oracle import valle_oracle as O
+    trace = {}
+    ref = O.ar_generate(sd, cfg, *utt, trace=trace)
+    out = m.generate(*[None if u is None else u.to(DEV) for u in utt]).cpu()
+    n = min(len(out), len(ref))
+    bad = (out[:n] != ref[:n]).nonzero()
+    assert len(out) == len(ref) and (bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4), (out.tolist(), ref.tolist())
+    return out
+
+
+@pytest.mark.parametrize('n_prompt_tokens,n_target_tokens,n_frames', [(1, None, 1), (1, 1, 1), (7, None, 30), (3, 5, 1), (40, 0, 2)])
+def test_generate_smallest_inputs(n_prompt_tokens, n_target_tokens, n_frames):
+    """One text token, no target text (target_tokens=None, valle_ar.py:95-97,120-123) or an EMPTY one, a one-frame prompt: the
+    prompt pass is then 3 positions (text, BOS, one frame) and every kernel runs far below its tile sizes."""
+    from valle2_amd import synth
+    cfg, sd, m = _ar()
+    u = synth.synth_utterance(cfg, n_prompt_tokens, max(n_target_tokens or 0, 1), n_frames, seed=100 + n_frames)
+    target = None if n_target_tokens is None else u[2][:n_target_tokens]
+    out = _same_tokens(m, sd, cfg, (u[0], u[1], target))
+    assert out.dtype == torch.int64 and out.dim() == 1 and len(out) <= cfg.max_audio_len
+
+
+@pytest.mark.parametrize('beams,max_new', [(1, 1), (1, 2), (4, 1), (2, 3), (64, 2)])
+def test_generate_one_beam_and_one_new_token(beams, max_new):
+    from valle2_amd import synth
+    cfg, sd, m = _ar(num_beams=beams, max_audio_len=max_new)
+    u = synth.synth_utterance(cfg, 9, 4, 6, seed=200 + beams)
+    out = _same_tokens(m, sd, cfg, u)
+    assert len(out) == max_new
+    assert m.last_generate_stats['steps_run'] == max_new
+
+
+def test_generate_that_emits_eos_at_the_first_step_returns_nothing():
+    """valle_ar.py:168-171,174-180: every beam emits EOS at step 0, the loop breaks before anything is appended and the best beam
+    stripped of EOS is an empty 1-D int64 tensor."""
+    from valle2_amd import get_model_class, synth
+    kw = dict(KW, norm='LayerNorm', num_beams=3, top_k=1, max_audio_len=8)
+    cfg = C.cfg_of(kw)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=6, rich=True, std=0.15)
+    sd['proj.weight'][:] = 0.0
+    sd['proj.weight'][cfg.num_audio_tokens] = 0.0
+    # logits = proj . y: make EOS the arg-max for any hidden state — every other row the negative of the EOS row would need y;
+    # simpler: a zero matrix gives all-equal logits (arg-max = column 0), so put the only nonzero row at EOS with a sign that is
+    # decided by the oracle itself: try both and keep the one whose oracle run ends at step 0
+    from oracle import valle_oracle as O
+    u = synth.synth_utterance(cfg, 5, 5, 4, seed=7)
+    chosen = None
+    for sign in (1.0, -1.0):
+        sd['proj.weight'][cfg.num_audio_tokens] = sign * sd['audio_emb.word_embeddings.weight'][0, :].sign() * 0.5
+        trace = {}
+        ref = O.ar_generate(sd, cfg, *u, trace=trace)
+        if len(ref) == 0 and len(trace['tokens']) == 1:
+            chosen = sign
+            break
+    if chosen is None:
+        pytest.skip('no sign makes EOS the first arg-max for this seed')
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    out = m.generate(*[t.to(DEV) for t in u])
+    assert out.dtype == torch.int64 and out.dim() == 1 and out.numel() == 0
+    assert m.last_generate_stats['tokens_appended'] == 0
+
+
+def test_generate_up_to_the_last_row_of_the_positional_table():
+    """modules.py:56: PositionalEncoding holds max_len = 5000 rows.  A prompt of 4990 frames + BOS and 9 new tokens ends exactly
+    on row 4999 of the audio table (tokens equal to the oracle's); one token more is refused before anything is launched."""
+    from valle2_amd import _lib, synth
+    cfg, sd, m = _ar(num_beams=1, max_audio_len=9)
+    u = synth.synth_utterance(cfg, 6, 3, 4990, seed=300)
+    _same_tokens(m, sd, cfg, u)
+    assert m.last_generate_stats['s0'] == 9 + 4991
+    m.config.max_audio_len = 10
+    with pytest.raises(_lib.VhError, match='positional table'):
+        m.generate(*[t.to(DEV) for t in u])
+    m.config.max_audio_len = 9
+    long_text = torch.zeros(5001, dtype=torch.int64)
+    with pytest.raises(_lib.VhError, match='positional table'):
+        m.generate(long_text.to(DEV), u[1].to(DEV))
+
+
+def test_generate_refuses_what_the_reference_asserts_on_and_ids_outside_their_tables():
+    from valle2_amd import _lib, synth
+    cfg, sd, m = _ar()
+    u = [t.to(DEV) for t in synth.synth_utterance(cfg, 5, 5, 6, seed=9)]
+    with pytest.raises(AssertionError, match='1D'):
+        m.generate(u[0].unsqueeze(0), u[1], u[2])
+    with pytest.raises(AssertionError, match='2D'):
+        m.generate(u[0], u[1][:, 0], u[2])
+    with pytest.raises(AssertionError, match='1D'):
+        m.generate(u[0], u[1], u[2].unsqueeze(0))
+    # an id outside its table: nn.Embedding raises IndexError in the reference; here the gather kernels flag it on the device
+    # (no host read of device-resident ids) and the generate raises IndexError when it next synchronises — and the flag is
+    # cleared, so the next call is clean
+    bad_text = u[0].clone()
+    bad_text[2] = cfg.vocab_size
+    with pytest.raises(IndexError, match='embedding table'):
+        m.generate(bad_text, u[1], u[2])
+    bad_codes = u[1].clone()
+    bad_codes[3, 0] = cfg.num_audio_tokens + 5
+    with pytest.raises(IndexError, match='embedding table'):
+        m.generate(u[0], bad_codes, u[2])
+    assert m.generate(u[0], u[1], u[2]).dim() == 1
+    with pytest.raises(ValueError, match='non-empty'):
+        m.generate_batch([], [])
+
+
+@pytest.mark.parametrize('n_tokens,n_frames', [(1, 1), (1, 2), (2, 3), (5, 4), (3, 7)])
+def test_nar_stage_on_utterances_of_a_few_frames(n_tokens, n_frames):
+    """valle_nar.py:179: prefix = min(T // 3, 150) — 0 frames for T < 3 (every frame is predicted), 1 for T = 3 .. 5."""
+    from oracle import valle_oracle as O
+    from valle2_amd import get_model_class, synth
+    cfg = C.cfg_of(dict(KW, norm='AdaptiveLayerNorm'))
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=11, rich=True, std=0.15)
+    m = get_model_class('ValleNAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    batch = synth.synth_nar_batch(cfg, 3, n_tokens=n_tokens, n_frames=n_frames, seed=400 + n_frames)
+    for stage in (1, 4, 7):
+        ref, p_ref = O.nar_stage_logits(sd, cfg, batch, stage)
+        got, p = m.stage_logits(batch, stage)
+        assert p == p_ref == min(n_frames // 3, 150)
+        assert tuple(got.shape) == tuple(ref.shape) == (3, n_frames - p, cfg.num_audio_tokens)
+        torch.testing.assert_close(got.cpu(), ref, atol=2e-4, rtol=1e-4)
