@@ -4,6 +4,7 @@ reference's signatures admit, the largest the positional table admits, and input
   generate():  no target text, one text token, a one-frame acoustic prompt, one beam, one / two new tokens, an EOS at the first
                step, a context that ends exactly at the last row of the positional table (max_len 5000, modules.py:56);
   NAR:         one- to four-frame utterances (the prefix rule min(T // 3, 150) gives a prefix of 0 or 1 frame), one text token;
+  training:    AR / NAR steps on one-row batches, one text token, two codec frames, rows of very different lengths;
   refusals:    ranks the reference asserts on (valle_ar.py:109-112), ids outside their tables (IndexError, as nn.Embedding), a
                sequence beyond the table.
 """
@@ -153,3 +154,54 @@ def test_nar_stage_on_utterances_of_a_few_frames(n_tokens, n_frames):
         assert p == p_ref == min(n_frames // 3, 150)
         assert tuple(got.shape) == tuple(ref.shape) == (3, n_frames - p, cfg.num_audio_tokens)
         torch.testing.assert_close(got.cpu(), ref, atol=2e-4, rtol=1e-4)
+
+
+def _grads_match(model, params, names, tol=1e-3):
+    for n in names:
+        got, ref = dict(model.named_parameters())[n].grad, params[n].grad
+        assert got is not None, f'no gradient reached {n}'
+        err = (got.cpu() - ref).norm().item() / max(ref.norm().item(), 1e-12)
+        assert err < tol, f'{n}: relative gradient error {err:.2e}'
+
+
+@pytest.mark.parametrize('batch,tok_range,code_range', [(1, (1, 1), (2, 2)), (1, (3, 3), (40, 40)), (2, (1, 9), (2, 30)),
+                                                       (5, (1, 4), (5, 70))])
+def test_ar_training_step_on_the_smallest_batches(batch, tok_range, code_range):
+    """valle_ar.py:43-90 on batches at the lower edge of the collate format (one row; one text token; two codec frames;
+    rows of very different lengths, so most positions of a row are padding that still counts in the loss): loss and every
+    parameter's gradient against the oracle's autograd."""
+    from oracle import valle_oracle as O
+    from valle2_amd import get_model_class, synth
+    kw = dict(KW, norm='LayerNorm')
+    cfg = C.cfg_of(kw)
+    sd = synth.make_state_dict(cfg, 'ValleAR', seed=21, rich=True, std=0.15)
+    b = synth.synth_ar_batch(cfg, batch, tok_range=tok_range, code_range=code_range, seed=500 + batch)
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    ref_loss = O.ar_training_loss(params, cfg, b)
+    ref_loss.backward()
+    m = get_model_class('ValleAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    loss = m.training_step({k: v.clone() for k, v in b.items()})
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    _grads_match(m, params, sorted(k for k, v in params.items() if v.grad is not None and float(v.grad.abs().sum()) > 0))
+
+
+@pytest.mark.parametrize('batch,n_tokens,n_frames,stage', [(1, 1, 1, 1), (1, 2, 3, 7), (2, 1, 2, 4), (3, 4, 6, 2)])
+def test_nar_training_step_on_the_smallest_batches(batch, n_tokens, n_frames, stage):
+    from oracle import valle_oracle as O
+    from valle2_amd import get_model_class, synth
+    cfg = C.cfg_of(dict(KW, norm='AdaptiveLayerNorm'))
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=22, rich=True, std=0.15)
+    b = synth.synth_nar_batch(cfg, batch, n_tokens=n_tokens, n_frames=n_frames, seed=600 + n_frames)
+    params = {k: v.clone().requires_grad_(not k.endswith('.pe')) for k, v in sd.items()}
+    ref_loss = O.nar_training_loss(params, cfg, b, stage)
+    ref_loss.backward()
+    m = get_model_class('ValleNAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    loss = m.training_step(b, stage=stage)
+    torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
+    loss.backward()
+    _grads_match(m, params, sorted(k for k, v in params.items() if v.grad is not None and float(v.grad.abs().sum()) > 0))
