@@ -205,3 +205,44 @@ def test_nar_training_step_on_the_smallest_batches(batch, n_tokens, n_frames, st
     torch.testing.assert_close(loss.detach().cpu(), ref_loss.detach(), rtol=1e-5, atol=1e-6)
     loss.backward()
     _grads_match(m, params, sorted(k for k, v in params.items() if v.grad is not None and float(v.grad.abs().sum()) > 0))
+
+
+def test_nar_generate_on_the_smallest_utterances_and_an_extremely_ragged_batch():
+    """valle_nar.py:107-165 (the oracle's greedy form): a one-frame target after a one-frame prompt and one text token; and a
+    batch whose rows differ by two orders of magnitude in every length — each row equal to the oracle run on it alone."""
+    from oracle import valle_oracle as O
+    from valle2_amd import get_model_class, synth
+    cfg = C.cfg_of(dict(KW, norm='AdaptiveLayerNorm'))
+    sd = synth.make_state_dict(cfg, 'ValleNAR', seed=31, rich=True, std=0.15)
+    m = get_model_class('ValleNAR')(cfg)
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    g = torch.Generator().manual_seed(7)
+    shapes = [(2, 1, 1), (2, 1, 3), (150, 90, 200), (3, 200, 2), (40, 2, 120)]          # (text, prompt frames, target frames)
+    us = [(torch.randint(0, cfg.vocab_size, (t,), generator=g), torch.randint(0, cfg.num_audio_tokens, (p, cfg.num_quantizers), generator=g),
+           torch.randint(0, cfg.num_audio_tokens, (y,), generator=g)) for t, p, y in shapes]
+    outs = m.generate_batch([u[0].to(DEV) for u in us], [u[1].to(DEV) for u in us], [u[2].to(DEV) for u in us], greedy=True)
+    for (text, pc, first), got in zip(us, outs):
+        ref = O.nar_generate(sd, cfg, text[:1], pc, text[1:], first, greedy=True)
+        assert got.shape == ref.shape == (first.shape[0], cfg.num_quantizers)
+        assert torch.equal(got.cpu(), ref), f'{(got.cpu() != ref).sum().item()} of {ref.numel()} codes differ'
+    one = m.generate(us[0][0][:1].to(DEV), us[0][1].to(DEV), us[0][0][1:].to(DEV), us[0][2].to(DEV), greedy=True)
+    assert torch.equal(one, outs[0])
+
+
+def test_ar_generate_batch_extremely_ragged_rows():
+    """Rows of one decode batch with 1 .. 120 text tokens and 1 .. 300 prompt frames: every row equal to the oracle on that
+    utterance alone (per-row key lengths, per-row positions, EOS-filled tails)."""
+    from oracle import valle_oracle as O
+    from valle2_amd import synth
+    cfg, sd, m = _ar(num_beams=1, max_audio_len=10)
+    shapes = [(1, 1), (120, 300), (2, 299), (119, 1), (30, 40), (1, 300)]
+    us = [synth.synth_utterance(cfg, t, 1, p, seed=700 + i) for i, (t, p) in enumerate(shapes)]
+    rows = m.generate_batch([torch.cat([u[0], u[2]]).to(DEV) for u in us], [u[1][:, 0].to(DEV) for u in us])
+    for r, u in enumerate(us):
+        trace = {}
+        ref = O.ar_generate(sd, cfg, *u, trace=trace)
+        p0 = m.last_generate_stats['prompt_lens'][r]
+        got = rows[r, p0:p0 + len(ref)].cpu()
+        bad = (got != ref).nonzero()
+        assert bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4, (r, got.tolist(), ref.tolist())
