@@ -246,3 +246,40 @@ def test_ar_generate_batch_extremely_ragged_rows():
         got = rows[r, p0:p0 + len(ref)].cpu()
         bad = (got != ref).nonzero()
         assert bad.numel() == 0 or trace['margin'][int(bad[0])] < 1e-4, (r, got.tolist(), ref.tolist())
+
+
+def test_two_host_threads_on_their_own_streams_decode_side_by_side():
+    """include/valle_hip.h: "calls are thread-safe for distinct streams".  Two host threads, each with its own torch stream and
+    its own model, run generates (prompt pass, graph capture, replays, EOS polls) at the same time; each must return what it
+    returns alone.  (Capture is serialised on the engine's shared capture stream; hipStreamCaptureModeThreadLocal keeps the
+    other thread's allocations out of it.)"""
+    import threading
+    from valle2_amd import synth
+    jobs = []
+    for i in range(2):
+        cfg, sd, m = _ar(seed=40 + i, num_beams=1, max_audio_len=40)
+        us = [synth.synth_utterance(cfg, 10 + r, 6, 20 + 3 * r, seed=800 + 10 * i + r) for r in range(6)]
+        texts, prompts = [torch.cat([u[0], u[2]]).to(DEV) for u in us], [u[1][:, 0].to(DEV) for u in us]
+        jobs.append((m, texts, prompts, m.generate_batch(texts, prompts).clone()))
+    torch.cuda.synchronize()
+    errors, results = [], [[], []]
+
+    def work(i):
+        try:
+            m, texts, prompts, _ = jobs[i]
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(4):
+                    results[i].append(m.generate_batch(texts, prompts).clone())
+                st.synchronize()
+        except Exception as e:                       # noqa: BLE001 — reported by the main thread
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == 4 and all(torch.equal(r, jobs[i][3]) for r in results[i]), f'thread {i} decoded something else'

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 
 import torch
@@ -339,6 +340,7 @@ def pick_n_split(rows_x_heads: int) -> int:
 
 
 _CAPTURE_STREAMS = {}
+_CAPTURE_LOCK = threading.Lock()      # one capture at a time on the shared capture stream (host threads with their own streams)
 
 
 def _capture_stream(device_index):
@@ -496,8 +498,9 @@ class ArDecoder:
         """Record the step graphs now (host work only: capture enqueues nothing).  generate_batch calls it right after
         the prompt pass is enqueued, so the ~1.7 ms of capture + instantiate run on the host while the GPU is busy."""
         if self.use_graph and not self._captured:
-            cap = _capture_stream(torch.cuda.current_device())
-            check(_lib.lib().vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
+            with _CAPTURE_LOCK:
+                cap = _capture_stream(torch.cuda.current_device())
+                check(_lib.lib().vh_ar_decoder_capture(self._h, cap.cuda_stream), 'vh_ar_decoder_capture')
             self._captured = True
 
     def run(self, n_steps):
