@@ -26,10 +26,11 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(params=[1, 2, 3], ids=['two_slabs_k64', 'ring_k32', 'one_slab_4wg'])
+@pytest.fixture(params=[1, 2, 3, 4], ids=['two_slabs_k64', 'ring_k32', 'one_slab_4wg', 'persistent_256sq'])
 def gemm_form(request):
     """The tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / a ring of three slabs of 32 k / one slab of
-    64 k with four workgroups per CU."""
+    64 k with four workgroups per CU / the persistent 256 x 256 form of csrc/gemm16p.hip (shapes it does not take — N % 256,
+    K % 128 — fall back to the two-slab form)."""
     from valle2_amd import _lib
     _lib.lib().vh_set_tuning(15, request.param)
     yield request.param
@@ -82,10 +83,41 @@ def test_linear_bf16(K, gemm_form, M, N, K_, out16, act, res):
         torch.testing.assert_close(out.cpu().double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('M,N,K_,out16,act,res', [
+    (256, 256, 256, False, 0, False), (300, 512, 384, False, 0, True), (1, 256, 256, True, 0, False),
+    (16384 + 77, 2048, 512, True, 1, False),      # 520 tiles: up to three per workgroup, the last row of tiles ragged
+    (20000, 1536, 512, False, 1, True),           # 474 tiles, fp32 + GELU + residual, ragged
+    (65536, 512, 512, True, 0, False), (8192, 1024, 1024, False, 0, True), (5000, 4096, 1024, True, 1, False)])
+def test_linear_bf16_persistent_256(K, M, N, K_, out16, act, res):
+    """csrc/gemm16p.hip on its own shapes (N % 256 == 0, K % 128 == 0): one tile, ragged rows, many tiles per persistent workgroup
+    (the request stream and the counted waits run across tile boundaries and epilogues).  Reference in fp64 on the device."""
+    from valle2_amd import _lib
+    a = torch.randn(M, K_, generator=g(10)).bfloat16().to(DEV)
+    w = (0.05 * torch.randn(N, K_, generator=g(11))).bfloat16().to(DEV)
+    bias = torch.randn(N, generator=g(12)).to(DEV)
+    r = torch.randn(M, N, generator=g(13)).to(DEV) if res else None
+    ref = a.double() @ w.double().T + bias.double()
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    _lib.lib().vh_set_tuning(15, 4)
+    try:
+        out = K.linear_bf16(a, w, bias, residual=r, act=K.ACT_GELU if act else K.ACT_NONE, out_bf16=out16)
+        out2 = K.linear_bf16(a, w, bias, residual=r, act=K.ACT_GELU if act else K.ACT_NONE, out_bf16=out16)
+    finally:
+        _lib.lib().vh_set_tuning(15, 0)
+    assert torch.equal(out, out2)                 # the same bits on every launch (no race between request stream and reads)
+    if out16:
+        torch.testing.assert_close(out.double(), ref, atol=1e-4 if act else 1e-5, rtol=2 ** -7 if act else 2 ** -8)
+    else:
+        torch.testing.assert_close(out.double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5)
+
+
 def test_linear_bf16_integer_operands_are_exact(K, gemm_form):
     """Small integers are exact in bf16 and their products / sums exact in fp32: any operand-layout or accumulator-map
     error shows as a wrong integer.  Asymmetric data (a[m][k] depends on m and k differently than w[n][k] on n and k)."""
-    M, N, K_ = 260, 256, 192
+    M, N, K_ = (520, 512, 256) if gemm_form == 4 else (260, 256, 192)
     m, n, k = torch.arange(M)[:, None], torch.arange(N)[:, None], torch.arange(K_)[None, :]
     a = ((3 * m + 5 * k) % 7 - 3).float()
     w = ((2 * n + k) % 5 - 2).float()
@@ -105,7 +137,8 @@ def test_linear_bf16_refuses_shapes_outside_the_tile_kernel(K):
         K.linear_bf16(a.float(), torch.zeros(128, 96, device=DEV, dtype=torch.bfloat16))
 
 
-@pytest.mark.parametrize('B,T,h,with_len', [(2, 5, 2, False), (3, 150, 4, True), (1, 1000, 8, False), (40, 7, 2, True)])
+@pytest.mark.parametrize('B,T,h,with_len', [(2, 5, 2, False), (3, 150, 4, True), (1, 1000, 8, False), (40, 7, 2, True),
+                                           (40, 7, 8, True), (33, 1024, 8, False), (9, 700, 16, True)])
 def test_linear_qkv_bf16_scatter(K, gemm_form, B, T, h, with_len):
     d = 64 * h
     S_max = T + 20
@@ -219,20 +252,25 @@ def test_perf_mode_prefill_logits_within_tolerance_of_the_reference():
 
 
 def test_both_gemm_forms_give_the_same_stack_output():
-    """The tile machines accumulate k in the same order (32x32x16 MFMAs over ascending k): the whole stack's output is
-    bit-identical between them — the default (a form per output type) and each form forced everywhere."""
+    """The 128^2 tile machines accumulate k in the same order (32x32x16 MFMAs over ascending k) and add the bias last: the whole
+    stack's output is bit-identical between them.  The persistent 256^2 form (the default where the shape allows it) has the same
+    k order but starts its accumulators FROM the bias (one value per lane, no add in the epilogue): fp32 roundings differ in the
+    last bit, a bf16 rounding downstream flips here and there — its logits agree to a bf16 ulp of the activations, no more."""
     from valle2_amd import _lib
     kw, sd, batch = C.nar_inputs()
     m = build('ValleNAR', kw, sd)
-    outs = []
-    for form in (0, 1, 2, 3):
+    outs = {}
+    for form in (0, 1, 2, 3, 4):
         _lib.lib().vh_set_tuning(15, form)
         try:
             with torch.no_grad():
-                outs.append(m.stage_logits(batch, 3, perf_mode=True)[0].clone())
+                outs[form] = m.stage_logits(batch, 3, perf_mode=True)[0].clone()
         finally:
             _lib.lib().vh_set_tuning(15, 0)
-    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+    for form in (0, 4):
+        err = float((outs[form] - outs[1]).abs().max())
+        assert err < 2e-2, (form, err)
 
 
 def test_perf_mode_nar_stage_logits_within_tolerance_of_the_reference():

@@ -17,20 +17,7 @@
 //   D reg x: row (x & 3) + 8 (x >> 2) + 4 h, col r.
 #include <type_traits>
 
-#include "vh_common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
-    const bf16x2 r = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ u32x4 ldq(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
-__device__ __forceinline__ void stq(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
+#include "bf16_common.h"
 
 // ---------------------------------------------------------------------------------------------
 // fp32 -> bf16 of a (rows, cols) matrix (weights once per weights epoch; cols % 8 == 0)
@@ -129,25 +116,6 @@ extern "C" int vh_layernorm_bf16(const float* x, const float* gamma, const float
     return VH_OK;
 }
 
-// GELU (exact-erf form, nn.GELU() of valle/models/modules.py:216) for a result that is ROUNDED TO bf16 right after: erf as
-// 1 - 2^(R5(t) - log2(e) t^2), t = min(|z|, 4), R5 ~ log2(erfcx(t)) (degree 5, least squares on Chebyshev nodes of [0, 4]),
-// one branch — the cancellation near z = 0 is an ABSOLUTE error of 4e-5 in gelu, a sixth of bf16's half ulp wherever
-// |gelu| > 0.03, and below SURVEY 8(c)'s 5e-2 by three orders.  12 vector instructions per pair against gelu_erf2's 25:
-// at bf16 MFMA rates the epilogue's GELU costs as much issue time as the tile's products.
-__device__ __forceinline__ vh_f32x2 gelu16_2(vh_f32x2 x) {
-    const vh_f32x2 z = x * vh_splat2(0.70710678118654752440f);
-    const vh_f32x2 t = {fminf(fabsf(z.x), 4.0f), fminf(fabsf(z.y), 4.0f)};
-    vh_f32x2 q = vh_splat2(-1.2391665950417519e-03f);
-    q = __builtin_elementwise_fma(q, t, vh_splat2(1.875305362045765e-02f));
-    q = __builtin_elementwise_fma(q, t, vh_splat2(-1.2387025356292725e-01f));
-    q = __builtin_elementwise_fma(q, t, vh_splat2(5.004633665084839e-01f));
-    q = __builtin_elementwise_fma(q, t, vh_splat2(-1.6198172569274902e+00f));
-    q = __builtin_elementwise_fma(q, t, vh_splat2(-4.4126855209469795e-04f));
-    q = __builtin_elementwise_fma(vh_splat2(-1.4426950408889634f) * t, t, q);
-    const vh_f32x2 e = {copysignf(1.0f - __builtin_amdgcn_exp2f(q.x), z.x), copysignf(1.0f - __builtin_amdgcn_exp2f(q.y), z.y)};
-    return vh_splat2(0.5f) * x * (vh_splat2(1.0f) + e);
-}
-
 // =============================================================================================
 // bf16 tile GEMM
 // =============================================================================================
@@ -157,24 +125,6 @@ __device__ __forceinline__ vh_f32x2 gelu16_2(vh_f32x2 x) {
 #define SLAB16 (T16M * 128)           // bytes of one operand slab (128 rows x 128 B)
 #define EPI16_LD 132                  // floats per row of the epilogue's transposition image
 #define VH_BF16_RING_DEFAULT false     // which kernel VH_TUNE_BF16_GEMM = 0 means (set by measurement, tools/bench_bf16.py)
-
-enum { G16_F32 = 0, G16_BF16 = 1, G16_QKV = 2 };
-
-struct Gemm16Args {
-    const uint16_t* A;
-    int lda;
-    const uint16_t* W;
-    const float* bias;
-    const float* res;
-    int ldr;
-    void* out;
-    int ldo;
-    int M, N, K, act;
-    uint16_t* kc;
-    uint16_t* vc;
-    const int32_t* cache_len;
-    int T, S_max, d_model, n_heads;
-};
 
 #ifdef VH_TILE_PROBE16
 // Phase stamps (tools/probe_tile16.hip only): 100 MHz wall clock at entry | first slab landed | main loop done | image
@@ -770,6 +720,14 @@ static bool use_occ16(bool bf16_out) {
     const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
     return knob == 0 ? bf16_out : knob == 3;
 }
+// round 6: the persistent 256^2 / 8-wave form (gemm16p.hip) where the shape allows it (N % 256 == 0, K % 128 == 0) and there
+// are enough rows to fill the part; VH_TUNE_BF16_GEMM = 4 forces it for every shape it takes, 1 / 2 / 3 keep the 128^2 forms
+static bool use_p256(const Gemm16Args& a, int out_kind) {
+    const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
+    if (knob != 0 && knob != 4) return false;
+    if (!vh_gemm16_p256_ok(a, out_kind)) return false;
+    return knob == 4 || (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 128;
+}
 
 static int check_gemm16(const char* name, const Gemm16Args& a) {
     VH_REQUIRE(a.A && a.W && a.out, VH_EINVAL, "%s: null pointer", name);
@@ -795,6 +753,7 @@ extern "C" int vh_linear_bf16(const uint16_t* A, int lda, const uint16_t* W, con
                "vh_linear_bf16: ldo=%d (bf16 output: ldo %% 8 == 0, no residual)", ldo);
     const int tm = (M + T16M - 1) / T16M, tn = N / T16N;
     hipStream_t s = (hipStream_t)stream;
+    if (use_p256(a, out_bf16 ? G16_BF16 : G16_F32)) return vh_gemm16_p256_launch(a, out_bf16 ? G16_BF16 : G16_F32, s);
     if (use_occ16(out_bf16 != 0)) {
         if (out_bf16) hipLaunchKernelGGL(gemm16_occ_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
         else hipLaunchKernelGGL(gemm16_occ_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
@@ -823,6 +782,7 @@ extern "C" int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wq
     VH_REQUIRE(ldq % 8 == 0 && ldq >= d_model && vh_aligned16(kcache16) && vh_aligned16(vcache16), VH_EALIGN,
                "vh_linear_qkv_bf16: ldq=%d / cache alignment", ldq);
     const int tm = (a.M + T16M - 1) / T16M, tn = a.N / T16N;
+    if (use_p256(a, G16_QKV)) return vh_gemm16_p256_launch(a, G16_QKV, (hipStream_t)stream);
     if (use_occ16(true)) hipLaunchKernelGGL(gemm16_occ_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     else if (use_ring16()) hipLaunchKernelGGL(gemm16_ring_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     else hipLaunchKernelGGL(gemm16_tile_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
