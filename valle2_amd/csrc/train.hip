@@ -2,9 +2,9 @@
 // LayerNorm backward (with the adaptive scale/shift), exact-erf GELU forward/backward on a saved
 // pre-activation, row softmax forward/backward for the recomputed attention probabilities,
 // fused cross-entropy forward+backward, embedding scatter-add, column sums for bias gradients.
-// All HBM-bound row kernels: one wave64 per row, float4 per lane, DPP reductions.  The plain
-// backward GEMMs (dX = dY·W, dW = dYᵀ·X, the five attention products) are library GEMMs (rocBLAS
-// through torch.matmul) — unfused matrix products, as the build rules allow.
+// All HBM-bound row kernels: one wave64 per row, float4 per lane, DPP reductions.  The backward's
+// matrix products are this library's own MFMA kernels: dX = dY·W and dW = dYᵀ·X in gemm.hip
+// (vh_linear_ex / vh_gemm_tn), the five attention products in attention.hip (vh_attn_rows_bwd_ws).
 // Column-sum style gradients use fp32 atomics (order not fixed: last-bit run-to-run variation).
 #include "vh_common.h"
 
