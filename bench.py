@@ -80,6 +80,8 @@ def parse():
     ap.add_argument('--extras-deadline', type=float, default=600.0,
                     help='seconds the optional legs (roofline, nar, train, cpu_baseline) may take in total')
     ap.add_argument('--small', action='store_true', help='tiny shapes for a functional check')
+    ap.add_argument('--allow-partial-group', action='store_true',
+                    help='N > 1: print the line even if RCCL did not carry all N ranks through an all-reduce (default: exit 3)')
     return ap.parse_args()
 
 
@@ -575,6 +577,21 @@ def main():
         seen = {'backend': dist.get_backend() if dist.is_initialized() else None, 'group_world_size': world,
                 'allreduce_count': None, 'error': f'{type(e).__name__}: {e}'}
         args.no_train = True
+    # every rank takes the same branch: a rank that alone skipped the training leg would leave the others inside its
+    # RCCL all-reduce until the deadline (agreed over the host-side gloo group, which needs no GPU collective)
+    if world > 1:
+        flag = torch.tensor([1 if args.no_train else 0, 1 if seen.get('allreduce_count') == world else 0], dtype=torch.int32)
+        lo = flag.clone()
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=host_pg)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=host_pg)
+        args.no_train = bool(flag[0])
+        # ... and the line is only worth printing if the default group really spans the N ranks it claims
+        on_rccl = dist.get_backend() == 'nccl'
+        if (not bool(lo[1]) or not on_rccl) and os.environ.get('VALLE2_DIST_BACKEND', 'nccl') == 'nccl' and not args.allow_partial_group:
+            log(f'rank {rank}: the default process group carried {seen.get("allreduce_count")} of {world} ranks through an all-reduce '
+                f'({seen}); refusing to print a {world}-GPU line (--allow-partial-group to time the headline anyway)')
+            dist.barrier(group=host_pg)
+            raise SystemExit(3)
 
     rows, text, frames, new = ROWS, TEXT, FRAMES, NEW
     ar_kw = dict(AR)

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 122            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 123            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -239,6 +239,14 @@ int vh_attn_rows(const float* q, int ldq, const float* kcache, const float* vcac
                  int ldo, int B, int n_heads, int Tq, int Tk, int S_max, int mode, int x_len,
                  const int32_t* x_len_dev, const int32_t* kv_len, const uint8_t* mask,
                  const uint8_t* pad, void* stream);
+
+/* vh_attn_rows in VH_MASK_EXPLICIT mode with ONE MASK PER BATCH ROW: mask (B,Tq,Tk) u8, mask_batch_stride elements between the
+ * rows' masks (0 = the same (Tq,Tk) mask for all) — the 3-D attn_mask MultiHeadAttention.forward accepts
+ * (valle/models/modules.py:187-188: 'b t t -> b 1 t t'); key j of row b visible to query i iff
+ * !mask[b*stride + i*Tk + j] && !(pad && pad[b*Tk + j]). */
+int vh_attn_rows_bmask(const float* q, int ldq, const float* kcache, const float* vcache, float* out, int ldo, int B,
+                       int n_heads, int Tq, int Tk, int S_max, const uint8_t* mask, int64_t mask_batch_stride,
+                       const uint8_t* pad, void* stream);
 
 /* vh_attn_rows that also writes lse2 (B, n_heads, Tq): log2 of the softmax denominator of every query row
  * in the scaled-score units the backward kernels use (lse2 = max + log2(sum 2^(s - max)), s = q.k/8*log2 e). */

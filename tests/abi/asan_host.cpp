@@ -110,6 +110,9 @@ int main() {
     REFUSED(vh_attn_rows(P, 64, P, P, P, 128, 1, 2, 4, 4, 8, VH_MASK_FULL, 0, nullptr, nullptr, nullptr, nullptr, S));       // ldq < h * 64
     REFUSED(vh_attn_rows(P, 128, P, P, P, 128, 1, 2, 4, 4, 8, 7, 0, nullptr, nullptr, nullptr, nullptr, S));
     REFUSED(vh_attn_rows_lse(P, 128, P, P, P, 128, 1, 2, 4, 4, 8, VH_MASK_FULL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, S));
+    REFUSED(vh_attn_rows_bmask(P, 128, P, P, P, 128, 1, 2, 4, 4, 8, nullptr, 16, nullptr, S));                                  // no mask
+    REFUSED(vh_attn_rows_bmask(P, 128, P, P, P, 128, 2, 2, 4, 4, 8, (const uint8_t*)P, 15, nullptr, S));                        // stride < Tq * Tk
+    REFUSED(vh_attn_rows_bmask(nullptr, 128, P, P, P, 128, 2, 2, 4, 4, 8, (const uint8_t*)P, 16, nullptr, S));
     REFUSED(vh_attn_rows_bwd(nullptr, 128, P, P, P, 128, P, 128, P, P, P, P, P, 128, 1, 2, 4, 8, VH_MASK_FULL, 0, nullptr, nullptr, nullptr, nullptr, S));
     REFUSED(vh_attn_rows_bwd(P, 128, P, P, P, 128, P, 128, P, P, P, P, P, 126, 1, 2, 4, 8, VH_MASK_FULL, 0, nullptr, nullptr, nullptr, nullptr, S));
     REFUSED(vh_attn_rows_bwd_ws(P, 128, P, P, P, 128, P, 128, P, P, P, P, 128, 1, 2, 4, 8, VH_MASK_FULL, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 1 << 20, S));

@@ -111,6 +111,28 @@ def test_generate_up_to_the_last_row_of_the_positional_table():
         m.generate(long_text.to(DEV), u[1].to(DEV))
 
 
+def test_generate_with_a_prompt_beyond_the_shared_kernels_record_bound_decodes_as_independent_rows():
+    """vh_attn_decode_shared merges at most 256 records per (beam, head): ceil(s0 / 32) prompt blocks + the suffix splits (16 at
+    4 beams x 2 heads) — a context of more than 7680 keys is legal (text <= 5000, prompt <= 5000 - max_new positions) and
+    must not raise at graph capture: generate() falls back to independent rows (round-5 advisor finding), the decoder's
+    create refuses the over-long shared form.  s0 = 4990 text ids + BOS + 2690 frames = 7681; tokens against a forced
+    independent-rows run."""
+    from valle2_amd import engine, synth
+    cfg, sd, m = _ar(max_audio_len=3)
+    assert engine.shared_prompt_fits(4, 2, 7680) and not engine.shared_prompt_fits(4, 2, 7681)
+    u = synth.synth_utterance(cfg, 2495, 2495, 2690, seed=77)
+    out = m.generate(*[t.to(DEV) for t in u]).cpu()
+    st = m.last_generate_stats
+    assert not st['shared_prompt'] and st['steps_run'] == 3
+    text = torch.cat([u[0], u[2]]).to(DEV)
+    rows = m.generate_batch([text] * 4, [u[1][:, 0].to(DEV)] * 4)            # the same four rows, never shared
+    assert torch.equal(out, rows[0, u[1].shape[0] + 1:u[1].shape[0] + 1 + len(out)].cpu())
+    # one step below the bound the shared form still runs
+    u2 = synth.synth_utterance(cfg, 2495, 2495, 2689, seed=78)
+    m.generate(*[t.to(DEV) for t in u2])
+    assert m.last_generate_stats['shared_prompt']
+
+
 def test_generate_refuses_what_the_reference_asserts_on_and_ids_outside_their_tables():
     from valle2_amd import _lib, synth
     cfg, sd, m = _ar()

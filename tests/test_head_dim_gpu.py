@@ -20,6 +20,34 @@ def close(a, b, atol=2e-4, rtol=1e-4):
     torch.testing.assert_close(a.detach().cpu(), b.detach(), atol=atol, rtol=rtol)
 
 
+@pytest.mark.parametrize('d,h', [(128, 2), (128, 4)])
+def test_multi_head_attention_takes_one_mask_per_batch_row(d, h):
+    """modules.py:187-188: a 3-D attn_mask (B,T,T) is one mask per batch row ('b t t -> b 1 t t'), merged with the key padding by
+    addition.  The HIP path hands it to the explicit-mask mode with a batch stride (vh_attn_rows_bmask; the materialised path
+    at other head widths applies it row by row).  Against oracle.multi_head_attention."""
+    from oracle import valle_oracle as O
+    from valle2_amd.modules import MultiHeadAttention
+    b, n = 3, 70
+    g = torch.Generator().manual_seed(3)
+    m = MultiHeadAttention(d, h)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(b, n, d, generator=g)
+    am = (torch.rand(b, n, n, generator=g) < 0.3).float()
+    am[:, torch.arange(n), torch.arange(n)] = 0          # every query sees itself: no empty rows
+    pm = torch.zeros(b, n)
+    pm[1, -9:] = 1
+    pm[2, -1:] = 1
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        out, _ = m(x.to(DEV), attn_mask=am.to(DEV), padding_mask=pm.to(DEV))
+        ref, _ = O.multi_head_attention(sd, '', x, h, attn_mask=am, padding_mask=pm)
+    torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-4)
+    with torch.no_grad():                                  # without padding, and a float mask with values other than 1
+        out, _ = m(x.to(DEV), attn_mask=(3 * am).to(DEV))
+        ref, _ = O.multi_head_attention(sd, '', x, h, attn_mask=3 * am)
+    torch.testing.assert_close(out.cpu(), ref, atol=3e-5, rtol=1e-4)
+
+
 @pytest.mark.parametrize('d,h', WIDTHS)
 def test_multi_head_attention_any_head_dim_matches_the_oracle(d, h):
     from oracle import valle_oracle as O

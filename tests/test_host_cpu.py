@@ -20,7 +20,6 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), f'{name} declared in include/valle_hip.h but not exported'
-    assert lib.vh_version() == 122
     assert int(re.search(r'#define VH_VERSION (\d+)', header).group(1)) == lib.vh_version()
 
 

@@ -120,6 +120,8 @@ SIGNATURES = {
     'vh_attn_rows': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
                                c_u8p, C.c_void_p]),
+    'vh_attn_rows_bmask': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, c_u8p, C.c_int64, c_u8p, C.c_void_p]),
     'vh_attn_rows_lse': (C.c_int, [c_f32p, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int,
                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_i32p, c_i32p, c_u8p,
                                    c_u8p, c_f32p, C.c_void_p]),

@@ -566,6 +566,7 @@ struct RowsArgs {
     const uint8_t* mask; const uint8_t* pad;
     int n_qblocks;
     float* lse2;   // optional (B, h, Tq): log2-sum-exp of the scaled scores, for the backward kernels
+    int64_t mask_bstride;   // explicit mode: elements between the masks of consecutive batch rows (0: one (Tq,Tk) mask for all)
 };
 
 __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
@@ -671,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
                     const int key = k0 + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool vis;
                     if (a.mode == VH_MASK_EXPLICIT) {
-                        vis = key < a.Tk && qi < a.Tq && !a.mask[(int64_t)qi * a.Tk + key] &&
+                        vis = key < a.Tk && qi < a.Tq && !a.mask[b * a.mask_bstride + (int64_t)qi * a.Tk + key] &&
                               !(a.pad && a.pad[(int64_t)b * a.Tk + key]);
                     } else {
                         vis = key < kvl;
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(RowsArgs a) {
 static int attn_rows_launch(const float* q, int ldq, const float* kcache, const float* vcache,
                             float* out, int ldo, int B, int n_heads, int Tq, int Tk, int S_max,
                             int mode, int x_len, const int32_t* x_len_dev, const int32_t* kv_len,
-                            const uint8_t* mask, const uint8_t* pad, float* lse2, void* stream) {
+                            const uint8_t* mask, const uint8_t* pad, float* lse2, void* stream, int64_t mask_bstride = 0) {
     VH_REQUIRE(q && kcache && vcache && out, VH_EINVAL, "vh_attn_rows: null pointer");
     VH_REQUIRE(B >= 0 && n_heads > 0 && Tq >= 0 && Tk >= Tq && S_max >= Tk, VH_EINVAL,
                "vh_attn_rows: bad dims B=%d h=%d Tq=%d Tk=%d S_max=%d", B, n_heads, Tq, Tk, S_max);
@@ -760,7 +761,7 @@ static int attn_rows_launch(const float* q, int ldq, const float* kcache, const 
     if (B == 0 || Tq == 0) return VH_OK;
     const int nqb = (Tq + QB - 1) / QB;
     RowsArgs a{q, ldq, kcache, vcache, out, ldo, n_heads, Tq, Tk, S_max, mode, x_len,
-               x_len_dev, kv_len, mask, pad, nqb, lse2};
+               x_len_dev, kv_len, mask, pad, nqb, lse2, mask_bstride};
     dim3 grid(nqb * B * n_heads);
     hipLaunchKernelGGL(attn_rows_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     VH_CHECK_LAUNCH("vh_attn_rows");
@@ -773,6 +774,16 @@ extern "C" int vh_attn_rows(const float* q, int ldq, const float* kcache, const 
                             const uint8_t* mask, const uint8_t* pad, void* stream) {
     return attn_rows_launch(q, ldq, kcache, vcache, out, ldo, B, n_heads, Tq, Tk, S_max, mode, x_len,
                             x_len_dev, kv_len, mask, pad, nullptr, stream);
+}
+
+extern "C" int vh_attn_rows_bmask(const float* q, int ldq, const float* kcache, const float* vcache, float* out, int ldo, int B,
+                                  int n_heads, int Tq, int Tk, int S_max, const uint8_t* mask, int64_t mask_batch_stride,
+                                  const uint8_t* pad, void* stream) {
+    VH_REQUIRE(mask && (mask_batch_stride == 0 || mask_batch_stride >= (int64_t)Tq * Tk), VH_EINVAL,
+               "vh_attn_rows_bmask: a (B,Tq,Tk) mask with batch stride >= Tq*Tk (or 0: one mask for every row), got %lld",
+               (long long)mask_batch_stride);
+    return attn_rows_launch(q, ldq, kcache, vcache, out, ldo, B, n_heads, Tq, Tk, S_max, VH_MASK_EXPLICIT, 0, nullptr, nullptr,
+                            mask, pad, nullptr, stream, mask_batch_stride);
 }
 
 extern "C" int vh_attn_rows_lse(const float* q, int ldq, const float* kcache, const float* vcache,

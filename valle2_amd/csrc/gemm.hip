@@ -1149,7 +1149,10 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
         __shared__ int s_ticket, s_tok[16], s_pos[16];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) s_ticket = atomicAdd(hs->counters + blockIdx.z, 1);
+        // the ticket is the hand-over: release (this workgroup's candidates) and acquire (everybody else's) at agent scope, so
+        // that the last arriver's view rests on the memory model and not on write-through stores + vmcnt alone (one fence
+        // pair per workgroup; this opt-in form is the slower one either way)
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(hs->counters + blockIdx.z, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != (int)gridDim.x - 1) return;
         if (tid == 0) hs->counters[blockIdx.z] = 0;          // ready for the next launch (graph replay)

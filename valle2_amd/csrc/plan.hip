@@ -81,6 +81,9 @@ static int decoder_check(const vh_ar_decoder_desc* d) {
     }
     if (d->prefix_len > 0) {
         VH_REQUIRE(!d->kv_bf16, VH_EUNSUPPORTED, "vh_ar_decoder: the shared prompt has no bf16 form");
+        VH_REQUIRE((d->prefix_len + 31) / 32 + d->n_split <= 256, VH_EUNSUPPORTED,
+                   "vh_ar_decoder: a shared prompt of %d keys with %d suffix splits exceeds the 256 records vh_attn_decode_shared merges",
+                   d->prefix_len, d->n_split);
         VH_REQUIRE(d->prefix_len <= d->prefix_S && d->attn_partial &&
                        d->attn_partial_bytes >= vh_attn_decode_shared_ws_bytes(d->B, d->n_heads, d->prefix_len, d->n_split),
                    VH_EINVAL, "vh_ar_decoder: shared prompt of %d / %d keys needs attn_partial of %zu bytes (got %zu)",

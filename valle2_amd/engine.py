@@ -332,6 +332,21 @@ def _transformer_forward_generic(transformer, x, *, mode, x_len, x_len_dev, kv_l
     return x
 
 
+SHARED_MAX_RECORDS = 256          # vh_attn_decode_shared: prefix blocks of 32 keys + suffix splits one merge launch serves
+
+
+def shared_n_split(batch: int, n_heads: int) -> int:
+    """Key splits of the beams' own rows under a shared prompt (two workgroups per CU keep twice the loads in flight:
+    profiles/r5_ab_shared_prompt.log).  VALLE2_SHARED_SPLIT: the A/B knob."""
+    return int(os.environ.get('VALLE2_SHARED_SPLIT') or min(16, -(-512 // (batch * n_heads))))
+
+
+def shared_prompt_fits(batch: int, n_heads: int, prefix_len: int) -> bool:
+    """Whether vh_attn_decode_shared takes a prompt of prefix_len keys for `batch` beams (its merge serves at most 256
+    records per (row, head): ceil(prefix_len / 32) prefix blocks + the suffix splits) — 4 beams x 8 heads: up to 7680 keys."""
+    return (prefix_len + 31) // 32 + shared_n_split(batch, n_heads) <= SHARED_MAX_RECORDS
+
+
 def pick_n_split(rows_x_heads: int) -> int:
     """Key-range splits of decode attention so that the grid covers the 256 CUs."""
     if rows_x_heads >= 256:
@@ -410,9 +425,8 @@ class ArDecoder:
         self.n_split = n_split or pick_n_split(batch * cfg.n_heads)
         if prefix is not None and n_split is None:
             # shared prompt: the beams' own rows are short streams — two workgroups per CU keep twice the loads in flight
-            # (32 beams x 8 heads: 436.8 us per step with one split, 420.9 with two, 426.9 with four;
-            # profiles/r5_ab_shared_prompt.log).  VALLE2_SHARED_SPLIT: the A/B knob.
-            self.n_split = int(os.environ.get('VALLE2_SHARED_SPLIT') or min(16, -(-512 // (batch * cfg.n_heads))))
+            # (32 beams x 8 heads: 436.8 us per step with one split, 420.9 with two, 426.9 with four)
+            self.n_split = shared_n_split(batch, cfg.n_heads)
         f32 = dict(device=dev, dtype=torch.float32)
         self.x = torch.empty(batch, d, **f32)
         self.q = torch.empty(batch, d, **f32)

@@ -272,6 +272,15 @@ def attn_rows(q, kcache, vcache, out, B, n_heads, Tq, Tk, mode, x_len=0, x_len_d
         raise _lib.VhError(f'attn_rows: cache {tuple(kcache.shape)} Tq={Tq} Tk={Tk}')
     if q.shape[0] != B * Tq or out.shape[0] != B * Tq:
         raise _lib.VhError('attn_rows: q/out rows')
+    if mask is not None and mask.dim() == 3:       # one mask per batch row (inference only: no lse2)
+        if mask.dtype != torch.uint8 or tuple(mask.shape) != (B, Tq, Tk) or not mask.is_contiguous() or lse2 is not None:
+            raise _lib.VhError('attn_rows: a per-row mask must be contiguous uint8 (B,Tq,Tk); the training forward takes 2-D masks')
+        if pad is not None and (pad.dtype != torch.uint8 or tuple(pad.shape) != (B, Tk)):
+            raise _lib.VhError('attn_rows: pad must be uint8 (B,Tk)')
+        check(_lib.lib().vh_attn_rows_bmask(
+            _dev_f32(q, 'q'), q.stride(0), ptr(kcache), ptr(vcache), _dev_f32(out, 'out'), out.stride(0), B, n_heads, Tq, Tk,
+            S_max, ptr(mask), Tq * Tk, ptr(pad), stream()), 'vh_attn_rows_bmask')
+        return out
     if mask is not None and (mask.dtype != torch.uint8 or tuple(mask.shape) != (Tq, Tk)):
         raise _lib.VhError('attn_rows: mask must be uint8 (Tq,Tk)')
     if pad is not None and (pad.dtype != torch.uint8 or tuple(pad.shape) != (B, Tk)):
@@ -337,7 +346,14 @@ def attn_generic(q, k, v, out, scale, **spec):
     tp = (Tk + 3) // 4 * 4
     P = torch.empty(B, h, Tq, tp, device=q.device, dtype=torch.float32)[..., :Tk]
     gemm(q, k, P)                                               # raw scores
-    softmax_rows(P, tp, B, h, Tq, Tk, scale, **spec)
+    mask = spec.get('mask')
+    if mask is not None and mask.dim() == 3:                    # one mask per batch row: the row softmax row by row
+        pad = spec.get('pad')
+        for b in range(B):
+            softmax_rows(P[b:b + 1], tp, 1, h, Tq, Tk, scale, mode=spec['mode'], mask=mask[b],
+                         pad=None if pad is None else pad[b:b + 1])
+    else:
+        softmax_rows(P, tp, B, h, Tq, Tk, scale, **spec)
     gemm(P, v, out, b_kmajor=True)
     return P
 

@@ -165,7 +165,12 @@ class PositionalEncoding(nn.Module):
         b, t, c = x.shape
         if t > self.pe.shape[0]:
             raise _lib.VhError(f'sequence length {t} exceeds max_len {self.pe.shape[0]}')
-        out = kernels.add_pe(x.float(), self.pe)      # (the model paths fuse this add into embed_sum_pe)
+        if (torch.is_grad_enabled() and x.requires_grad) or c % 4 or x.dtype != torch.float32:
+            # the reference's forward (modules.py:78-80) is differentiable in x and takes any width / dtype: keep that contract
+            # where the kernel does not cover it (the model paths never come here: they fuse the add into embed_sum_pe)
+            out = x + self.pe[:t, 0].to(x.dtype)
+        else:
+            out = kernels.add_pe(x, self.pe)
         return _drop(self.dropout, out)
 
 
@@ -231,9 +236,11 @@ def _mask_spec(attn_mask, padding_mask, tq, tk, device):
     tag = getattr(attn_mask, '_vh_prefix', None)
     if tag is not None and tag[0] + tag[1] == tq == tk and (padding_mask is None or lens is not None):
         return dict(mode=kernels.MASK_PREFIX, x_len=tag[0], kv_len=lens)
-    if attn_mask.dim() != 2:
-        raise _lib.VhError('3-D attention masks are not supported by the HIP path (2-D + key padding only)')
-    if tuple(attn_mask.shape) != (tq, tk):
+    if attn_mask.dim() == 3:
+        # one mask per batch row (modules.py:187-188): the explicit mode with a batch stride (vh_attn_rows_bmask)
+        if tuple(attn_mask.shape[1:]) != (tq, tk):
+            raise _lib.VhError(f'attn_mask shape {tuple(attn_mask.shape)} != (B,{tq},{tk})')
+    elif attn_mask.dim() != 2 or tuple(attn_mask.shape) != (tq, tk):
         raise _lib.VhError(f'attn_mask shape {tuple(attn_mask.shape)} != ({tq},{tk})')
     m = (attn_mask != 0).to(device=device, dtype=torch.uint8).contiguous()
     p = None

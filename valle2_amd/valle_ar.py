@@ -17,6 +17,7 @@ from torch import optim
 
 from . import _lib, dropout, kernels
 from .engine import (ArDecoder, ForwardScratch, ForwardScratch16, KVCache, StepSampler, perf_forward_supported,
+                     shared_prompt_fits,
                      transformer_forward, transformer_forward_bf16)
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device, device_mirror
 from .utils import get_best_beam
@@ -175,6 +176,8 @@ class ValleAR(_Base):
         beams = self.config.num_beams
         text = prompt_tokens if target_tokens is None else torch.cat((prompt_tokens, target_tokens), dim=0)
         shared = SHARED_PROMPT and self.config.use_kv_cache and self.config.d_model == self.config.n_heads * kernels.HEAD_DIM
+        # (a prompt beyond the shared kernel's record bound — 7680 keys at 4 beams x 8 heads — decodes as independent rows)
+        shared = shared and shared_prompt_fits(beams, self.config.n_heads, int(text.shape[0]) + int(prompt_codes.shape[0]) + 1)   # + BOS
         rows = self.generate_batch([text] * beams, [prompt_codes[..., 0]] * beams, shared_prompt=shared and beams <= MAX_DECODE_ROWS)
         # beams → one sequence (valle_ar.py:174-180); with top_k=1 every log-prob is exactly 0
         sum_logprobs = self.last_generate_stats['sum_logprobs']
