@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 123            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 124            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -424,6 +424,10 @@ typedef struct {
      * greedy step are ONE launch (vh_head_greedy) instead of vh_linear + vh_greedy_step. */
     void *head_ws;
     size_t head_ws_bytes;
+    /* optional: a device uint64 ADDED to `seed` by every sampling step (top_k != 1).  A captured graph freezes `seed`; a decoder
+     * that serves many generate() calls keeps the call's seed here and rewrites it between calls (valle2_amd/valle_ar.py keeps
+     * a decoder per shape: graphs, caches and workspaces survive the call). */
+    const uint64_t *seed_dev;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

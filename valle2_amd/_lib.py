@@ -53,7 +53,7 @@ class VhArDecoderDesc(C.Structure):
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t), ('kv_bf16', C.c_int),
         ('prefix_len', C.c_int), ('prefix_S', C.c_int), ('attn_partial_bytes', C.c_size_t),
-        ('head_ws', C.c_void_p), ('head_ws_bytes', C.c_size_t),
+        ('head_ws', C.c_void_p), ('head_ws_bytes', C.c_size_t), ('seed_dev', C.c_void_p),
     ]
 
 
@@ -219,7 +219,19 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
         fn = getattr(lib, name)   # AttributeError here = header/library drift
         fn.restype = res
         fn.argtypes = args
+    # tuning knobs shape what a decoder captures: whoever keeps captured graphs across calls (valle_ar's decoder slots)
+    # keys them on this count of vh_set_tuning calls
+    raw_set = lib.vh_set_tuning
+
+    def set_tuning(knob, value):
+        global TUNING_EPOCH
+        TUNING_EPOCH += 1
+        return raw_set(knob, value)
+    lib.vh_set_tuning = set_tuning
     return lib
+
+
+TUNING_EPOCH = 0
 
 
 def lib() -> C.CDLL:

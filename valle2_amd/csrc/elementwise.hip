@@ -362,7 +362,9 @@ __global__ __launch_bounds__(256) void sample_step_kernel(
     uint64_t seed, int64_t* __restrict__ codes, int64_t codes_stride, int32_t* __restrict__ eos_count,
     const int32_t* __restrict__ pos_base, float* __restrict__ sum_logprobs,
     const float* __restrict__ audio_emb, const float* __restrict__ pe, int32_t* __restrict__ audio_pos,
-    int32_t* __restrict__ cache_len, float* __restrict__ x_next, int d, int npow2) {
+    int32_t* __restrict__ cache_len, float* __restrict__ x_next, int d, int npow2, const uint64_t* __restrict__ seed_dev) {
+    // a captured graph freezes `seed`; a decoder that outlives one generate() keeps the call's seed in device memory instead
+    if (seed_dev) seed += *seed_dev;
     __shared__ float s_val[SAMPLE_MAXV];
     __shared__ int s_idx[SAMPLE_MAXV];
     __shared__ int s_hist[256];
@@ -563,11 +565,12 @@ __global__ __launch_bounds__(256) void sample_step_kernel(
     }
 }
 
-extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p,
-                              float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
-                              int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
-                              const float* audio_emb, const float* pe, int32_t* audio_pos,
-                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+// vh_sample_step with the seed = seed + *seed_dev (seed_dev may be NULL): the decoder plan's form (plan.hip)
+int vh_internal_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p,
+                            float temperature, uint64_t seed, const uint64_t* seed_dev, int64_t* codes, int64_t codes_stride,
+                            int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
+                            const float* audio_emb, const float* pe, int32_t* audio_pos,
+                            int32_t* cache_len, float* x_next, int B, int d, void* stream) {
     VH_REQUIRE(logits && codes && eos_count && audio_emb && pe && audio_pos && cache_len && x_next,
                VH_EINVAL, "vh_sample_step: null pointer");
     VH_REQUIRE(B > 0 && V > 0 && V <= SAMPLE_MAXV && ldl >= V && d > 0 && d % 4 == 0, VH_EINVAL,
@@ -579,9 +582,18 @@ extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int 
     while (npow2 < V) npow2 <<= 1;
     hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
                        eos, top_k, top_p, 1.0f / temperature, seed, codes, codes_stride, eos_count,
-                       pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, d, npow2);
+                       pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, d, npow2, seed_dev);
     VH_CHECK_LAUNCH("vh_sample_step");
     return VH_OK;
+}
+
+extern "C" int vh_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p,
+                              float temperature, uint64_t seed, int64_t* codes, int64_t codes_stride,
+                              int32_t* eos_count, const int32_t* pos_base, float* sum_logprobs,
+                              const float* audio_emb, const float* pe, int32_t* audio_pos,
+                              int32_t* cache_len, float* x_next, int B, int d, void* stream) {
+    return vh_internal_sample_step(logits, ldl, V, eos, top_k, top_p, temperature, seed, nullptr, codes, codes_stride, eos_count,
+                                   pos_base, sum_logprobs, audio_emb, pe, audio_pos, cache_len, x_next, B, d, stream);
 }
 
 

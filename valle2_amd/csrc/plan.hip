@@ -129,6 +129,10 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
 // One decode step for every row: x (B,d) holds the new token's embedding on entry and the NEXT
 // token's embedding on exit.  `ev` (optional) brackets each decode-attention launch.
 void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop);   // attention.hip
+int vh_internal_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p, float temperature, uint64_t seed,
+                            const uint64_t* seed_dev, int64_t* codes, int64_t codes_stride, int32_t* eos_count,
+                            const int32_t* pos_base, float* sum_logprobs, const float* audio_emb, const float* pe,
+                            int32_t* audio_pos, int32_t* cache_len, float* x_next, int B, int d, void* stream);   // elementwise.hip
 
 static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEvent_t>* ev,
                            std::vector<hipEvent_t>* kev = nullptr) {
@@ -216,9 +220,9 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
         TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
                            d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
     else
-        TRY(vh_sample_step(d.logits, dec->ldl, d.V, d.eos, d.top_k, d.top_p, d.temperature, d.seed,
-                           d.codes, d.codes_stride, d.eos_count, d.pos_base, d.sum_logprobs, d.audio_emb,
-                           d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
+        TRY(vh_internal_sample_step(d.logits, dec->ldl, d.V, d.eos, d.top_k, d.top_p, d.temperature, d.seed, d.seed_dev,
+                                    d.codes, d.codes_stride, d.eos_count, d.pos_base, d.sum_logprobs, d.audio_emb,
+                                    d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));
     return VH_OK;
 }
 

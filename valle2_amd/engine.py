@@ -445,6 +445,9 @@ class ArDecoder:
         self.eos_count = torch.zeros(codes.shape[1] + 1, device=dev, dtype=torch.int32)
         self.sum_logprobs = torch.zeros(batch, **f32)
         self.sampling = (int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature), int(seed))
+        # the sampling seed lives in device memory (desc.seed = 0 + *seed_dev): a captured graph would freeze a by-value
+        # seed, and this decoder may serve many generate() calls (`reset`)
+        self.seed_dev = torch.tensor([int(seed)], dtype=torch.int64).to(dev) if self.sampling[0] != 1 else None
         self.codes, self.cache, self.cache_len, self.audio_pos = codes, cache, cache_len, audio_pos
         self.pos_base = pos_base
         self._folded = folded_layer_norms(model.transformer)   # kept alive: the table holds raw pointers
@@ -474,7 +477,8 @@ class ArDecoder:
             gemm_ws_bytes=ws_bytes, cache_len=ptr(cache_len),
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
-            temperature=self.sampling[2], seed=self.sampling[3] & (2 ** 64 - 1),
+            temperature=self.sampling[2], seed=0 if self.seed_dev is not None else self.sampling[3] & (2 ** 64 - 1),
+            seed_dev=ptr(self.seed_dev),
             sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes,
             kv_bf16=int(self.kv_bf16), prefix_len=self.prefix_len if prefix is not None else 0,
             prefix_S=prefix.s_max if prefix is not None else 0,
@@ -494,6 +498,15 @@ class ArDecoder:
             self._h = None
 
     __del__ = close
+
+    def reset(self, seed=0):
+        """Ready for another generate() over the SAME buffers (codes, caches, cache_len, audio_pos, pos_base are the
+        caller's to refill): counters and scores cleared, the new call's seed written where the captured steps read it."""
+        self.eos_count.zero_()
+        self.sum_logprobs.zero_()
+        self.sampling = self.sampling[:3] + (int(seed),)
+        if self.seed_dev is not None:
+            self.seed_dev.copy_(torch.tensor([int(seed)], dtype=torch.int64), non_blocking=True)
 
     def sample_from(self, hidden_last):
         """Head + greedy step on the last hidden row of a prefill (the tail of step 0)."""

@@ -10,6 +10,8 @@ step (valle_ar.py:169-170).
 from __future__ import annotations
 
 import os
+import threading
+import time
 
 import torch
 import torch.nn as nn
@@ -39,6 +41,28 @@ SHARED_PROMPT = os.environ.get('VALLE2_SHARED_PROMPT', '1') != '0'
 
 class _Run:
     """Shapes and modes of one generate_batch call, handed between its helpers."""
+
+
+class _DecodeSlot:
+    """Everything of a generate_batch call that a captured decode graph points at, kept per SHAPE on the model so that the
+    next call of the same shape neither allocates, nor builds a decoder, nor captures (~1.7 ms of capture +
+    the construction per call, which a 2 ms prompt pass no longer hides): the token buffer, the K/V caches, the per-row
+    counters and the ArDecoder with its graphs and workspaces.  A slot is used by one call at a time (`busy`)."""
+
+    def __init__(self):
+        self.codes = self.cache = self.prefix = self.cache_len = self.audio_pos = self.pos_base = self.dec = None
+        self.busy = False
+        self.uses = 0
+
+    def close(self):
+        if self.dec is not None:
+            self.dec.close()
+            self.dec = None
+
+
+_DECODER_ENV = ('VALLE2_HEAD_FUSED', 'VALLE2_SHARED_SPLIT', 'VALLE2_FOLD_LN')   # environment knobs read when a decoder is built
+DECODER_SLOTS = int(os.environ.get('VALLE2_DECODER_SLOTS', '2'))    # decoders kept per model (0: build one per call, as before)
+_SLOT_LOCK = threading.Lock()
 
 
 class ValleAR(_Base):
@@ -208,6 +232,47 @@ class ValleAR(_Base):
         self.last_generate_stats = merged
         return out
 
+    def _weights_key(self):
+        """Changes whenever a pointer or a value the decoder's tables were built from may have changed."""
+        from . import engine
+        return (engine._WEIGHTS_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _acquire_slot(self, key):
+        """The free slot of this shape (LRU order), or a new one (the oldest free slot beyond DECODER_SLOTS is dropped).
+        None when slots are off."""
+        if DECODER_SLOTS <= 0:
+            return None
+        with _SLOT_LOCK:
+            slots = self.__dict__.setdefault('_decode_slots', {})
+            slot = slots.pop(key, None)
+            if slot is not None and slot.busy:              # another host thread is decoding this shape right now
+                slots[key] = slot
+                return None
+            if slot is None:
+                slot = _DecodeSlot()
+                free = [k for k, v in slots.items() if not v.busy]
+                while len(slots) >= DECODER_SLOTS and free:
+                    slots.pop(free.pop(0)).close()
+            slot.busy = True
+            slots[key] = slot                                # most recently used last
+            return slot
+
+    def _release_slot(self, key, slot, ok):
+        if slot is None:
+            return
+        with _SLOT_LOCK:
+            slot.busy = False
+            if not ok:                                       # a failed call leaves nothing behind
+                self.__dict__.get('_decode_slots', {}).pop(key, None)
+                slot.close()
+
+    def release_decoders(self):
+        """Free the decoders (graphs, K/V caches, workspaces) kept from earlier generate() calls."""
+        with _SLOT_LOCK:
+            for slot in self.__dict__.pop('_decode_slots', {}).values():
+                if not slot.busy:
+                    slot.close()
+
     def _prompt_pass(self, run, texts, first_codes, codes):
         """Step 0 (valle_ar.py:143-155 at kv_cache=None): embed and run the whole prompt.  Row b is laid out
         [text_b | BOS + prompt_b | padding]; the prefix-LM mask takes per-row lengths.  Returns the K/V cache the decode
@@ -217,7 +282,10 @@ class ValleAR(_Base):
         B, s0, s_max = run.B, run.s0, run.s_max
         i32 = dict(device=dev, dtype=torch.int32)
         prefix = None
-        if run.any_head_dim:
+        slot = getattr(run, 'slot', None)
+        if slot is not None and slot.cache is not None:
+            cache, prefix = slot.cache, slot.prefix          # the buffers this shape's captured graphs point at
+        elif run.any_head_dim:
             cache = None
         elif run.shared:
             # ONE row through the prompt pass: its K/V are the prefix every beam reads; the beams' cache holds generated rows only
@@ -375,7 +443,22 @@ class ValleAR(_Base):
         run.shared = bool(shared_prompt)
         if run.shared and (perf_mode or run.ragged):
             raise ValueError('shared_prompt: identical rows, fp32')
-        codes = torch.full((B, run.pl_max + run.max_new), self.eos_token, device=dev, dtype=torch.int64)
+        t_host0 = time.perf_counter()
+        # a decoder per shape survives the call (graphs, caches, counters: _DecodeSlot) unless the call is one of the
+        # measurement / test forms that drive the decoder by hand
+        slot_key = slot = None
+        if not (no_cache or forced is not None or profile_attn or (perf_mode and not run.perf_prefill)):
+            slot_key = (B, run.s0 if run.shared else None, run.s_max, run.pl_max + run.max_new, run.max_new, run.shared,
+                        run.perf_prefill, bool(use_graph), int(cfg.top_k), float(cfg.tok_p), float(cfg.temperature),
+                        str(dev), _lib.TUNING_EPOCH, tuple(os.environ.get(k) for k in _DECODER_ENV), self._weights_key())
+            slot = self._acquire_slot(slot_key)
+        run.slot = slot
+        reuse = slot is not None and slot.dec is not None
+        if reuse:
+            codes = slot.codes
+            codes.fill_(self.eos_token)
+        else:
+            codes = torch.full((B, run.pl_max + run.max_new), self.eos_token, device=dev, dtype=torch.int64)
         codes[:, 0] = self.bos_token                                   # valle_ar.py:115-117
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(3)]   # prefill | decode phase times
         marks[0].record()
@@ -388,19 +471,46 @@ class ValleAR(_Base):
         # would hold the host until the pass has finished, and the decoder is built and captured during the pass)
         # cache_len: rows in the cache the decode steps append to (+1 by the sample step); shared prompt: generated rows only
         first_len = [-1] * B if run.shared else [t + p - 1 for t, p in zip(run.txs, run.pls)]
-        cache_len = _lib.to_device_async(torch.tensor(first_len, dtype=torch.int32), dev)
-        audio_pos = _lib.to_device_async(torch.tensor(run.pls, dtype=torch.int32), dev)
-        pos_base = audio_pos.clone()
-        cache, prefix, last = self._prompt_pass(run, texts, first_codes, codes)
+        if reuse:
+            cache_len, audio_pos, pos_base = slot.cache_len, slot.audio_pos, slot.pos_base
+            cache_len.copy_(torch.tensor(first_len, dtype=torch.int32), non_blocking=True)
+            audio_pos.copy_(torch.tensor(run.pls, dtype=torch.int32), non_blocking=True)
+            pos_base.copy_(audio_pos)
+        else:
+            cache_len = _lib.to_device_async(torch.tensor(first_len, dtype=torch.int32), dev)
+            audio_pos = _lib.to_device_async(torch.tensor(run.pls, dtype=torch.int32), dev)
+            pos_base = audio_pos.clone()
         # sampling seed drawn from torch's generator, so torch.manual_seed() makes a run repeatable
         seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if cfg.top_k != 1 else 0
-        if run.any_head_dim:
+        if reuse:
+            slot.dec.reset(seed)                          # (before the prompt pass is enqueued: its copies do not queue behind it)
+        t_host1 = time.perf_counter()
+        ok = False
+        try:
+            cache, prefix, last = self._prompt_pass(run, texts, first_codes, codes)
+        except BaseException:
+            self._release_slot(slot_key, slot, False)
+            raise
+        t_host2 = time.perf_counter()
+        if reuse:
+            dec = slot.dec
+        elif run.any_head_dim:
             dec = StepSampler(self, B, codes, cache_len, audio_pos, pos_base, seed=seed)
         else:
-            dec = ArDecoder(self, B, cache.s_max, codes, cache, cache_len, audio_pos, pos_base,
-                            use_graph=use_graph and not no_cache, seed=seed, prefix=prefix, prefix_len=run.s0)
+            try:
+                dec = ArDecoder(self, B, cache.s_max, codes, cache, cache_len, audio_pos, pos_base,
+                                use_graph=use_graph and not no_cache, seed=seed, prefix=prefix, prefix_len=run.s0)
+            except BaseException:
+                self._release_slot(slot_key, slot, False)
+                raise
+            if slot is not None:
+                slot.codes, slot.cache, slot.prefix, slot.dec = codes, cache, prefix, dec
+                slot.cache_len, slot.audio_pos, slot.pos_base = cache_len, audio_pos, pos_base
+        if slot is not None:
+            slot.uses += 1
         try:
             dec.capture()                                 # (a no-op without a graph: the no-cache path only borrows the sampler)
+            t_host3 = time.perf_counter()
             dec.sample_from(last)
             marks[1].record()
             del last
@@ -421,6 +531,7 @@ class ValleAR(_Base):
                 stop = int(full[0]) if full.numel() else None
             n_new = run.max_new if stop is None else stop     # the all-EOS step is not appended (:169-171)
             marks[2].synchronize()
+            t_host4 = time.perf_counter()
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
                                         'ffn_fused': dec.ffn_ws is not None and cfg.d_model <= 512, 'kv_bf16': dec.kv_bf16,
@@ -431,10 +542,24 @@ class ValleAR(_Base):
                                         'attn_mean_ms': attn_ms, 'attn_floor_ms': attn_floor_ms,
                                         'attn_kernel_ms': attn_kernel_ms, 's0': run.s0,
                                         'prompt_lens': run.pls,
-                                        'sum_logprobs': dec.sum_logprobs.clone()}
-            return codes[:, : run.pl_max + n_new].clone()
+                                        'sum_logprobs': dec.sum_logprobs.clone(),
+                                        # host time this call spent OUTSIDE enqueueing the prompt pass and the replays and
+                                        # waiting for them: set-up of the call's state + building / capturing the decoder
+                                        # (nothing on a reused slot) + the tail after the last step has finished
+                                        'decoder_reused': bool(reuse), 'slot_uses': slot.uses if slot is not None else 0,
+                                        'host_setup_ms': (t_host1 - t_host0) * 1e3,
+                                        'host_decoder_ms': (t_host3 - t_host2) * 1e3}
+            out_codes = codes[:, : run.pl_max + n_new].clone()
+            self.last_generate_stats['host_tail_ms'] = (time.perf_counter() - t_host4) * 1e3
+            self.last_generate_stats['host_outside_ms'] = (self.last_generate_stats['host_setup_ms']
+                                                           + self.last_generate_stats['host_decoder_ms']
+                                                           + self.last_generate_stats['host_tail_ms'])
+            ok = True
+            return out_codes
         finally:
-            dec.close()
+            if slot is None or dec is not slot.dec:
+                dec.close()
+            self._release_slot(slot_key, slot, ok)
 
     def configure_optimizers(self):
         """valle_ar.py:182-194"""
