@@ -53,7 +53,8 @@ sys.path.insert(0, str(REPO))
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32 MFMA dense peak
-MFMA_BF16_PEAK_TF = 2500.0 # bf16 MFMA DENSE peak (MI355X_MICROARCH.md: ~2.5 PF; the 5 PF headline figure is with 2:1 sparsity)
+MFMA_BF16_PEAK_TF = 2500.0 # bf16 / fp16 MFMA DENSE peak (MI355X_MICROARCH.md: ~2.5 PF, the F16 forms take the same cycles; the 5 PF
+                           # headline figure is with 2:1 sparsity).  The 16-bit operand format of perf mode is the library's (`h16_name`).
 
 AR = dict(d_model=512, n_heads=8, dim_feedforward=2048, num_layers=12, dropout=0.0, norm='LayerNorm',
           top_k=1, use_kv_cache=True)
@@ -359,7 +360,7 @@ def config5_leg(dev):
     torch.cuda.synchronize()
     dt16 = time.perf_counter() - t0
     same = float(torch.stack([(a == b).float().mean() for a, b in zip(codes, codes16)]).mean())
-    res['nar']['perf_mode'] = {'label': 'SECONDARY, not the metric: the seven stage forwards with bf16 operands / fp32 accumulators',
+    res['nar']['perf_mode'] = {'label': f'SECONDARY, not the metric: the seven stage forwards with {h16_name()} operands / fp32 accumulators',
                                'ms_total': dt16 * 1e3, 'ms_per_stage': dt16 * 1e3 / stages, 'tflops': flop / dt16 / 1e12,
                                'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF, 'frac_of_bf16_peak': flop / dt16 / 1e12 / MFMA_BF16_PEAK_TF,
                                'vs_f32': dtn / dt16, 'greedy_codes_equal_to_f32_run': same}
@@ -532,6 +533,13 @@ def train_leg(dev, world, rank, small):
         del model, opt, reducer
         torch.cuda.empty_cache()
     return out
+
+
+def h16_name():
+    """'fp16' (default build) or 'bf16' (-DVH_PERF_BF16): the 16-bit operand format of the perf-mode kernels and the narrow K/V cache."""
+    import torch
+    from valle2_amd._lib import h16_dtype
+    return 'fp16' if h16_dtype() == torch.float16 else 'bf16'
 
 
 def main():
@@ -813,7 +821,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_perf_mode:
         # SURVEY section 7's perf mode, a LABELLED SECONDARY line (narrower storage than the reference: never the headline,
         # never `dtype`): the same generate over a bf16 K/V cache, everything else fp32
-        log('perf_mode: the same generate over a bf16 K/V cache')
+        log(f'perf_mode: the same generate over a {h16_name()} K/V cache')
         out_p = model.generate_batch(texts, firsts, perf_mode=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -829,17 +837,17 @@ def main():
         dec_bytes_p = 2.0 * kv_elems + 4.0 * other
         gbs_p = dec_bytes_p / (st_p['decode_ms'] * 1e-3) / 1e9
         result['perf_mode'] = {
-            'label': 'SECONDARY, not the metric: K/V cache stored as bf16 (weights, activations, softmax, accumulators fp32); '
+            'label': f'SECONDARY, not the metric: K/V cache stored as {h16_name()} (weights, activations, softmax, accumulators fp32); '
                      'teacher-forced logits within atol 5e-2 of the reference (tests/test_fullsize_golden_gpu.py), greedy '
                      'tokens not guaranteed',
-            'storage': 'bf16 K/V cache, fp32 weights', 'value': rows * new / dtp, 'unit': 'tokens/s',
+            'storage': f'{h16_name()} K/V cache, fp32 weights', 'h16_format': h16_name(), 'value': rows * new / dtp, 'unit': 'tokens/s',
             'ms_per_generate': dtp * 1e3, 'decode_ms_per_step': st_p['decode_ms'] / (new - 1),
             'algorithmic_bytes_total': dec_bytes_p, 'achieved': gbs_p, 'peak': HBM_PEAK_GBS, 'unit_bw': 'GB/s',
             'frac': gbs_p / HBM_PEAK_GBS, 'vs_f32_headline': (rows * new / dtp) / (value / world),
             'greedy_tokens_equal_to_f32_run': float((out_p == out).float().mean()),
             # the prompt pass of this mode runs on the bf16 matrix cores (round 5): same flop count as `prefill`, priced
             # against the bf16 dense peak of MI355X_MICROARCH.md (~2.5 PF/s; AMD's 5 PF figure is with 2:1 sparsity)
-            'prefill': {'storage': 'bf16 operands (weights narrowed once per weight set, activations in the producers\' epilogues), '
+            'prefill': {'storage': f'{h16_name()} operands (weights narrowed once per weight set, activations in the producers\' epilogues), '
                                    'fp32 accumulators, residual stream, LayerNorm statistics, softmax',
                         'ms': st_p['prefill_ms'], 'prefill_bf16': bool(st_p.get('prefill_bf16')),
                         'tflops': prefill_flop / (st_p['prefill_ms'] * 1e-3) / 1e12, 'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF,
@@ -914,7 +922,7 @@ def main():
             torch.cuda.synchronize()
             t16 = (time.perf_counter() - t0) / reps
             result['nar']['perf_mode'] = {
-                'label': 'SECONDARY, not the metric: the stage forward with bf16 operands / fp32 accumulators (teacher-forced '
+                'label': f'SECONDARY, not the metric: the stage forward with {h16_name()} operands / fp32 accumulators (teacher-forced '
                          'logits within atol 5e-2 of the reference: tests/test_bf16_gpu.py)',
                 'value': NAR_B * s / t16, 'unit': 'tokens/s', 'ms_per_stage': t16 * 1e3, 'tflops': flop / t16 / 1e12,
                 'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF, 'frac_of_bf16_peak': flop / t16 / 1e12 / MFMA_BF16_PEAK_TF,
@@ -940,7 +948,7 @@ def main():
             entry = {'ms_total': t_all * 1e3, 'value': NAR_B * target * stages / t_all, 'unit': 'codec tokens/s',
                      'tflops': stages * flop / t_all / 1e12}
             if mode:
-                all_stages['perf_mode'] = dict(entry, label='SECONDARY, not the metric: bf16 operands / fp32 accumulators',
+                all_stages['perf_mode'] = dict(entry, label=f'SECONDARY, not the metric: {h16_name()} operands / fp32 accumulators',
                                                vs_f32=all_stages['ms_total'] / entry['ms_total'])
             else:
                 all_stages = dict(entry, workload='configs[2] as generate() runs it: 64 rows x (256 text + 150-frame prompt + 618 '

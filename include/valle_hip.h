@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 124            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 125            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -640,6 +640,11 @@ int vh_transformer_forward(const vh_forward_desc* desc, void* stream);
  *                           (B,h,S_max,64) — the layout vh_attn_decode_kv16 streams, so a perf-mode generate needs no
  *                           narrowing pass.  d_model % 128 == 0.
  *   vh_attn_rows_bf16       vh_attn_rows over bf16 q / K / V with a bf16 output; analytic masks only (FULL / PREFIX). */
+/* The 16-bit operand format ("h16") of everything called *bf16 / *kv16 / *16 in this header — operands of the perf-mode kernels and
+ * the narrow K/V cache of the decode step: 0 = IEEE fp16 (the default build: same MFMA rate as bf16, 11 bits of significand
+ * against 8 — teacher-forced logits of the 24-layer stack 5.5e-3 from the reference against 4.2e-2), 1 = bf16 (the round-5
+ * format, -DVH_PERF_BF16).  The entry points keep their round-5 names; the narrowing is IEEE (overflow -> infinity, NaN stays NaN). */
+int vh_h16_format(void);
 int vh_to_bf16(const float* src, int64_t lds, uint16_t* dst, int64_t ldd, int64_t rows, int cols, void* stream);
 int vh_layernorm_bf16(const float* x, const float* gamma, const float* beta, const float* ada_scale,
                       const float* ada_shift, uint16_t* out, int rows, int d, float eps, void* stream);

@@ -23,6 +23,10 @@ from tests.golden import cases as C
 from tests.oracle_runners import load_golden
 
 pytestmark = pytest.mark.gpu
+# perf mode (SECONDARY): SURVEY 8c allows teacher-forced logits 5e-2 off the reference; with the default fp16 operand format the
+# measured errors are 8e-4 ... 7e-3 (bf16 build: 9e-3 ... 4.8e-2) — the bound follows the format the library carries
+from valle2_amd._lib import h16_dtype
+PERF_TOL = 1.5e-2 if h16_dtype() == torch.float16 else 5e-2
 DEV = 'cuda'
 
 
@@ -129,7 +133,7 @@ def test_config4_ar_leg_long_context_perf_mode_within_tolerance():
     got = torch.stack([st['logits'][t][0] for t in steps]).cpu()
     err = float((got - gold['logits']).abs().max())
     print(f'config4 long context, perf mode: max |logit error| = {err:.2e}')
-    assert err < 5e-2, err
+    assert err < PERF_TOL, err
 
 
 def test_config1_full_size_prefill_logits_match_the_reference():
@@ -276,7 +280,7 @@ def test_perf_mode_teacher_forced_logits_within_tolerance():
         rows = torch.stack([st['logits'][t] for t in steps])
         assert float((rows - rows[:, :1]).abs().max()) == 0.0        # 32 identical beams: identical logits
     assert errs[False] < 2e-4, errs
-    assert errs[True] < 5e-2, errs
+    assert errs[True] < PERF_TOL, errs
     free = m.generate_batch([text] * 32, [first] * 32, max_new=512, perf_mode=True)
     agree = float((free[0, 768:].cpu() == gold['tokens']).float().mean())
     print(f'perf mode: max |logit error| {errs[True]:.2e} (parity path {errs[False]:.2e}); '

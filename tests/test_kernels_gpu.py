@@ -11,6 +11,8 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+from valle2_amd._lib import h16_dtype
+H16 = h16_dtype()      # the library's 16-bit operand format (fp16 by default, bf16 with -DVH_PERF_BF16)
 
 DEV = 'cuda'
 
@@ -603,7 +605,7 @@ def test_attn_decode_long_context(K, form, S):
     k = torch.randn(B, h, S_max, 64, generator=gen)
     v = torch.randn(B, h, S_max, 64, generator=gen)
     if form == 'kv16':
-        k, v = k.bfloat16(), v.bfloat16()
+        k, v = k.to(H16), v.to(H16)
     tails = [0, 1, 31, 32, 33, 255, 256, 1000, S // 2, S - 1537, 63, 64, 65, 511, 512, 513]
     lens = torch.tensor([max(1, S - tails[i % len(tails)]) for i in range(B)], dtype=torch.int32)
     ref = _decode_ref64(q, k.float(), v.float(), lens, h)
@@ -882,8 +884,8 @@ def test_attn_decode_kv16_matches_fp32_math_on_the_rounded_cache(K, S_max):
     d = 64 * h
     gen = g(170 + S_max)
     q = torch.randn(B, d, generator=gen)
-    k = torch.randn(B, h, S_max, 64, generator=gen).bfloat16()
-    v = torch.randn(B, h, S_max, 64, generator=gen).bfloat16()
+    k = torch.randn(B, h, S_max, 64, generator=gen).to(H16)
+    v = torch.randn(B, h, S_max, 64, generator=gen).to(H16)
     edges = [1, 2, 5, 31, 32, 33, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1024, 1087]
     lens = torch.tensor([min(S_max, edges[i % len(edges)] + (i // len(edges))) for i in range(B)], dtype=torch.int32)
     ref = torch.empty(B, d)
@@ -899,15 +901,15 @@ def test_attn_decode_kv16_matches_fp32_math_on_the_rounded_cache(K, S_max):
 
 
 def test_kv_narrowing_and_bf16_append_round_to_nearest_even(K):
-    """vh_kv_to_bf16 == torch's .bfloat16() bit for bit on the valid rows; vh_linear_qkv_folded_kv16 appends exactly the
+    """vh_kv_to_bf16 == torch's .to(H16) bit for bit on the valid rows; vh_linear_qkv_folded_kv16 appends exactly the
     bf16 rounding of what vh_linear_qkv_folded appends in fp32, and leaves q untouched."""
     from valle2_amd import engine
     L, B, h, S0, S1 = 2, 5, 2, 37, 64
     cache = engine.KVCache(L, B, h, S0, DEV)
     cache.buf.copy_(torch.randn(cache.buf.shape, generator=g(191)) * 3)
     narrow = cache.narrowed(S1)
-    assert narrow.buf.dtype == torch.bfloat16 and tuple(narrow.buf.shape) == (L, 2, B, h, S1, 64)
-    assert torch.equal(narrow.buf[..., :S0, :].view(torch.int16), cache.buf.bfloat16().view(torch.int16))
+    assert narrow.buf.dtype == H16 and tuple(narrow.buf.shape) == (L, 2, B, h, S1, 64)
+    assert torch.equal(narrow.buf[..., :S0, :].view(torch.int16), cache.buf.to(H16).view(torch.int16))
     d = 64 * h
     gen = g(192)
     x = (torch.randn(B, d, generator=gen) + 0.2).to(DEV)
@@ -917,10 +919,10 @@ def test_kv_narrowing_and_bf16_append_round_to_nearest_even(K):
     k32, v32 = torch.zeros(B, h, S1, 64, device=DEV), torch.zeros(B, h, S1, 64, device=DEV)
     q32 = torch.empty(B, d, device=DEV)
     K.linear_qkv_folded(x, folded, q32, k32, v32, B, 1, h, cache_len=cl)
-    k16 = torch.zeros(B, h, S1, 64, device=DEV, dtype=torch.bfloat16)
+    k16 = torch.zeros(B, h, S1, 64, device=DEV, dtype=H16)
     v16 = torch.zeros_like(k16)
     q16 = torch.empty(B, d, device=DEV)
     K.linear_qkv_folded_kv16(x, folded, q16, k16, v16, h, cl)
     assert torch.equal(q16, q32)
-    assert torch.equal(k16.view(torch.int16), k32.bfloat16().view(torch.int16))
-    assert torch.equal(v16.view(torch.int16), v32.bfloat16().view(torch.int16))
+    assert torch.equal(k16.view(torch.int16), k32.to(H16).view(torch.int16))
+    assert torch.equal(v16.view(torch.int16), v32.to(H16).view(torch.int16))

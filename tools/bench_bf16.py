@@ -13,6 +13,8 @@ import torch
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 DEV = 'cuda'
+from valle2_amd._lib import h16_dtype  # noqa: E402
+H16 = h16_dtype()          # the library's 16-bit operand format (fp16 by default)
 
 
 def timeit(fn, reps):
@@ -45,18 +47,18 @@ def main():
                                            (2048, 512, 1, False, True, 'linear_1+gelu'), (512, 2048, 0, True, False, 'linear_2')):
             a32 = torch.randn(M, Kd, generator=g).to(DEV)
             w32 = (0.05 * torch.randn(N, Kd, generator=g)).to(DEV)
-            a, w = a32.bfloat16(), w32.bfloat16()
+            a, w = a32.to(H16), w32.to(H16)
             bias = torch.randn(N, generator=g).to(DEV)
             r = torch.randn(M, N, generator=g).to(DEV) if res else None
-            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16 if o16 else torch.float32)
+            out = torch.empty(M, N, device=DEV, dtype=H16 if o16 else torch.float32)
             out32 = torch.empty(M, N, device=DEV)
-            o2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            o2 = torch.empty(M, N, device=DEV, dtype=H16)
             wt = w.T
 
             def blas_same():
                 y = torch.matmul(a, wt, out=o2)
                 if o16:
-                    y = y + bias.bfloat16()
+                    y = y + bias.to(H16)
                     return torch.nn.functional.gelu(y) if act else y
                 y = y.float() + bias
                 return y + r if res else y
@@ -85,8 +87,8 @@ def main():
         k32 = torch.randn(B, h, T, 64, generator=g).to(DEV)
         v32 = torch.randn(B, h, T, 64, generator=g).to(DEV)
         o32 = torch.empty(B * T, d, device=DEV)
-        q, k, v = q32.bfloat16(), k32.bfloat16(), v32.bfloat16()
-        o = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+        q, k, v = q32.to(H16), k32.to(H16), v32.to(H16)
+        o = torch.empty(B * T, d, device=DEV, dtype=H16)
         kw = dict(mode=K.MASK_FULL) if mode == 'full' else dict(mode=K.MASK_PREFIX, x_len=256)
         t16 = timeit(lambda: K.attn_rows_bf16(q, k, v, o, B, h, T, T, **kw), args.reps)
         t32 = timeit(lambda: K.attn_rows(q32, k32, v32, o32, B, h, T, T, **kw), args.reps)
@@ -97,7 +99,7 @@ def main():
     for rows in (32768, 65536):
         x = torch.randn(rows, 512, generator=g).to(DEV)
         gm, bt = torch.ones(512, device=DEV), torch.zeros(512, device=DEV)
-        o = torch.empty(rows, 512, device=DEV, dtype=torch.bfloat16)
+        o = torch.empty(rows, 512, device=DEV, dtype=H16)
         t = timeit(lambda: K.layernorm_bf16(x, gm, bt, out=o), args.reps)
         print(f'rows={rows} {t:7.1f} us = {rows * 512 * 6 / t * 1e-6:5.2f} TB/s')
     if args.skip_model:
@@ -117,7 +119,7 @@ def main():
         x = torch.empty_like(x0)
         emb = m.stage_embs[2].weight if name == 'nar' else None
         c32 = engine.KVCache(12, B, 8, T, DEV)
-        c16 = engine.KVCache(12, B, 8, T, DEV, dtype=torch.bfloat16)
+        c16 = engine.KVCache(12, B, 8, T, DEV, dtype=H16)
         s32, s16 = engine.ForwardScratch(B * T, 512, 2048, DEV), engine.ForwardScratch16(B * T, 512, 2048, DEV)
 
         def f32():

@@ -16,8 +16,15 @@ DEV = 'cuda'
 SITES = ('xn1', 'wqkv', 'q', 'k', 'v', 'p', 'attn', 'wo', 'xn2', 'w1', 'hidden', 'w2')
 
 
+FMT = torch.bfloat16        # (this probe compares the two formats whatever the library was built with)
+PEAK = [0.0]
+
+
 def rb(t, on):
-    return t.bfloat16().float() if on else t
+    if on:
+        PEAK[0] = max(PEAK[0], float(t.abs().max()))
+        return t.to(FMT).float()
+    return t
 
 
 def emulated_forward(transformer, x, cache, *, mode, x_len=0, x_len_dev=None, kv_len=None, embedding=None, scratch=None, x_in=None,
@@ -89,6 +96,13 @@ def main():
     print(f'emulation, everything narrowed: {run(SITES):.3e}')
     for s in SITES:
         print(f'   all but {s:7s}: {run([t for t in SITES if t != s]):.3e}      only {s:7s}: {run([s]):.3e}', flush=True)
+    global FMT
+    FMT = torch.float16
+    PEAK[0] = 0.0
+    print(f'the same stack with fp16 in place of bf16 at every site: {run(SITES):.3e} (stage 7), {run(SITES, 2):.3e} (stage 2); '
+          f'largest magnitude narrowed: {PEAK[0]:.1f} (fp16 holds 65504)')
+    FMT = torch.bfloat16
+    print(f'bf16 again, stage 2: {run(SITES, 2):.3e}')
     groups = {'weights': ('wqkv', 'wo', 'w1', 'w2'), 'scores (q, k)': ('q', 'k'), 'norm outputs': ('xn1', 'xn2'),
               'attention values (v, p, attn)': ('v', 'p', 'attn')}
     for name, g in groups.items():

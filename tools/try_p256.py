@@ -12,6 +12,8 @@ import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 DEV = 'cuda'
+from valle2_amd._lib import h16_dtype  # noqa: E402
+H16 = h16_dtype()          # the library's 16-bit operand format (fp16 by default)
 
 
 def timeit(fn, reps):
@@ -41,8 +43,8 @@ def main():
                                     (1000, 512, 512, True, 1, False), (4096, 512, 2048, False, 0, True),
                                     (16384 + 77, 2048, 512, True, 1, False), (20000, 1536, 512, False, 1, True),
                                     (65536, 512, 512, True, 0, False)):
-        a = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
-        w = (0.05 * torch.randn(N, Kd, generator=g)).bfloat16().to(DEV)
+        a = torch.randn(M, Kd, generator=g).to(H16).to(DEV)
+        w = (0.05 * torch.randn(N, Kd, generator=g)).to(H16).to(DEV)
         bias = torch.randn(N, generator=g).to(DEV)
         r = torch.randn(M, N, generator=g).to(DEV) if res else None
         ref = a.double() @ w.double().T + bias.double()
@@ -70,7 +72,7 @@ def main():
     w = ((2 * n + k) % 5 - 2).float()
     ref = a @ w.T
     L.vh_set_tuning(15, 4)
-    out = K.linear_bf16(a.bfloat16().to(DEV), w.bfloat16().to(DEV))
+    out = K.linear_bf16(a.to(H16).to(DEV), w.to(H16).to(DEV))
     L.vh_set_tuning(15, 0)
     ok = torch.equal(out.cpu(), ref)
     print('integer operands exact:', ok, flush=True)
@@ -79,13 +81,13 @@ def main():
     for B, T, h, with_len in ((3, 150, 8, True), (40, 7, 8, True), (33, 1024, 8, False)):
         d = 64 * h
         S_max = T + 20
-        a = torch.randn(B * T, d, generator=g).bfloat16().to(DEV)
-        w = (0.1 * torch.randn(3 * d, d, generator=g)).bfloat16().to(DEV)
+        a = torch.randn(B * T, d, generator=g).to(H16).to(DEV)
+        w = (0.1 * torch.randn(3 * d, d, generator=g)).to(H16).to(DEV)
         ref = (a.double() @ w.double().T).float()
         cl = torch.tensor([(3 * i) % 17 for i in range(B)], dtype=torch.int32).to(DEV) if with_len else None
-        kc = torch.zeros(B, h, S_max, 64, device=DEV, dtype=torch.bfloat16)
+        kc = torch.zeros(B, h, S_max, 64, device=DEV, dtype=H16)
         vc = torch.zeros_like(kc)
-        q = torch.empty(B * T, d, device=DEV, dtype=torch.bfloat16)
+        q = torch.empty(B * T, d, device=DEV, dtype=H16)
         L.vh_set_tuning(15, 4)
         K.linear_qkv_bf16(a, w, q, kc, vc, B, T, h, cache_len=cl)
         torch.cuda.synchronize()
@@ -112,11 +114,11 @@ def main():
     for M in (32768, 65536):
         for N, Kd, act, res, o16, name in ((1536, 512, 0, False, True, 'qkv-like'), (512, 512, 0, True, False, 'out-proj'),
                                            (2048, 512, 1, False, True, 'linear_1+gelu'), (512, 2048, 0, True, False, 'linear_2')):
-            a = torch.randn(M, Kd, generator=g).bfloat16().to(DEV)
-            w = (0.05 * torch.randn(N, Kd, generator=g)).bfloat16().to(DEV)
+            a = torch.randn(M, Kd, generator=g).to(H16).to(DEV)
+            w = (0.05 * torch.randn(N, Kd, generator=g)).to(H16).to(DEV)
             bias = torch.randn(N, generator=g).to(DEV)
             r = torch.randn(M, N, generator=g).to(DEV) if res else None
-            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16 if o16 else torch.float32)
+            out = torch.empty(M, N, device=DEV, dtype=H16 if o16 else torch.float32)
             tv = {}
             for rnd in range(3):
                 for form in (1, 3, 4):
@@ -125,7 +127,7 @@ def main():
                                                      out_bf16=o16), args.reps)
                     tv[form] = min(tv.get(form, 1e30), t)
                 wt = w.T
-                o2 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+                o2 = torch.empty(M, N, device=DEV, dtype=H16)
                 t = timeit(lambda: torch.matmul(a, wt, out=o2), args.reps)
                 tv['blas'] = min(tv.get('blas', 1e30), t)
             L.vh_set_tuning(15, 0)

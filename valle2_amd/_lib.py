@@ -192,6 +192,7 @@ SIGNATURES = {
                                   C.c_int64, C.c_int, c_f32p, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int,
                                   C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'vh_transformer_forward': (C.c_int, [C.POINTER(VhForwardDesc), C.c_void_p]),
+    'vh_h16_format': (C.c_int, []),
     'vh_to_bf16': (C.c_int, [c_f32p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     'vh_layernorm_bf16': (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                     C.c_void_p]),
@@ -232,6 +233,18 @@ def load_library(path: os.PathLike | None = None) -> C.CDLL:
 
 
 TUNING_EPOCH = 0
+
+
+def h16_dtype():
+    """torch dtype of the library's 16-bit operand format ("h16": operands of the perf-mode kernels, the narrow K/V cache):
+    float16 in the default build, bfloat16 in a -DVH_PERF_BF16 one (include/valle_hip.h, vh_h16_format).  Needs no GPU."""
+    global _H16
+    if _H16 is None:
+        _H16 = torch.bfloat16 if load_library().vh_h16_format() else torch.float16
+    return _H16
+
+
+_H16 = None
 
 
 def lib() -> C.CDLL:

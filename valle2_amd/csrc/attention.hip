@@ -310,8 +310,8 @@ __device__ __forceinline__ float row8_sum(float v) {
     v += dpp_get<0x141, 0xF>(v, 0.f);     // row_half_mirror: lane i <-> 7 - i inside each half row
     return v;
 }
-#define BF_LO(w) __uint_as_float((w) << 16)
-#define BF_HI(w) __uint_as_float((w) & 0xffff0000u)
+#define BF_LO(w) vh_h16_lo(w)
+#define BF_HI(w) vh_h16_hi(w)
 
 template <int NW, int D>
 __global__ __launch_bounds__(NW * 64) void attn_decode_ring16_kernel(
@@ -427,10 +427,9 @@ __global__ __launch_bounds__(256) void kv_to_bf16_kernel(const float* __restrict
     const int64_t n8 = (int64_t)rows * HD / 8;
     for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
         const f32x4 a = ld4(s + 8 * i), c = ld4(s + 8 * i + 4);
-        auto bf = [](float x) { const uint32_t u = __float_as_uint(x); return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16; };
         u32x4 o;
-        o.x = bf(a.x) | (bf(a.y) << 16); o.y = bf(a.z) | (bf(a.w) << 16);
-        o.z = bf(c.x) | (bf(c.y) << 16); o.w = bf(c.z) | (bf(c.w) << 16);
+        o.x = vh_pack_h16(a.x, a.y); o.y = vh_pack_h16(a.z, a.w);
+        o.z = vh_pack_h16(c.x, c.y); o.w = vh_pack_h16(c.z, c.w);
         *reinterpret_cast<u32x4*>(d + 8 * i) = o;
     }
 }

@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int s = t & 1;
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fw[s][0], acc[0][0], 0, 0, 0);
+            acc[0][0] = VH_MFMA16(fa[s][0], fw[s][0], acc[0][0]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (PF) {                           // all eight pieces in the first two groups: a piece requested in
                 if (t < 2) {                              // the last group would be waited for the moment it is issued
@@ -239,9 +239,9 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
                 fload(0, cur ^ 1, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][0], fw[s][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fw[s][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s][1], fw[s][1], acc[1][1], 0, 0, 0);
+            acc[0][1] = VH_MFMA16(fa[s][0], fw[s][1], acc[0][1]);
+            acc[1][0] = VH_MFMA16(fa[s][1], fw[s][0], acc[1][0]);
+            acc[1][1] = VH_MFMA16(fa[s][1], fw[s][1], acc[1][1]);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -454,10 +454,10 @@ __global__ __launch_bounds__(256, 3) void gemm16_ring_kernel(Gemm16Args a, int t
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], fw[t][0], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], fw[t][1], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], fw[t][0], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], fw[t][1], acc[1][1], 0, 0, 0);
+            acc[0][0] = VH_MFMA16(fa[t][0], fw[t][0], acc[0][0]);
+            acc[0][1] = VH_MFMA16(fa[t][0], fw[t][1], acc[0][1]);
+            acc[1][0] = VH_MFMA16(fa[t][1], fw[t][0], acc[1][0]);
+            acc[1][1] = VH_MFMA16(fa[t][1], fw[t][1], acc[1][1]);
         }
         // the fragments are in registers before the wave can reach the next barrier: its reads of this stage are done
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -628,10 +628,10 @@ __global__ __launch_bounds__(256, 4) void gemm16_occ_kernel(Gemm16Args a, int ti
             const int off = ((2 * t + h) ^ swz) << 4;
             const bf16x8 a0 = __builtin_bit_cast(bf16x8, ldq(fA + off)), a1 = __builtin_bit_cast(bf16x8, ldq(fA + off + 32 * 128));
             const bf16x8 w0 = __builtin_bit_cast(bf16x8, ldq(fW + off)), w1 = __builtin_bit_cast(bf16x8, ldq(fW + off + 32 * 128));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, w1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, w1, acc[1][1], 0, 0, 0);
+            acc[0][0] = VH_MFMA16(a0, w0, acc[0][0]);
+            acc[0][1] = VH_MFMA16(a0, w1, acc[0][1]);
+            acc[1][0] = VH_MFMA16(a1, w0, acc[1][0]);
+            acc[1][1] = VH_MFMA16(a1, w1, acc[1][1]);
         }
         __syncthreads();                                    // every wave has read the slab: it may be overwritten
     }
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = __builtin_bit_cast(bf16x8, ldq(kl + (32 * u + r) * 128 + (((2 * s + h) ^ kswz) << 4)));
-                    sacc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[u], 0, 0, 0);
+                    sacc[u] = VH_MFMA16(kf, qf[s], sacc[u]);
                 }
             }
             // ---- mask (only on tiles that need it: wave-uniform test) and the tile's row maximum
@@ -940,8 +940,8 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
                 }
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    const u32x4 pk = {pack_bf16(sacc[u][8 * s + 0], sacc[u][8 * s + 1]), pack_bf16(sacc[u][8 * s + 2], sacc[u][8 * s + 3]),
-                                      pack_bf16(sacc[u][8 * s + 4], sacc[u][8 * s + 5]), pack_bf16(sacc[u][8 * s + 6], sacc[u][8 * s + 7])};
+                    const u32x4 pk = {vh_pack_h16_unit(sacc[u][8 * s + 0], sacc[u][8 * s + 1]), vh_pack_h16_unit(sacc[u][8 * s + 2], sacc[u][8 * s + 3]),
+                                      vh_pack_h16_unit(sacc[u][8 * s + 4], sacc[u][8 * s + 5]), vh_pack_h16_unit(sacc[u][8 * s + 6], sacc[u][8 * s + 7])};
                     pf[u][s] = __builtin_bit_cast(bf16x8, pk);
                 }
             }
@@ -972,7 +972,7 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
                                                                (s16x4 __attribute__((address_space(3)))*)ad2));
                         }
                         const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
-                        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[u][s], oacc[db], 0, 0, 0);
+                        oacc[db] = VH_MFMA16(vf, pf[u][s], oacc[db]);
                     }
         }
         if (more) lstore(buf ^ 1);

@@ -3,16 +3,12 @@
 #pragma once
 #include "vh_common.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef vh_h16x8 bf16x8;                 // (round-5 name: eight h16 = one 32x32x16 operand fragment)
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {      // v_cvt_pk_bf16_f32 (round to nearest even)
-    const bf16x2 r = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, r);
-}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) { return vh_pack_h16(lo, hi); }      // (round-5 name)
 __device__ __forceinline__ u32x4 ldq(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ void stq(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 

@@ -1129,8 +1129,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
                 float* base = which == 1 ? a.kc : a.vc;
                 const int64_t at = (((int64_t)b * a.n_heads + head) * a.S_max + e_pos + t) * VH_HEAD_DIM + e;
                 if (EPI == EPI_QKV16) {           // four bf16 = one 8-byte store
-                    const uint64_t lo = vh_bf16_bits(sacc.x) | (vh_bf16_bits(sacc.y) << 16);
-                    const uint64_t hi = vh_bf16_bits(sacc.z) | (vh_bf16_bits(sacc.w) << 16);
+                    const uint64_t lo = vh_pack_h16(sacc.x, sacc.y);
+                    const uint64_t hi = vh_pack_h16(sacc.z, sacc.w);
                     *reinterpret_cast<uint64_t*>(reinterpret_cast<uint16_t*>(base) + at) = lo | (hi << 32);
                 } else {
                     st4(base + at, sacc);

@@ -244,8 +244,8 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
     auto quadrant = [&](int mb, int nt, bf16x8 (&fa)[2][4], bf16x8 (&fw_)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            acc[mb][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][s], fw_[s], acc[mb][nt], 0, 0, 0);
-            acc[mb + 1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][s], fw_[s], acc[mb + 1][nt], 0, 0, 0);
+            acc[mb][nt] = VH_MFMA16(fa[0][s], fw_[s], acc[mb][nt]);
+            acc[mb + 1][nt] = VH_MFMA16(fa[1][s], fw_[s], acc[mb + 1][nt]);
         }
     };
 

@@ -17,6 +17,7 @@ void vh_set_error(const char* fmt, ...) {
 }
 
 static int g_tuning[VH_TUNE_COUNT] = {0};
+extern "C" int vh_h16_format(void) { return VH_H16_IS_BF16; }     // 0 = IEEE fp16 (default), 1 = bf16 (-DVH_PERF_BF16)
 int vh_tuning(int knob) { return (knob >= 0 && knob < VH_TUNE_COUNT) ? g_tuning[knob] : 0; }
 extern "C" int vh_set_tuning(int knob, int value) {
     VH_REQUIRE(knob >= 0 && knob < VH_TUNE_COUNT, VH_EINVAL, "vh_set_tuning: knob=%d", knob);

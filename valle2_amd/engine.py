@@ -36,14 +36,14 @@ class KVCache:
 
     @property
     def bf16(self):
-        return self.buf.dtype == torch.bfloat16
+        return self.buf.dtype == kernels.H16
 
     def narrowed(self, s_max):
         """A bf16 cache of `s_max` rows per (layer, K|V, row, head) stream holding this fp32 cache's rows (round to
         nearest even, vh_kv_to_bf16): the decode steps of perf mode read half the bytes."""
         if self.bf16 or s_max < self.s_max:
             raise _lib.VhError('KVCache.narrowed: an fp32 cache and s_max >= its length')
-        out = KVCache(self.n_layers, self.batch, self.n_heads, s_max, self.buf.device, dtype=torch.bfloat16)
+        out = KVCache(self.n_layers, self.batch, self.n_heads, s_max, self.buf.device, dtype=kernels.H16)
         check(_lib.lib().vh_kv_to_bf16(ptr(self.buf), ptr(out.buf), self.n_layers * 2 * self.batch * self.n_heads,
                                        self.s_max, self.s_max, s_max, stream()), 'vh_kv_to_bf16')
         return out
@@ -204,7 +204,7 @@ class ForwardScratch16:
     """bf16 activations of the perf-mode forward: xn, q, attn (rows, d) and hidden (rows, dff)."""
 
     def __init__(self, rows, d, dff, device):
-        bf = dict(device=device, dtype=torch.bfloat16)
+        bf = dict(device=device, dtype=kernels.H16)
         self.xn = torch.empty(rows, d, **bf)
         self.q = torch.empty(rows, d, **bf)
         self.attn = torch.empty(rows, d, **bf)

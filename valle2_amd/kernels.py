@@ -14,6 +14,7 @@ from . import _lib
 from ._lib import check, ptr, stream
 
 MASK_FULL, MASK_PREFIX, MASK_EXPLICIT = 0, 1, 2
+H16 = _lib.h16_dtype()      # the 16-bit operand format of perf mode (float16 by default; the *_bf16 names are round 5's)
 ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_GELU_D, ACT_MUL = 0, 1, 2, 3, 4
 HEAD_DIM = 64
 
@@ -404,7 +405,7 @@ def attn_decode_shared(q, kprefix, vprefix, prefix_len, ksuffix, vsuffix, out, s
 def attn_decode_kv16(q, kcache16, vcache16, out, cache_len, len_bias):
     """attn_decode over a bf16 K/V cache (perf mode); one (row, head) per workgroup."""
     B, n_heads, S_max, hd = kcache16.shape
-    if hd != HEAD_DIM or kcache16.dtype != torch.bfloat16 or vcache16.dtype != torch.bfloat16 or q.shape[0] != B:
+    if hd != HEAD_DIM or kcache16.dtype != H16 or vcache16.dtype != H16 or q.shape[0] != B:
         raise _lib.VhError('attn_decode_kv16: bf16 caches (B, h, S_max, 64)')
     if cache_len.dtype != torch.int32 or cache_len.numel() != B:
         raise _lib.VhError('attn_decode_kv16: cache_len must be int32 (B)')
@@ -419,7 +420,7 @@ def linear_qkv_folded_kv16(a, folded, q_out, kcache16, vcache16, n_heads, cache_
     B, d = a.shape
     S_max = kcache16.shape[2]
     if tuple(wf.shape) != (3 * d, d) or tuple(kcache16.shape) != (B, n_heads, S_max, HEAD_DIM) or \
-            kcache16.dtype != torch.bfloat16 or vcache16.dtype != torch.bfloat16:
+            kcache16.dtype != H16 or vcache16.dtype != H16:
         raise _lib.VhError('linear_qkv_folded_kv16: shapes / dtypes')
     check(_lib.lib().vh_linear_qkv_folded_kv16(_dev_f32(a, 'a'), a.stride(0), ptr(wf), ptr(c1), ptr(c2), q_out.data_ptr(),
                                                q_out.stride(0), ptr(kcache16), ptr(vcache16), ptr(cache_len), B, d,
@@ -429,8 +430,8 @@ def linear_qkv_folded_kv16(a, folded, q_out, kcache16, vcache16, n_heads, cache_
 
 # ---- perf mode of the MFMA-bound legs: bf16 operands, fp32 accumulate (include/valle_hip.h; SECONDARY, never the parity path)
 def _bf16(t, name):
-    if t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(-1) != 1:
-        raise _lib.VhError(f'{name} must be a row-major bf16 HIP tensor, got {t.dtype} on {t.device}')
+    if t.dtype != H16 or not t.is_cuda or t.stride(-1) != 1:
+        raise _lib.VhError(f'{name} must be a row-major {H16} HIP tensor, got {t.dtype} on {t.device}')
     return t.data_ptr()
 
 
@@ -438,7 +439,7 @@ def to_bf16(x, out=None):
     """Round-to-nearest-even narrowing of a (rows, cols) fp32 matrix (vh_to_bf16): weights once per weight set."""
     rows, cols = x.shape
     if out is None:
-        out = torch.empty(rows, cols, device=x.device, dtype=torch.bfloat16)
+        out = torch.empty(rows, cols, device=x.device, dtype=H16)
     check(_lib.lib().vh_to_bf16(_dev_f32(x, 'x'), x.stride(0), _bf16(out, 'out'), out.stride(0), rows, cols, stream()),
           'vh_to_bf16')
     return out
@@ -448,7 +449,7 @@ def layernorm_bf16(x, gamma, beta, out=None, ada_scale=None, ada_shift=None, eps
     d = x.shape[-1]
     rows = x.numel() // d
     if out is None:
-        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+        out = torch.empty(x.shape, device=x.device, dtype=H16)
     check(_lib.lib().vh_layernorm_bf16(ptr(_f32(x, 'x')), ptr(gamma), ptr(beta), ptr(ada_scale), ptr(ada_shift),
                                        _bf16(out, 'out'), rows, d, eps, stream()), 'vh_layernorm_bf16')
     return out
@@ -461,8 +462,8 @@ def linear_bf16(a, w, bias=None, residual=None, out=None, act=ACT_NONE, out_bf16
     if K != K2 or not w.is_contiguous():
         raise _lib.VhError(f'linear_bf16: K mismatch {K} vs {K2} / w must be contiguous')
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
-    if out.dtype != (torch.bfloat16 if out_bf16 else torch.float32) or out.stride(1) != 1:
+        out = torch.empty(M, N, device=a.device, dtype=H16 if out_bf16 else torch.float32)
+    if out.dtype != (H16 if out_bf16 else torch.float32) or out.stride(1) != 1:
         raise _lib.VhError('linear_bf16: out dtype / layout')
     check(_lib.lib().vh_linear_bf16(_bf16(a, 'a'), a.stride(0), _bf16(w, 'w'), ptr(bias),
                                     _dev_f32(residual, 'residual') if residual is not None else None,

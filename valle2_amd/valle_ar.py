@@ -126,7 +126,7 @@ class ValleAR(_Base):
         # key padding covers audio only; text padding is NOT masked (valle_ar.py:69-73)
         kv_len = _lib.to_device_async(codes_lens.to(torch.int64) + tx, dev, torch.int32)
         if perf_mode:
-            cache = KVCache(self.config.num_layers, b, self.config.n_heads, tx + ty, dev, dtype=torch.bfloat16)
+            cache = KVCache(self.config.num_layers, b, self.config.n_heads, tx + ty, dev, dtype=kernels.H16)
             transformer_forward_bf16(self.transformer, x, cache, mode=kernels.MASK_PREFIX, x_len=tx, kv_len=kv_len)
         else:
             cache = KVCache(self.config.num_layers, b, self.config.n_heads, tx + ty, dev)
@@ -292,7 +292,7 @@ class ValleAR(_Base):
             prefix = KVCache(cfg.num_layers, 1, cfg.n_heads, (s0 + 31) // 32 * 32, dev)
             cache = KVCache(cfg.num_layers, B, cfg.n_heads, (run.max_new + 1 + 31) // 32 * 32, dev)
         elif run.perf_prefill:
-            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev, dtype=torch.bfloat16)
+            cache = KVCache(cfg.num_layers, B, cfg.n_heads, s_max, dev, dtype=kernels.H16)
         else:
             cache = KVCache(cfg.num_layers, B, cfg.n_heads, s0 if run.perf_mode else s_max, dev)
         rows = 1 if run.shared else B

@@ -96,7 +96,7 @@ class ValleNAR(_Base):
                              self.tokens_position_emb.pe, 0, x)
         p = self._embed_audio(codes, stage, x, tx, self.audio_position_emb.pe)
         if perf_mode:
-            cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev, dtype=torch.bfloat16)
+            cache = KVCache(cfg.num_layers, b, cfg.n_heads, tx + t, dev, dtype=kernels.H16)
             transformer_forward_bf16(self.transformer, x, cache, mode=kernels.MASK_FULL,
                                      embedding=self.stage_embs[stage - 1].weight)
         else:
@@ -228,7 +228,7 @@ class ValleNAR(_Base):
         starts = [0]
         for ty in tys:
             starts.append(starts[-1] + ty)
-        cache = KVCache(cfg.num_layers, B, cfg.n_heads, total, dev, dtype=torch.bfloat16 if perf_mode else torch.float32)
+        cache = KVCache(cfg.num_layers, B, cfg.n_heads, total, dev, dtype=kernels.H16 if perf_mode else torch.float32)
         scratch = (ForwardScratch16 if perf_mode else ForwardScratch)(B * total, d, cfg.dim_feedforward, dev)
         forward = transformer_forward_bf16 if perf_mode else transformer_forward
         x = torch.empty_like(base)
