@@ -436,6 +436,10 @@ def default_generate_leg(dev, sd, utt):
            'decode_us_per_step': st['decode_ms'] / max(1, steps - 1) * 1e3, 'n_split': st['n_split'],
            'launches_per_step': cfg.num_layers * per_layer + 2,
            'shared_prompt': bool(st.get('shared_prompt')),
+           # round 6: the decoder of a shape (graphs, caches, counters) survives generate(): what the timed calls spent on the
+           # host outside enqueueing the prompt pass and the replays (~1.7 ms of capture + construction before)
+           'decoder_reused': bool(st.get('decoder_reused')), 'host_outside_ms': st.get('host_outside_ms'),
+           'host_decoder_ms': st.get('host_decoder_ms'),
            'launches': 'per layer: QKV, '
                        + (f'shared-prompt attention (prefix launch + suffix x{st["n_split"]} key splits'
                           if st.get('shared_prompt') else f'decode attention (x{st["n_split"]} key splits')
@@ -808,6 +812,7 @@ def main():
                                                 'decode_us_per_step': st_i['decode_ms'] / (new - 1) * 1e3,
                                                 'prefill_ms': st_i['prefill_ms']},
                            'shared_over_independent': dti / dtb,
+                           'decoder_reused': bool(st_b.get('decoder_reused')), 'host_outside_ms': st_b.get('host_outside_ms'),
                            'same_tokens_as_independent_rows': bool(torch.equal(toks_b, toks_i))}
 
     if rank == 0 and world == 1 and not args.no_default_generate and not args.small:
