@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 125            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 126            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -383,6 +383,11 @@ typedef struct {
     /* shared-prompt decoding (vh_ar_decoder_desc.prefix_len > 0): this layer's prompt K / V, (1, h, prefix_S, 64), written
      * once by a one-row prompt pass and read by every beam; kcache / vcache then hold only the beams' generated rows */
     const float *kprefix, *vprefix;
+    /* perf mode of the decode step, second half (round 6; with vh_ar_decoder_desc.kv_bf16): h16 copies (vh_h16_format) of the four
+     * matrices a step streams — wqkv_f16 (3d, d) and w1_f16 (dff, d) of the FOLDED weights above, wo16 (d, d), w2_16 (d, dff).
+     * All four non-NULL: the step's QKV, out-projection and FeedForward launches read them (half the weight bytes; fp32
+     * accumulators, fp32 rows, c1 / c2 / biases fp32); any NULL: the fp32 matrices, as before. */
+    const uint16_t *wqkv_f16, *wo16, *w1_f16, *w2_16;
 } vh_layer;
 
 typedef struct {
@@ -428,6 +433,8 @@ typedef struct {
      * that serves many generate() calls keeps the call's seed here and rewrites it between calls (valle2_amd/valle_ar.py keeps
      * a decoder per shape: graphs, caches and workspaces survive the call). */
     const uint64_t *seed_dev;
+    /* optional (with kv_bf16): an h16 copy of proj_w (V, d) for the head GEMM of the step */
+    const uint16_t *proj_w16;
 } vh_ar_decoder_desc;
 
 typedef struct vh_ar_decoder vh_ar_decoder;

@@ -53,6 +53,7 @@ int main() {
     void* S = nullptr;
 
     EXPECT(vh_version() == VH_VERSION, "version");
+    EXPECT(vh_h16_format() == 0 || vh_h16_format() == 1, "h16 format");
     EXPECT(vh_set_tuning(-1, 0) < 0 && vh_set_tuning(VH_TUNE_COUNT, 1) < 0 && vh_set_tuning(VH_TUNE_FFN_FUSED, 0) == VH_OK, "tuning bounds");
 
     // ---- forward primitives -------------------------------------------------------------------------------------

@@ -35,7 +35,8 @@ c_dropp = C.POINTER(VhDropoutSpec)
 class VhLayer(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         'ln1_g', 'ln1_b', 'wqkv', 'wo', 'bo', 'ln2_g', 'ln2_b', 'w1', 'b1', 'w2', 'b2',
-        'kcache', 'vcache', 'wqkv_f', 'qkv_c1', 'qkv_c2', 'w1_f', 'w1_c1', 'w1_c2', 'kprefix', 'vprefix')]
+        'kcache', 'vcache', 'wqkv_f', 'qkv_c1', 'qkv_c2', 'w1_f', 'w1_c1', 'w1_c2', 'kprefix', 'vprefix',
+        'wqkv_f16', 'wo16', 'w1_f16', 'w2_16')]
 
 
 class VhArDecoderDesc(C.Structure):
@@ -53,7 +54,7 @@ class VhArDecoderDesc(C.Structure):
         ('top_k', C.c_int), ('top_p', C.c_float), ('temperature', C.c_float), ('seed', C.c_uint64),
         ('sum_logprobs', C.c_void_p), ('ffn_ws', C.c_void_p), ('ffn_ws_bytes', C.c_size_t), ('kv_bf16', C.c_int),
         ('prefix_len', C.c_int), ('prefix_S', C.c_int), ('attn_partial_bytes', C.c_size_t),
-        ('head_ws', C.c_void_p), ('head_ws_bytes', C.c_size_t), ('seed_dev', C.c_void_p),
+        ('head_ws', C.c_void_p), ('head_ws_bytes', C.c_size_t), ('seed_dev', C.c_void_p), ('proj_w16', C.c_void_p),
     ]
 
 

@@ -35,7 +35,9 @@ struct FfnArgs {
     float eps;
 };
 
-template <int D, int SW>
+// W16 (perf mode of the decode step, round 6): hw1 / hw2 point at h16 matrices (vh_common.h vh_h16) of the same logical
+// shape; a fragment is 8 bytes per lane, widened to fp32 in registers before its MFMAs — half the weight bytes per launch.
+template <int D, int SW, bool W16 = false>
 __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const float* hw1, const float* hw2, int h_ldx,
                                                          int hM, int h_dff, FfnArgs a) {
     constexpr int NW = 8, PW = D / 128, CB1 = SW / 16, CB2 = D / 128, KC2 = SW / 16, HLD = SW + 4;
@@ -62,13 +64,20 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
     const float* xrow = X + (int64_t)min(i, rows - 1) * h_ldx;  // rows beyond the group repeat its last row
     const float shift = xrow[0];                                // statistics are taken about the row's first element
     f32x4 wf1[CB1][PW], xf[PW];
+    uint2 wr1[CB1][PW];                                         // W16: raw fragments (4 h16)
 #pragma unroll
     for (int c = 0; c < PW; ++c) xf[c] = ld4(xrow + koff + 16 * c);
 #pragma unroll
     for (int cb = 0; cb < CB1; ++cb) {
-        const float* wp = hw1 + (int64_t)(n1 + 16 * cb + i) * D + koff;
+        if constexpr (W16) {
+            const uint16_t* wp = reinterpret_cast<const uint16_t*>(hw1) + (int64_t)(n1 + 16 * cb + i) * D + koff;
 #pragma unroll
-        for (int c = 0; c < PW; ++c) wf1[cb][c] = ld4(wp + 16 * c);
+            for (int c = 0; c < PW; ++c) wr1[cb][c] = *reinterpret_cast<const uint2*>(wp + 16 * c);
+        } else {
+            const float* wp = hw1 + (int64_t)(n1 + 16 * cb + i) * D + koff;
+#pragma unroll
+            for (int c = 0; c < PW; ++c) wf1[cb][c] = ld4(wp + 16 * c);
+        }
     }
     // phase-1 epilogue operands: wave w finalises component (w >> 1) & 3 of hidden column block w % CB1 … see below
     const int fcb = w % CB1, fcomp = (w / CB1) & 3;
@@ -76,13 +85,23 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
     const float e_c2 = a.c2[n1 + 16 * fcb + 4 * g + fcomp];
     // phase 2: W2 rows (= output columns) 16 (w CB2 + cb) + i, k = n1 + 16 c + 4 g + {0..3}: one 128-B line per row at SW = 32
     f32x4 wf2[CB2][KC2];
+    uint2 wr2[CB2][KC2];
 #pragma unroll
     for (int cb = 0; cb < CB2; ++cb) {
-        const float* wp = hw2 + (int64_t)(16 * (w * CB2 + cb) + i) * h_dff + n1 + 4 * g;
+        if constexpr (W16) {
+            const uint16_t* wp = reinterpret_cast<const uint16_t*>(hw2) + (int64_t)(16 * (w * CB2 + cb) + i) * h_dff + n1 + 4 * g;
 #pragma unroll
-        for (int c = 0; c < KC2; ++c) wf2[cb][c] = ld4(wp + 16 * c);
+            for (int c = 0; c < KC2; ++c) wr2[cb][c] = *reinterpret_cast<const uint2*>(wp + 16 * c);
+        } else {
+            const float* wp = hw2 + (int64_t)(16 * (w * CB2 + cb) + i) * h_dff + n1 + 4 * g;
+#pragma unroll
+            for (int c = 0; c < KC2; ++c) wf2[cb][c] = ld4(wp + 16 * c);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
+    auto widen = [](uint2 r) __attribute__((always_inline)) {
+        return f32x4{vh_h16_lo(r.x), vh_h16_hi(r.x), vh_h16_lo(r.y), vh_h16_hi(r.y)};
+    };
 
     // ---- row statistics from the operand fragments (no second read of the rows): this lane holds 4 PW elements of
     // row i; sums of (x - shift) and (x - shift)^2, folded over the wave's four k groups (lanes i, i+16, i+32, i+48),
@@ -107,12 +126,17 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
 #pragma unroll
     for (int cb = 0; cb < CB1; ++cb) acc1[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < PW; ++c)
+    for (int c = 0; c < PW; ++c) {
+        if constexpr (W16) {
+#pragma unroll
+            for (int cb = 0; cb < CB1; ++cb) wf1[cb][c] = widen(wr1[cb][c]);
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int cb = 0; cb < CB1; ++cb)
                 acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf1[cb][c][jj], xf[c][jj], acc1[cb], 0, 0, 0);
+    }
 #pragma unroll
     for (int cb = 0; cb < CB1; ++cb) st4(&red[w][cb][lane][0], acc1[cb]);
     __syncthreads();
@@ -145,12 +169,17 @@ __global__ __launch_bounds__(512) void ffn_decode_kernel(const float* hx, const 
 #pragma unroll
     for (int cb = 0; cb < CB2; ++cb) acc2[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < KC2; ++c)
+    for (int c = 0; c < KC2; ++c) {
+        if constexpr (W16) {
+#pragma unroll
+            for (int cb = 0; cb < CB2; ++cb) wf2[cb][c] = widen(wr2[cb][c]);
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
             for (int cb = 0; cb < CB2; ++cb)
                 acc2[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf2[cb][c][jj], hf[c][jj], acc2[cb], 0, 0, 0);
+    }
     // non-temporal stores: the slabs are read once, by another launch, from whatever XCD — written through they do
     // not wait in this XCD's L2 for the write-back at the end of the kernel (9.35 -> 8.66 us per launch)
     if (i < rows) {
@@ -221,9 +250,9 @@ extern "C" size_t vh_ffn_decode_ws_bytes(int M, int d_model, int dff) {
     return (size_t)(dff / 16) * M * d_model * sizeof(float);
 }
 
-extern "C" int vh_ffn_decode(const float* x, int ldx, const float* w1f, const float* c1, const float* c2,
+static int ffn_decode_launch(const float* x, int ldx, const float* w1f, const float* c1, const float* c2,
                              const float* w2, const float* b2, float* out, int ldo, int M, int d_model, int dff,
-                             float ln_eps, void* workspace, size_t workspace_bytes, void* stream) {
+                             float ln_eps, void* workspace, size_t workspace_bytes, void* stream, bool w16) {
     VH_REQUIRE(x && w1f && c1 && c2 && w2 && out && workspace, VH_EINVAL, "vh_ffn_decode: null pointer");
     int rg_rows = 0;
     const int sw = ffn_plan(M, d_model, dff, &rg_rows);
@@ -242,7 +271,11 @@ extern "C" int vh_ffn_decode(const float* x, int ldx, const float* w1f, const fl
     FfnArgs a{c1, c2, (float*)workspace, n_slices, (M + rg_rows - 1) / rg_rows, rg_rows, ln_eps};
     const dim3 grid(n_slices, a.n_rg);
     hipStream_t s = (hipStream_t)stream;
-#define FFN(DD, SS) hipLaunchKernelGGL((ffn_decode_kernel<DD, SS>), grid, dim3(512), 0, s, x, w1f, w2, ldx, M, dff, a)
+#define FFN(DD, SS)                                                                                                  \
+    do {                                                                                                            \
+        if (w16) hipLaunchKernelGGL((ffn_decode_kernel<DD, SS, true>), grid, dim3(512), 0, s, x, w1f, w2, ldx, M, dff, a); \
+        else hipLaunchKernelGGL((ffn_decode_kernel<DD, SS>), grid, dim3(512), 0, s, x, w1f, w2, ldx, M, dff, a);           \
+    } while (0)
 #define FFN_D(DD)                              \
     do {                                       \
         if (sw == 16) FFN(DD, 16);             \
@@ -258,4 +291,18 @@ extern "C" int vh_ffn_decode(const float* x, int ldx, const float* w1f, const fl
                        ldx, b2, out, ldo, M, d_model);
     VH_CHECK_LAUNCH("vh_ffn_decode");
     return VH_OK;
+}
+
+extern "C" int vh_ffn_decode(const float* x, int ldx, const float* w1f, const float* c1, const float* c2,
+                             const float* w2, const float* b2, float* out, int ldo, int M, int d_model, int dff,
+                             float ln_eps, void* workspace, size_t workspace_bytes, void* stream) {
+    return ffn_decode_launch(x, ldx, w1f, c1, c2, w2, b2, out, ldo, M, d_model, dff, ln_eps, workspace, workspace_bytes, stream, false);
+}
+
+// the same launch pair over h16 weights (w1f16 (dff, d), w2_16 (d, dff): the decoder plan's perf mode, plan.hip)
+int vh_internal_ffn_decode_w16(const float* x, int ldx, const uint16_t* w1f16, const float* c1, const float* c2,
+                               const uint16_t* w2_16, const float* b2, float* out, int ldo, int M, int d_model, int dff,
+                               float ln_eps, void* workspace, size_t workspace_bytes, void* stream) {
+    return ffn_decode_launch(x, ldx, reinterpret_cast<const float*>(w1f16), c1, c2, reinterpret_cast<const float*>(w2_16), b2, out, ldo,
+                             M, d_model, dff, ln_eps, workspace, workspace_bytes, stream, true);
 }

@@ -44,6 +44,7 @@ struct GemmArgs {
     float* colsum;  // training backward (EPI_PLAIN, tile kernels): += column sums of the stored output (a bias gradient)
     int k_len;  // K range of one workgroup column (split-K: K / gridDim.y; otherwise K)
     int rg_rows;  // rows per row group when gridDim.z > 1 (16, or 8: half of the MFMA's 16 rows idle)
+    int w16;      // decode GEMMs of perf mode: W points at an h16 (N,K) matrix (vh_common.h vh_h16), read as 8 bytes per fragment
     DropArgs drop;  // training forward (EPI_PLAIN, LDS-DMA tile kernel): out = dropout(act(acc + bias)) + residual
 #ifdef VH_STAMPS
     long long* dbg;  // diagnostic build only (tools/probe_skinny.hip): per-wave phase stamps
@@ -899,7 +900,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs a, LnFuse
 //     3 = folded, statistics taken from the OPERAND FRAGMENTS (MT = 1): no second read of the rows — the rows are
 //         fresh data of the previous launch, written on other XCDs, and every KB a workgroup pulls of them costs
 //         (profiles/r3_probe_launch_floor.log: ~16 GB/s per CU); one-pass sums about the row's first element.
-template <int MT, int NW, int EPI, int PW, int LN, int NJ>
+//   W16: the weights are h16 (perf mode of the decode step, round 6): a fragment is 8 bytes per lane instead of 16 — half the
+//   bytes of the stream that bounds these kernels — widened to fp32 in registers right before its four MFMAs.
+template <int MT, int NW, int EPI, int PW, int LN, int NJ, bool W16 = false>
 __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadStep* hs = nullptr) {
     const int hr0 = (EPI == EPI_HEAD && gridDim.z > 1) ? (int)blockIdx.z * a.rg_rows : 0;   // first row of this group
     // Row groups (gridDim.z > 1): this workgroup owns rows [rg_rows·z, rg_rows·(z+1)) of the problem — it
@@ -926,7 +929,8 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
     const int i = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int koff = blockIdx.y * a.k_len + w * (PW * 16) + 4 * g;   // this lane's first k in a pass
-    const float* wp = a.W + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
+    const float* wp = a.W + (W16 ? 0 : (int64_t)min(n0 + i, a.N - 1) * a.K + koff);
+    const uint16_t* wp16 = reinterpret_cast<const uint16_t*>(a.W) + (int64_t)min(n0 + i, a.N - 1) * a.K + koff;
     const float* xp[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) xp[mt] = a.A + (int64_t)min(mt * 16 + i, a.M - 1) * a.lda + koff;
@@ -934,10 +938,12 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
     const float* bp = LN == 1 ? ln.beta + koff : nullptr;
 
     f32x4 wf[PW], xf[PW][MT], gm[PW], bt[PW];
+    uint2 wraw[PW];                                        // W16: the raw fragments (4 h16 each)
     auto issue = [&](int kbase) {
 #pragma unroll
         for (int c = 0; c < PW; ++c) {
-            wf[c] = ld4(wp + kbase + 16 * c);
+            if constexpr (W16) wraw[c] = *reinterpret_cast<const uint2*>(wp16 + kbase + 16 * c);
+            else wf[c] = ld4(wp + kbase + 16 * c);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[c][mt] = ld4(xp[mt] + kbase + 16 * c);
             if (LN == 1) {
@@ -1044,12 +1050,14 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
             }
         }
 #pragma unroll
-        for (int c = 0; c < PW; ++c)
+        for (int c = 0; c < PW; ++c) {
+            if constexpr (W16) wf[c] = f32x4{vh_h16_lo(wraw[c].x), vh_h16_hi(wraw[c].x), vh_h16_lo(wraw[c].y), vh_h16_hi(wraw[c].y)};
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[c][jj], xf[c][mt][jj], acc[mt], 0, 0, 0);
+        }
         kbase += pass_stride;
         if (kbase >= a.k_len) break;
         issue(kbase);
@@ -1197,14 +1205,14 @@ __device__ __forceinline__ void skinny_body(GemmArgs a, LnFuse ln, const HeadSte
 }
 
 
-template <int MT, int NW, int EPI, int PW, int LN, int NJ>
+template <int MT, int NW, int EPI, int PW, int LN, int NJ, bool W16 = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_fast(const float* hA, const float* hW, int h_lda, int hK, int h_klen,
                                                             int hM, int hN, GemmArgs a, LnFuse ln) {
     // The operands every wave needs for its first loads travel as leading scalar arguments: with
     // -mllvm -amdgpu-kernarg-preload-count the command processor places them in SGPRs at dispatch, so the
     // weight / activation loads are issued without first waiting for a kernarg s_load round trip.
     a.A = hA; a.W = hW; a.lda = h_lda; a.K = hK; a.k_len = h_klen; a.M = hM; a.N = hN;
-    skinny_body<MT, NW, EPI, PW, LN, NJ>(a, ln);
+    skinny_body<MT, NW, EPI, PW, LN, NJ, W16>(a, ln);
 }
 
 // The AR head + greedy step (EPI_HEAD): same body, the step's operands as one more by-value argument.
@@ -1398,8 +1406,17 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             grid.z = (a.M + ag.rg_rows - 1) / ag.rg_rows;
         }
         // ---- compact fast path: K = 16*NW*PW*passes
-#define SF(MT, NW, PW, LN, NJ) \
-    hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln)
+#define SF(MT, NW, PW, LN, NJ)                                                                                                   \
+    do {                                                                                                                        \
+        if constexpr ((EPI == EPI_PLAIN && (LN) == 0 && (NW) == 8) || (EPI == EPI_QKV16 && (LN) >= 2)) {                          \
+            if (ag.w16) {                                                                                                       \
+                hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ, true>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln); \
+                break;                                                                                                          \
+            }                                                                                                                   \
+        }                                                                                                                       \
+        if (ag.w16) { vh_set_error("%s: no 16-bit-weight form of this shape", name); return VH_EUNSUPPORTED; }                   \
+        hipLaunchKernelGGL((gemm_skinny_fast<MT, NW, EPI, PW, LN, NJ>), grid, dim3(NW * 64), 0, s, SKINNY_ARGS(ag), ag, ln);        \
+    } while (0)
 #define SF_MT(NW, PW, LN, NJ)                                                  \
     do {                                                                       \
         if (rowgroups) SF(1, NW, PW, LN, NJ);                                  \
@@ -1449,6 +1466,7 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
             return VH_EUNSUPPORTED;
         } else {
         // ---- generic guarded kernel for every other K (multiple of 16)
+        if (a.w16) { vh_set_error("%s: no 16-bit-weight form of this shape (K=%d)", name, a.K); return VH_EUNSUPPORTED; }
 #define SK(MT, NW, CH, LN) \
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NW, EPI, CH, LN>), grid, dim3(NW * 64), 0, s, a, ln)
         if (has_ln) {
@@ -1464,6 +1482,7 @@ static int launch_gemm(const char* name, const GemmArgs& a, const LnFuse& ln, hi
         vh_set_error("%s: bf16 K/V append is the decode path (M <= 64)", name);
         return VH_EUNSUPPORTED;
     } else {
+        if (a.w16) { vh_set_error("%s: 16-bit weights are the decode step's form (M <= 64)", name); return VH_EUNSUPPORTED; }
         const int tm = (a.M + TM - 1) / TM, tn = (a.N + TN - 1) / TN;
         // The LDS-DMA kernel needs whole 32-wide K slabs; a ragged K goes to the register-staged kernel.
         if (a.k_len % TK == 0 && vh_tuning(VH_TUNE_TILE_DMA) != 1) {
@@ -1700,6 +1719,39 @@ extern "C" int vh_linear_qkv_folded_kv16(const float* A, int lda, const float* W
     if (int rc = check_gemm("vh_linear_qkv_folded_kv16", a, ln)) return rc;
     if (int rc = check_folded("vh_linear_qkv_folded_kv16", a, ln)) return rc;
     return launch_gemm<EPI_QKV16>("vh_linear_qkv_folded_kv16", a, ln, (hipStream_t)stream);
+}
+
+// ---- the decode step of perf mode with h16 weights (plan.hip): vh_linear (no LayerNorm, M <= 64) and vh_linear_qkv_folded_kv16
+int vh_internal_linear_w16(const float* A, int lda, const uint16_t* W16, const float* bias, const float* residual, int ldr,
+                           float* out, int ldo, int M, int N, int K, void* stream) {
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = reinterpret_cast<const float*>(W16); a.bias = bias; a.res = residual; a.ldr = ldr; a.out = out;
+    a.ldo = ldo; a.M = M; a.N = N; a.K = K; a.act = VH_ACT_NONE; a.k_len = K; a.w16 = 1;
+    LnFuse ln{};
+    VH_REQUIRE(M <= 64 && K % 128 == 0 && K <= 1024 && ldo >= N && (!residual || ldr >= N), VH_EUNSUPPORTED,
+               "vh_linear (16-bit weights): M=%d K=%d (decode rows, K a multiple of 128 up to 1024)", M, K);
+    VH_REQUIRE(((uintptr_t)W16 & 7u) == 0, VH_EALIGN, "vh_linear (16-bit weights): W must be 8-byte aligned");
+    if (int rc = check_gemm("vh_linear_w16", a, ln)) return rc;
+    return launch_gemm<EPI_PLAIN>("vh_linear_w16", a, ln, (hipStream_t)stream);
+}
+
+int vh_internal_linear_qkv_folded_kv16_w16(const float* A, int lda, const uint16_t* Wf16, const float* c1, const float* c2,
+                                           float* q_out, int ldq, uint16_t* kcache16, uint16_t* vcache16, const int32_t* cache_len,
+                                           int B, int d_model, int n_heads, int S_max, float ln_eps, void* stream) {
+    VH_REQUIRE(kcache16 && vcache16 && Wf16, VH_EINVAL, "vh_linear_qkv_folded_kv16 (16-bit weights): null pointer");
+    VH_REQUIRE(B >= 0 && B <= 64 && n_heads > 0 && d_model == n_heads * VH_HEAD_DIM, VH_EUNSUPPORTED,
+               "vh_linear_qkv_folded_kv16 (16-bit weights): B=%d d_model=%d n_heads=%d", B, d_model, n_heads);
+    VH_REQUIRE(S_max >= 1 && ldq >= d_model, VH_EINVAL, "vh_linear_qkv_folded_kv16 (16-bit weights): S_max / ldq");
+    GemmArgs a{};
+    a.A = A; a.lda = lda; a.W = reinterpret_cast<const float*>(Wf16); a.out = q_out; a.ldo = ldq;
+    a.M = B; a.N = 3 * d_model;
+    a.K = d_model; a.k_len = d_model; a.act = VH_ACT_NONE; a.w16 = 1;
+    a.kc = reinterpret_cast<float*>(kcache16); a.vc = reinterpret_cast<float*>(vcache16); a.cache_len = cache_len;
+    a.T = 1; a.S_max = S_max; a.d_model = d_model; a.n_heads = n_heads;
+    LnFuse ln{nullptr, nullptr, nullptr, nullptr, ln_eps, c1, c2};
+    if (int rc = check_gemm("vh_linear_qkv_folded_kv16_w16", a, ln)) return rc;
+    if (int rc = check_folded("vh_linear_qkv_folded_kv16_w16", a, ln)) return rc;
+    return launch_gemm<EPI_QKV16>("vh_linear_qkv_folded_kv16_w16", a, ln, (hipStream_t)stream);
 }
 
 extern "C" int vh_linear_ws(const float* A, int lda, const float* W, const float* bias,

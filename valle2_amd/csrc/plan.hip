@@ -130,6 +130,14 @@ extern "C" void vh_ar_decoder_destroy(vh_ar_decoder* dec) {
 // One decode step for every row: x (B,d) holds the new token's embedding on entry and the NEXT
 // token's embedding on exit.  `ev` (optional) brackets each decode-attention launch.
 void vh_internal_attn_decode_events(hipEvent_t start, hipEvent_t stop);   // attention.hip
+int vh_internal_linear_w16(const float* A, int lda, const uint16_t* W16, const float* bias, const float* residual, int ldr,
+                           float* out, int ldo, int M, int N, int K, void* stream);                                   // gemm.hip
+int vh_internal_linear_qkv_folded_kv16_w16(const float* A, int lda, const uint16_t* Wf16, const float* c1, const float* c2,
+                                           float* q_out, int ldq, uint16_t* kcache16, uint16_t* vcache16, const int32_t* cache_len,
+                                           int B, int d_model, int n_heads, int S_max, float ln_eps, void* stream);   // gemm.hip
+int vh_internal_ffn_decode_w16(const float* x, int ldx, const uint16_t* w1f16, const float* c1, const float* c2,
+                               const uint16_t* w2_16, const float* b2, float* out, int ldo, int M, int d_model, int dff,
+                               float ln_eps, void* workspace, size_t workspace_bytes, void* stream);                  // ffn.hip
 int vh_internal_sample_step(const float* logits, int ldl, int V, int eos, int top_k, float top_p, float temperature, uint64_t seed,
                             const uint64_t* seed_dev, int64_t* codes, int64_t codes_stride, int32_t* eos_count,
                             const int32_t* pos_base, float* sum_logprobs, const float* audio_emb, const float* pe,
@@ -181,7 +189,12 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
     for (int i = 0; i < d.n_layers; ++i) {
         const vh_layer& L = dec->layers[i];
         // LN1 fused into the QKV GEMM; K/V rows appended at cache_len[b]  (modules.py:146-157,271)
-        if (d.kv_bf16)
+        // (perf mode with h16 copies of the step's four matrices: the same launches over half the weight bytes)
+        const bool w16 = d.kv_bf16 && L.wqkv_f16 && L.wo16 && L.w1_f16 && L.w2_16 && D <= 1024;
+        if (w16)
+            TRY(vh_internal_linear_qkv_folded_kv16_w16(d.x, D, L.wqkv_f16, L.qkv_c1, L.qkv_c2, d.q, D, (uint16_t*)L.kcache,
+                                                       (uint16_t*)L.vcache, d.cache_len, B, D, d.n_heads, d.S_max, d.ln_eps, s));
+        else if (d.kv_bf16)
             TRY(vh_linear_qkv_folded_kv16(d.x, D, L.wqkv_f, L.qkv_c1, L.qkv_c2, d.q, D, (uint16_t*)L.kcache,
                                           (uint16_t*)L.vcache, d.cache_len, B, D, d.n_heads, d.S_max, d.ln_eps, s));
         else if (L.wqkv_f)
@@ -192,9 +205,17 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                               d.S_max, L.ln1_g, L.ln1_b, nullptr, nullptr, d.ln_eps, s));
         TRY(run_attention(L));
         // out-proj + bias + residual (modules.py:171,277)
-        TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
-                      nullptr, nullptr, 0.f, s));
+        if (w16)
+            TRY(vh_internal_linear_w16(d.attn, D, L.wo16, L.bo, d.x, D, d.x, D, B, D, D, s));
+        else
+            TRY(vh_linear(d.attn, D, L.wo, L.bo, d.x, D, d.x, D, B, D, D, VH_ACT_NONE, nullptr, nullptr,
+                          nullptr, nullptr, 0.f, s));
         // LN2 + linear_1 + exact GELU + linear_2 + bias + residual (modules.py:215-221,278-279)
+        if (w16 && d.ffn_ws) {             // (the fused FeedForward is the only 16-bit-weight form: taken at every width)
+            TRY(vh_internal_ffn_decode_w16(d.x, D, L.w1_f16, L.w1_c1, L.w1_c2, L.w2_16, L.b2, d.x, D, B, D, d.dff, d.ln_eps, d.ffn_ws,
+                                           d.ffn_ws_bytes, s));
+            continue;
+        }
         if (ffn_fused) {
             TRY(vh_ffn_decode(d.x, D, L.w1_f, L.w1_c1, L.w1_c2, L.w2, L.b2, d.x, D, B, D, d.dff, d.ln_eps, d.ffn_ws,
                               d.ffn_ws_bytes, s));
@@ -215,8 +236,11 @@ static int decoder_enqueue(vh_ar_decoder* dec, hipStream_t s, std::vector<hipEve
                            d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, d.head_ws, d.head_ws_bytes, s));
         return VH_OK;
     }
-    TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
-                  nullptr, nullptr, nullptr, nullptr, 0.f, s));
+    if (d.kv_bf16 && d.proj_w16 && D <= 1024)
+        TRY(vh_internal_linear_w16(d.x, D, d.proj_w16, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, s));
+    else
+        TRY(vh_linear(d.x, D, d.proj_w, nullptr, nullptr, 0, d.logits, dec->ldl, B, d.V, D, VH_ACT_NONE,
+                      nullptr, nullptr, nullptr, nullptr, 0.f, s));
     if (d.top_k == 1)
         TRY(vh_greedy_step(d.logits, dec->ldl, d.V, d.eos, d.codes, d.codes_stride, d.eos_count,
                            d.pos_base, d.audio_emb, d.audio_pe, d.audio_pos, d.cache_len, d.x, B, D, s));

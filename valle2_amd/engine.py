@@ -200,6 +200,29 @@ def bf16_weights(transformer):
     return out
 
 
+# perf mode's decode step over h16 copies of its four matrices (+ the head): built in round 6, measured SLOWER (471.1 vs 463.9 us per
+# step at 32 rows x 12L/512d, profiles/r6_ab_decode_w16.log — the chain's launches are round trips, not byte streams, and an 8-byte
+# fragment per lane halves the useful part of every line it touches) — so it is opt-in: VALLE2_DECODE_W16=1
+DECODE_W16 = os.environ.get('VALLE2_DECODE_W16', '0') == '1'
+
+
+def decode_weights16(transformer, folded):
+    """Per layer (Wqkv∘γ1, Wo, W1∘γ2, W2) as h16 for the PERF-MODE decode step (the second half of SURVEY section 7's perf mode:
+    16-bit storage of what a step streams, fp32 accumulate — the folded matrices are narrowed AFTER the fold, so the
+    epilogue's c1 / c2 stay the fp32 sums of the fold).  Built once per weight set, beside the folded weights."""
+    layers = list(transformer.layers)
+    key = (_WEIGHTS_EPOCH, id(folded)) + tuple((t.data_ptr(), t._version) for l in layers
+                                               for t in (l.self_attn.out.weight, l.ffn.linear_2.weight))
+    cached = _derived(transformer).get('decode16')
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    with torch.no_grad(), torch.inference_mode(False):
+        out = [(kernels.to_bf16(folded[i][0][0]), kernels.to_bf16(l.self_attn.out.weight.detach()),
+                kernels.to_bf16(folded[i][1][0]), kernels.to_bf16(l.ffn.linear_2.weight.detach())) for i, l in enumerate(layers)]
+    _derived(transformer)['decode16'] = (key, out, folded)       # (the folded list is kept alive: its id is part of the key)
+    return out
+
+
 class ForwardScratch16:
     """bf16 activations of the perf-mode forward: xn, q, attn (rows, d) and hidden (rows, dff)."""
 
@@ -463,6 +486,16 @@ class ArDecoder:
         if os.environ.get('VALLE2_HEAD_FUSED') == '1' and self.sampling[0] == 1 and batch <= 64 and d in (128, 256, 512, 1024):
             self.head_ws = kernels.head_greedy_ws(batch, V, dev)
         self._table = layer_table(model.transformer, cache, self._folded)
+        # perf mode, second half: the step's four matrices (and the head) as h16 — half the weight bytes per launch
+        self._w16 = self._proj16 = None
+        if self.kv_bf16 and DECODE_W16 and self.ffn_ws is not None and d <= 1024 and cfg.dim_feedforward % 16 == 0:
+            self._w16 = decode_weights16(model.transformer, self._folded)
+            for i, (wq, wo, w1, w2) in enumerate(self._w16):
+                self._table[i].wqkv_f16, self._table[i].wo16 = ptr(wq), ptr(wo)
+                self._table[i].w1_f16, self._table[i].w2_16 = ptr(w1), ptr(w2)
+            with torch.inference_mode(False):
+                self._proj16 = kernels.to_bf16(model.proj.weight.detach()) if d % 8 == 0 else None
+        self.w16 = self._w16 is not None
         if prefix is not None:
             for i in range(cfg.num_layers):
                 self._table[i].kprefix, self._table[i].vprefix = ptr(prefix.k(i)), ptr(prefix.v(i))
@@ -478,7 +511,7 @@ class ArDecoder:
             audio_pos=ptr(audio_pos), eos_count=ptr(self.eos_count), pos_base=ptr(pos_base),
             codes=ptr(codes), codes_stride=codes.stride(0), top_k=self.sampling[0], top_p=self.sampling[1],
             temperature=self.sampling[2], seed=0 if self.seed_dev is not None else self.sampling[3] & (2 ** 64 - 1),
-            seed_dev=ptr(self.seed_dev),
+            seed_dev=ptr(self.seed_dev), proj_w16=ptr(self._proj16),
             sum_logprobs=ptr(self.sum_logprobs), ffn_ws=ptr(self.ffn_ws), ffn_ws_bytes=ffn_bytes,
             kv_bf16=int(self.kv_bf16), prefix_len=self.prefix_len if prefix is not None else 0,
             prefix_S=prefix.s_max if prefix is not None else 0,

@@ -60,7 +60,7 @@ class _DecodeSlot:
             self.dec = None
 
 
-_DECODER_ENV = ('VALLE2_HEAD_FUSED', 'VALLE2_SHARED_SPLIT', 'VALLE2_FOLD_LN')   # environment knobs read when a decoder is built
+_DECODER_ENV = ('VALLE2_HEAD_FUSED', 'VALLE2_SHARED_SPLIT', 'VALLE2_FOLD_LN', 'VALLE2_DECODE_W16')   # environment knobs read when a decoder is built
 DECODER_SLOTS = int(os.environ.get('VALLE2_DECODER_SLOTS', '2'))    # decoders kept per model (0: build one per call, as before)
 _SLOT_LOCK = threading.Lock()
 
@@ -535,6 +535,7 @@ class ValleAR(_Base):
             _lib.raise_device_errors(dev)                 # ids that were already on the device: checked in-kernel
             self.last_generate_stats = {'steps_run': done, 'tokens_appended': n_new, 'n_split': dec.n_split,
                                         'ffn_fused': dec.ffn_ws is not None and cfg.d_model <= 512, 'kv_bf16': dec.kv_bf16,
+                                        'decode_w16': bool(getattr(dec, 'w16', False)),
                                         'head_fused': dec.head_ws is not None,
                                         'prefill_bf16': run.perf_prefill, 'shared_prompt': run.shared, 'logits': kept,
                                         'prefill_ms': marks[0].elapsed_time(marks[1]),
