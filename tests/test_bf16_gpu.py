@@ -128,6 +128,45 @@ def test_linear_bf16_persistent_256(K, M, N, K_, out16, act, res):
         torch.testing.assert_close(out.double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5)
 
 
+def test_linear_bf16_persistent_256_random_shapes_and_repeatable_bits(K):
+    """Property test of csrc/gemm16p.hip: 24 seeded draws of (M, N, K, output kind) — M from 1 to 40 000 (ragged last tile rows,
+    one to several tiles per persistent workgroup), N / 256 in 1..16, K / 128 in 2..32 (4 to 64 K-tiles: every length of the
+    request stream's head and tail), fp32 + residual / 16-bit / 16-bit + GELU — against fp64 on the device, each launched three
+    times with bit-identical results (a read that overtakes its LDS-DMA, or a request that overtakes the last read of its
+    buffer, shows as a run-to-run difference long before it shows as a wrong sum)."""
+    import random
+    from valle2_amd import _lib
+    rng = random.Random(2026)
+    _lib.lib().vh_set_tuning(15, 4)
+    try:
+        for draw in range(24):
+            M = rng.choice([1, 255, 256, 257, 511, 4096, 4097, rng.randrange(1, 40000), rng.randrange(1, 40000)])
+            N = 256 * rng.randrange(1, 17)
+            K_ = 128 * rng.randrange(2, 33)
+            if M * N * K_ > 3e11:                     # keep a draw under ~0.3 s of fp64 on the device
+                K_ = max(256, 128 * int(3e11 / (M * N) // 128))
+            kind = rng.randrange(3)
+            a = torch.randn(M, K_, generator=g(1000 + draw)).to(H16).to(DEV)
+            w = (torch.randn(N, K_, generator=g(2000 + draw)) * K_ ** -0.5).to(H16).to(DEV)
+            bias = torch.randn(N, generator=g(3000 + draw)).to(DEV)
+            r = torch.randn(M, N, generator=g(4000 + draw)).to(DEV) if kind == 0 else None
+            ref = a.double() @ w.double().T + bias.double()
+            if kind == 2:
+                ref = F.gelu(ref)
+            if r is not None:
+                ref = ref + r.double()
+            outs = [K.linear_bf16(a, w, bias, residual=r, act=K.ACT_GELU if kind == 2 else K.ACT_NONE, out_bf16=kind != 0)
+                    for _ in range(3)]
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (draw, M, N, K_, kind)
+            if kind == 0:
+                torch.testing.assert_close(outs[0].double(), ref, atol=2e-5 * K_ ** 0.5, rtol=1e-5, msg=f'draw {draw}: {M}x{N}x{K_}')
+            else:
+                torch.testing.assert_close(outs[0].double(), ref, atol=1e-4 if kind == 2 else 1e-5, rtol=2 * EPS if kind == 2 else EPS,
+                                           msg=f'draw {draw}: {M}x{N}x{K_} kind {kind}')
+    finally:
+        _lib.lib().vh_set_tuning(15, 0)
+
+
 def test_linear_bf16_integer_operands_are_exact(K, gemm_form):
     """Small integers are exact in bf16 and their products / sums exact in fp32: any operand-layout or accumulator-map
     error shows as a wrong integer.  Asymmetric data (a[m][k] depends on m and k differently than w[n][k] on n and k)."""
