@@ -80,9 +80,11 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_TAIL_SPLIT = 10,     /* vh_linear_ex with a workspace: 0 (default) = the tiles beyond the last multiple of 256 are
                                        computed as K slices + a fix-up launch when they would fill <= half of the CUs, 1 = never */
        VH_TUNE_TN_WGS = 11,         /* vh_gemm_tn: workgroups the contraction split aims at, 0 (default) = 256 (one per CU) */
-       VH_TUNE_DECODE_COMBINE = 12, /* decode attention with key splits: 0 (default) = a second launch adds the split records,
-                                       1 = the last workgroup of a (b, head) to arrive does, in the same launch (same bits:
-                                       split order either way; measured 13 us per decode step slower at 4 beams x 8 splits) */
+       VH_TUNE_DECODE_COMBINE = 12, /* decode attention with key splits: 1 = the last workgroup of a (b, head) to arrive adds the split
+                                       records in the same launch, 2 = a second launch does (same bits: split order either way);
+                                       0 (default) = as measured: in the same launch at two splits (configs[4], 8 rows x 16 heads:
+                                       13 us per step faster at context 2.7 k), a second launch at more (13 us per step slower at
+                                       4 beams x 8 splits) */
        VH_TUNE_ATTN_BWD = 13,       /* vh_attn_rows_bwd_ws: 0 (default) / 2 = the five-product kernel + slab reduce, 1 = the two-kernel,
                                        seven-product form of vh_attn_rows_bwd (its D scratch taken from the workspace) */
        VH_TUNE_ATTN_BWD_CHUNKS = 14, /* five-product attention backward: key chunks per (batch row, head); 0 (default) = chosen from the

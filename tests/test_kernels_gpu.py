@@ -512,9 +512,9 @@ def test_attn_decode(K, B, h, S, n_split):
 
 @pytest.mark.parametrize('B,h,n_split', [(4, 8, 8), (8, 16, 2), (3, 2, 16), (1, 8, 5)])
 def test_attn_decode_split_combine_in_launch_equals_the_second_launch(K, B, h, n_split):
-    """Key splits combined by the last workgroup to arrive (VH_TUNE_DECODE_COMBINE = 1) against the separate combine launch
-    (default): the records are added in split order either way, so the results are the same BITS; the ticket words
-    re-arm themselves — 25 launches on one workspace — and end at zero."""
+    """Key splits combined by the last workgroup to arrive (VH_TUNE_DECODE_COMBINE = 1; the default at two splits since round 6)
+    against the separate combine launch (2; the default at more splits): the records are added in split order either way, so
+    the results are the same BITS; the ticket words re-arm themselves — 25 launches on one workspace — and end at zero."""
     from valle2_amd import _lib
     d, S = 64 * h, 700
     gen = g(90 + n_split)
@@ -526,7 +526,7 @@ def test_attn_decode_split_combine_in_launch_equals_the_second_launch(K, B, h, n
     lib = _lib.lib()
     outs = {}
     try:
-        for knob in (0, 1):
+        for knob in (2, 1, 0):
             lib.vh_set_tuning(12, knob)
             out = torch.empty(B, d, device=DEV)
             for _ in range(25 if knob == 1 else 1):
@@ -535,7 +535,7 @@ def test_attn_decode_split_combine_in_launch_equals_the_second_launch(K, B, h, n
             outs[knob] = out.clone()
     finally:
         lib.vh_set_tuning(12, 0)
-    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(outs[2], outs[1]) and torch.equal(outs[2], outs[0])
     tickets = ws.view(torch.int32)[B * h * n_split * 72:][: B * h]
     assert int(tickets.abs().sum()) == 0
     ref = torch.empty(B, d)

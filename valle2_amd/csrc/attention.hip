@@ -530,7 +530,11 @@ extern "C" int vh_attn_decode(const float* q, int ldq, const float* kcache, cons
     // second launch 364.6 us per step; in-launch with an agent-scope release + acquire 609.7 (the release writes back the
     // L2); in-launch with write-through stores and agent-scope loads, no fences, 377.6 — the hand-off (drain, ticket,
     // dependent loads from beyond the L2) still costs 1 us per layer more than the 1.75 us dependent-launch floor it saves.
-    const bool fused_combine = n_split > 1 && vh_tuning(VH_TUNE_DECODE_COMBINE) == 1;
+    // the split records are combined by the last arriver of a (row, head) inside this launch (knob 1), or by a second launch
+    // (knob 2); default: inside at TWO splits (configs[4], 8 rows x 16 heads: 1483.5 vs 1496.6 us per step at context 2.7 k, 1027.2 vs
+    // 1028.3 at 0.6 k, profiles/r6_ab_config5_combine.log), the second launch at more (4 beams x 8 heads, 8 splits: DESIGN 3.1)
+    const int combine_knob = vh_tuning(VH_TUNE_DECODE_COMBINE);
+    const bool fused_combine = n_split > 1 && (combine_knob == 1 || (combine_knob == 0 && n_split == 2));
     unsigned* arrived = fused_combine ? (unsigned*)((char*)partial + decode_records_bytes(B, n_heads, n_split)) : nullptr;
     if (variant != 1 && big && n_split == 1 && nw == 0) {
         const int waves = 8;

@@ -223,15 +223,27 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
     // accumulators start from the tile's bias (a lane = a column of every block: one value per lane and block column), so the
     // epilogues add nothing
     f32x16 acc[4][2];
-    auto acc_init = [&](int i) __attribute__((always_inline)) {
-        float b0 = 0.f, b1 = 0.f;
+    // The NEXT tile's two bias values (one per lane and block column) are requested by hand-counted loads at the start of a tile's
+    // LAST PAIR of K-tiles and waited for at the epilogue's start with vmcnt(8) (the two phases in between request eight pieces):
+    // a compiler-counted load here ends in vmcnt(0) — its counter is the in-order one and it cannot see the DMA — and drained every
+    // store and every request in flight at each tile boundary (r6 ISA audit).
+    float nb0 = 0.f, nb1 = 0.f;
+    auto bias_request = [&](int i) __attribute__((always_inline)) {
         if (OUT != G16_QKV && a.bias && i < n_my) {
             int m0, n0;
             tile_mn(i, m0, n0);
-            const int r = tid & 31;
-            b0 = a.bias[n0 + wc * 64 + r];
-            b1 = a.bias[n0 + wc * 64 + 32 + r];
+            const float* base = a.bias + n0 + wc * 64;
+            const uint32_t vo = (uint32_t)(tid & 31) * 4u;
+            // ("+v": the destinations stay the registers nb0 / nb1 already live in — a fresh "=v" value merged with the old one
+            // after this branch made hipcc COPY the registers before the wait below, i.e. before the data had landed)
+            asm volatile("global_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128"
+                         : "+v"(nb0), "+v"(nb1) : "v"(vo), "s"(base) : "memory");
         }
+    };
+    auto bias_wait = [&]() __attribute__((always_inline)) {           // (after the tile's last tile nothing was requested: harmless)
+        if (OUT != G16_QKV && a.bias) asm volatile("s_waitcnt vmcnt(8)" : "+v"(nb0), "+v"(nb1)::"memory");
+    };
+    auto acc_fill = [&](float b0, float b1) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -240,7 +252,11 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
                 acc[mt][1][e] = b1;
             }
     };
-    acc_init(0);
+    if (OUT != G16_QKV && a.bias) {                           // the first tile's bias: nothing else is in flight yet
+        bias_request(0);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(nb0), "+v"(nb1)::"memory");
+    }
+    acc_fill(nb0, nb1);
     auto quadrant = [&](int mb, int nt, bf16x8 (&fa)[2][4], bf16x8 (&fw_)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -338,6 +354,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
         const int r = lane & 31, h = lane >> 5;
         const int mw = m0 + wr * 128, nw = n0 + wc * 64;    // this wave's first row / column
         const bool full = m0 + 256 <= a.M;
+        bias_wait();
         if constexpr (OUT == G16_F32) {
             // 32 x 32 blocks through a row-major fp32 image (float index row * 32 + (col ^ (((row >> 1) & 1) << 2))); store side:
             // lane = (row (lane >> 3) + 8 i, columns 4 (lane & 7) .. + 3): 8 rows x 128 B per instruction; the residual's four
@@ -444,7 +461,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
         }
         // a ragged tile issued fewer than NST stores: empty the queue, so that the counted waits that follow stay true
         if (!full) pk_vmwait<0>();
-        acc_init(ci + 1);
+        acc_fill(nb0, nb1);
     };
 
     // ---- prologue: K-tile 0 complete (Wa, Aa, Ab, Wb), Wa, Aa, Ab of K-tile 1; then LEAD = K-tile 2, TRAIL = K-tile 1
@@ -474,6 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
         if (wr == 1) PK_BAR();
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 == nk) bias_request(ci + 1);
             ktile(P0{}, T, ci > 0 && kt == 0);
             ktile(P1{}, T + 1, false);
             T += 2;

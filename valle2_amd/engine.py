@@ -526,7 +526,7 @@ class ArDecoder:
         self.use_graph = use_graph
 
     def close(self):
-        if getattr(self, '_h', None):
+        if getattr(self, '_h', None) and _lib is not None:     # (a decoder kept in a slot may outlive the module at interpreter exit)
             _lib.lib().vh_ar_decoder_destroy(self._h)
             self._h = None
 
