@@ -90,11 +90,12 @@ enum { VH_TUNE_DECODE_VARIANT = 0,  /* decode attention: 0 = default (the ring k
        VH_TUNE_ATTN_BWD_CHUNKS = 14, /* five-product attention backward: key chunks per (batch row, head); 0 (default) = chosen from the
                                        shape (bwd_chunks in csrc/attention.hip), else that many (at least ceil(T / 256)) */
        VH_TUNE_BF16_GEMM = 15,      /* perf-mode tile GEMM: 0 (default) = form 4 where the shape allows it (N % 256 == 0, K % 128 == 0,
-                                       >= 128 tiles), else per output type (bf16 outputs: form 3; fp32 output + residual: form 1);
-                                       1 = 128^2 tiles, two slabs of 64 k (two workgroups per CU), 2 = a ring of three slabs of 32 k with
-                                       counted waits (three workgroups per CU), 3 = one slab of 64 k, no software pipeline, four
-                                       workgroups per CU, 4 = one persistent workgroup per CU, 256^2 tiles, 8 waves taking turns on the
-                                       matrix pipe, requests in flight across barriers and tiles (csrc/gemm16p.hip) */
+                                       >= 128 tiles), else per output type (16-bit outputs: form 3; fp32 output + residual: form 1);
+                                       1 = 128^2 tiles, two slabs of 64 k (two workgroups per CU), 3 = one slab of 64 k, no software
+                                       pipeline, four workgroups per CU, 4 = one persistent workgroup per CU, 256^2 tiles, 8 waves
+                                       taking turns on the matrix pipe, requests in flight across barriers and tiles
+                                       (csrc/gemm16p.hip); 2 (round 5's ring of three slabs of 32 k, removed: slower on 7 of 8 shapes)
+                                       = the default */
        VH_TUNE_COUNT = 16 };
 int vh_set_tuning(int knob, int value);
 

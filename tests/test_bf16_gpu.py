@@ -39,11 +39,11 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-@pytest.fixture(params=[1, 2, 3, 4], ids=['two_slabs_k64', 'ring_k32', 'one_slab_4wg', 'persistent_256sq'])
+@pytest.fixture(params=[1, 3, 4], ids=['two_slabs_k64', 'one_slab_4wg', 'persistent_256sq'])
 def gemm_form(request):
-    """The tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / a ring of three slabs of 32 k / one slab of
-    64 k with four workgroups per CU / the persistent 256 x 256 form of csrc/gemm16p.hip (shapes it does not take — N % 256,
-    K % 128 — fall back to the two-slab form)."""
+    """The tile machines of the perf-mode GEMM (VH_TUNE_BF16_GEMM): two slabs of 64 k / one slab of 64 k with four workgroups per
+    CU / the persistent 256 x 256 form of csrc/gemm16p.hip (shapes it does not take — N % 256, K % 128 — fall back to the
+    two-slab form).  (Round 5's ring of three slabs was slower on 7 of 8 shapes and is gone.)"""
     from valle2_amd import _lib
     _lib.lib().vh_set_tuning(15, request.param)
     yield request.param
@@ -76,7 +76,7 @@ def test_layernorm_bf16(K, rows, d, ada):
 @pytest.mark.parametrize('M,N,K_,out16,act,res', [
     (128, 128, 64, False, 0, False), (300, 256, 128, False, 0, True), (1000, 512, 512, True, 1, False),
     (77, 1536, 512, False, 1, True), (4096, 512, 2048, False, 0, True), (129, 2048, 512, True, 1, False), (1, 128, 64, False, 0, False),
-    (200, 128, 192, False, 0, True), (333, 256, 320, True, 0, False)])        # K / 32 = 6, 10: every tail length of the ring
+    (200, 128, 192, False, 0, True), (333, 256, 320, True, 0, False)])        # K / 64 = 3, 5: odd numbers of K steps
 def test_linear_bf16(K, gemm_form, M, N, K_, out16, act, res):
     a = torch.randn(M, K_, generator=g(10)).to(H16)
     w = (0.05 * torch.randn(N, K_, generator=g(11))).to(H16)
@@ -313,14 +313,14 @@ def test_both_gemm_forms_give_the_same_stack_output():
     kw, sd, batch = C.nar_inputs()
     m = build('ValleNAR', kw, sd)
     outs = {}
-    for form in (0, 1, 2, 3, 4):
+    for form in (0, 1, 3, 4):
         _lib.lib().vh_set_tuning(15, form)
         try:
             with torch.no_grad():
                 outs[form] = m.stage_logits(batch, 3, perf_mode=True)[0].clone()
         finally:
             _lib.lib().vh_set_tuning(15, 0)
-    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[3])
+    assert torch.equal(outs[1], outs[3])
     for form in (0, 4):
         err = float((outs[form] - outs[1]).abs().max())
         assert err < 2e-2, (form, err)

@@ -124,7 +124,6 @@ extern "C" int vh_layernorm_bf16(const float* x, const float* gamma, const float
 #define T16K 64                       // bf16 elements per K step: 128 B per row of a slab
 #define SLAB16 (T16M * 128)           // bytes of one operand slab (128 rows x 128 B)
 #define EPI16_LD 132                  // floats per row of the epilogue's transposition image
-#define VH_BF16_RING_DEFAULT false     // which kernel VH_TUNE_BF16_GEMM = 0 means (set by measurement, tools/bench_bf16.py)
 
 #ifdef VH_TILE_PROBE16
 // Phase stamps (tools/probe_tile16.hip only): 100 MHz wall clock at entry | first slab landed | main loop done | image
@@ -357,209 +356,6 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
 }
 
 // =============================================================================================
-// Ring variant of the bf16 tile GEMM (round 5, second form): K step 32 (a slab row is 64 B), a ring of THREE slab pairs of
-// 16 KB, the DMA of step k + 2 requested while step k is multiplied, three workgroups per CU (48 KB of LDS each).
-// Why: with a K step of 64 and two slabs the DMA of step k + 1 has one step — 512 MFMA cycles of its own wave — to land,
-// which an L2 hit under load (500 - 800 cycles) does not always make, and the wait is a vmcnt(0) in front of a barrier
-// (MFMA-busy 27 - 35 %, profiles/r5_pmc_bf16_mfma_busy.md); here a piece has two steps and three waves per SIMD to hide
-// behind, and the wait is counted (vmcnt(4): the four pieces of step k + 1 stay in flight across the barrier — raw
-// s_barrier, never __syncthreads(), which would drain them: cdna_hip_programming.md "Pipelining across barriers").
-//   LDS image of a slab: [128 rows][64 B], lane-linear per DMA piece (16 rows x 64 B = 1 KiB); 16-byte chunk c of row r
-//   sits at chunk c ^ ((r >> 2) & 3): the 16 rows a ds_read_b128 lane group touches spread over the four chunk columns
-//   (rows r and r + 4 share a 256-B bank row otherwise).
-// Epilogue: the 48 KB cannot hold the fp32 image of the whole tile, so it is transposed in two passes of 64 rows
-// (every wave hands over its 32-row half mt = pass), 64 x 132 floats each.
-// =============================================================================================
-#define R16K 32                       // bf16 elements per K step
-#define RSLAB (T16M * 64)             // bytes of one operand slab (128 rows x 64 B)
-#define RSTAGE (2 * RSLAB)            // A + W
-#define RLDS (3 * RSTAGE)             // 49152 B
-
-template <int OUT>
-__global__ __launch_bounds__(256, 3) void gemm16_ring_kernel(Gemm16Args a, int tiles_m, int tiles_n) {
-    __shared__ __attribute__((aligned(16))) char lds[RLDS];
-    __builtin_amdgcn_s_setprio(3);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
-    const int nwg = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
-    const int q8 = nwg / 8, r8 = nwg % 8, xcd = bid % 8;
-    const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / 8;
-    const int m0 = (tile / tiles_n) * T16M, n0 = (tile % tiles_n) * T16N;
-
-    // DMA: a stage = 16 pieces (8 of A, 8 of W) of 16 rows x 64 B; wave w issues pieces 4w .. 4w+3.  Lane L fills slot
-    // (row L >> 2 of the piece, chunk L & 3) and fetches chunk (L & 3) ^ swz(row) of that row.
-    const int ws = __builtin_amdgcn_readfirstlane(w);
-    const char* baseA = (const char*)(a.A + (int64_t)m0 * a.lda);
-    const char* baseW = (const char*)(a.W + (int64_t)n0 * a.K);
-    uint32_t voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = ws * 4 + i, row = (q & 7) * 16 + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        voff[i] = q < 8 ? (uint32_t)(min(row, a.M - 1 - m0) * a.lda + 8 * c) * 2u
-                        : (uint32_t)(min(row, a.N - 1 - n0) * a.K + 8 * c) * 2u;
-    }
-    auto dma1 = [&](int i, int stage, int k0) {
-        const int q = ws * 4 + i;
-        const char* base = (q < 8 ? baseA : baseW) + (int64_t)k0 * 2;
-        const uint32_t dst = (uint32_t)(uintptr_t)(lds + stage * RSTAGE + (q >> 3) * RSLAB + (q & 7) * 1024);
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
-                     :: "s"(dst), "v"(voff[i]), "s"(base) : "memory");
-    };
-    auto dma_stage = [&](int stage, int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dma1(i, stage, k0);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nk = a.K / R16K;                              // >= 2 (K % 64 == 0)
-    dma_stage(0, 0);
-    dma_stage(1, R16K);
-
-    // fragment addresses in stage 0: row (wm | wn) * 64 + r (+ 32), chunk (2 t + h) ^ ((r >> 2) & 3), t = 0, 1
-    const int swz = (r >> 2) & 3;
-    const char* fA[2];
-    const char* fW[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        fA[t] = lds + (wm * 64 + r) * 64 + (((2 * t + h) ^ swz) << 4);
-        fW[t] = lds + RSLAB + (wn * 64 + r) * 64 + (((2 * t + h) ^ swz) << 4);
-    }
-    __builtin_amdgcn_s_setprio(0);
-    auto kstep = [&](int kt, auto st_c, auto pf) {           // st_c: stage holding slab kt (compile-time); pf: a slab kt + 2 exists
-        constexpr int st = decltype(st_c)::value;
-        constexpr bool PF = decltype(pf)::value;
-        // slab kt has landed once all but this wave's youngest four pieces (slab kt + 1) are done; the barrier then says
-        // the same of every wave — and that every wave has finished reading stage (kt + 2) % 3 (= slab kt - 1)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if constexpr (PF) dma_stage((st + 2) % 3, (kt + 2) * R16K);
-        bf16x8 fa[2][2], fw[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            fa[t][0] = __builtin_bit_cast(bf16x8, ldq(fA[t] + st * RSTAGE));
-            fa[t][1] = __builtin_bit_cast(bf16x8, ldq(fA[t] + st * RSTAGE + 32 * 64));
-            fw[t][0] = __builtin_bit_cast(bf16x8, ldq(fW[t] + st * RSTAGE));
-            fw[t][1] = __builtin_bit_cast(bf16x8, ldq(fW[t] + st * RSTAGE + 32 * 64));
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            acc[0][0] = VH_MFMA16(fa[t][0], fw[t][0], acc[0][0]);
-            acc[0][1] = VH_MFMA16(fa[t][0], fw[t][1], acc[0][1]);
-            acc[1][0] = VH_MFMA16(fa[t][1], fw[t][0], acc[1][0]);
-            acc[1][1] = VH_MFMA16(fa[t][1], fw[t][1], acc[1][1]);
-        }
-        // the fragments are in registers before the wave can reach the next barrier: its reads of this stage are done
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    using S0 = std::integral_constant<int, 0>;
-    using S1 = std::integral_constant<int, 1>;
-    using S2 = std::integral_constant<int, 2>;
-    int kt = 0;
-    for (; kt + 5 <= nk; kt += 3) {                          // three steps per trip: the stage index is a compile-time constant
-        kstep(kt, S0{}, std::true_type{});
-        kstep(kt + 1, S1{}, std::true_type{});
-        kstep(kt + 2, S2{}, std::true_type{});
-    }
-    // tail: nk - kt in {2, 3, 4} steps left, the last two without a prefetch
-    const int left = nk - kt;
-    if (left == 2) {
-        kstep(kt, S0{}, std::false_type{});
-        kstep(kt + 1, S1{}, std::false_type{});
-    } else if (left == 3) {
-        kstep(kt, S0{}, std::true_type{});
-        kstep(kt + 1, S1{}, std::false_type{});
-        kstep(kt + 2, S2{}, std::false_type{});
-    } else {
-        kstep(kt, S0{}, std::true_type{});
-        kstep(kt + 1, S1{}, std::true_type{});
-        kstep(kt + 2, S2{}, std::false_type{});
-        kstep(kt + 3, S0{}, std::false_type{});
-    }
-    __syncthreads();                                        // every wave has read its last fragments: LDS is free
-    __builtin_amdgcn_s_setprio(3);
-    // ---- epilogue in two passes of 64 rows: pass p takes every wave's 32-row half mt = p through a 64 x 132 fp32 image ----
-    float* ct = (float*)lds;
-    const int ec4 = tid & 31, er4 = tid >> 5;               // fp32 output: column group of 4, rows er4 + 8 it
-    const int ec8 = tid & 15, er8 = tid >> 4;               // bf16 outputs: column group of 8, rows er8 + 16 it
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, b0 = bias4, b1 = bias4;
-    if (OUT == G16_F32 && a.bias) bias4 = ld4(a.bias + n0 + 4 * ec4);
-    if (OUT == G16_BF16 && a.bias) { b0 = ld4(a.bias + n0 + 8 * ec8); b1 = ld4(a.bias + n0 + 8 * ec8 + 4); }
-    uint16_t* dst16 = (uint16_t*)a.out;
-    bool cache = false;
-    if (OUT == G16_QKV) {
-        const int en = n0 + 8 * ec8;
-        const int which = en / a.d_model, c = en - which * a.d_model;     // d_model % 128 == 0: a tile lies in one of q | K | V
-        cache = which != 0;
-        dst16 = which == 0 ? (uint16_t*)a.out + c
-                           : (which == 1 ? a.kc : a.vc) + (int64_t)(c / VH_HEAD_DIM) * a.S_max * VH_HEAD_DIM + (c % VH_HEAD_DIM);
-    } else if (OUT == G16_BF16) {
-        dst16 += n0 + 8 * ec8;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass) __syncthreads();                          // the first pass has been read out
-        float* cw = ct + (wm * 32 + 4 * h) * EPI16_LD + wn * 64 + r;
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int x = 0; x < 16; ++x) cw[((x & 3) + 8 * (x >> 2)) * EPI16_LD + nt * 32] = acc[pass][nt][x];
-        __syncthreads();
-        if (OUT == G16_F32) {
-            float* out = (float*)a.out;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int ir = er4 + 8 * it;                 // image row -> tile row (ir >> 5) * 64 + pass * 32 + (ir & 31)
-                const int m = m0 + (ir >> 5) * 64 + pass * 32 + (ir & 31);
-                if (m < a.M) {
-                    f32x4 v = ld4(ct + ir * EPI16_LD + 4 * ec4) + bias4;
-                    if (a.act == VH_ACT_GELU_ERF) {
-                        const vh_f32x2 g0 = gelu_erf2(vh_f32x2{v.x, v.y}), g1 = gelu_erf2(vh_f32x2{v.z, v.w});
-                        v = f32x4{g0.x, g0.y, g1.x, g1.y};
-                    }
-                    if (a.res) v += ld4(a.res + (int64_t)m * a.ldr + n0 + 4 * ec4);
-                    st4(out + (int64_t)m * a.ldo + n0 + 4 * ec4, v);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int ir = er8 + 16 * it;
-                const int m = m0 + (ir >> 5) * 64 + pass * 32 + (ir & 31);
-                if (m < a.M) {
-                    const float* cr = ct + ir * EPI16_LD + 8 * ec8;
-                    f32x4 v0 = ld4(cr) + b0, v1 = ld4(cr + 4) + b1;
-                    if (OUT == G16_BF16 && a.act == VH_ACT_GELU_ERF) {
-                        const vh_f32x2 g0 = gelu16_2(vh_f32x2{v0.x, v0.y}), g1 = gelu16_2(vh_f32x2{v0.z, v0.w});
-                        const vh_f32x2 g2 = gelu16_2(vh_f32x2{v1.x, v1.y}), g3 = gelu16_2(vh_f32x2{v1.z, v1.w});
-                        v0 = f32x4{g0.x, g0.y, g1.x, g1.y};
-                        v1 = f32x4{g2.x, g2.y, g3.x, g3.y};
-                    }
-                    const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
-                    if (cache) {
-                        const int b = m / a.T, t = m - b * a.T;
-                        const int cl = a.cache_len ? a.cache_len[b] : 0;
-                        stq(dst16 + ((int64_t)b * a.n_heads * a.S_max + cl + t) * VH_HEAD_DIM, pk);
-                    } else {
-                        stq(dst16 + (int64_t)m * a.ldo, pk);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// =============================================================================================
 // Occupancy variant of the bf16 tile GEMM (round 5, third form): ONE slab pair of K step 64 (32 KB of LDS), no software
 // pipeline at all — request the slab, wait, barrier, 16 MFMAs per wave, barrier — and FOUR workgroups per CU (<= 128 VGPRs)
 // whose phases interleave by themselves: while one workgroup waits for its slab the other three multiply.
@@ -708,23 +504,20 @@ __global__ __launch_bounds__(256, 4) void gemm16_occ_kernel(Gemm16Args a, int ti
     VH_P16_END();
 }
 
-// which tile machine a launch takes: VH_TUNE_BF16_GEMM = 1 the two-slab K-64 kernel, 2 the three-slab K-32 ring, 0 the default
-static bool use_ring16() {
-    const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
-    return knob == 0 ? VH_BF16_RING_DEFAULT : knob == 2;
-}
+// (round 5's third machine — a ring of three slabs of 32 k with counted waits, three workgroups per CU — was slower than the two-slab
+// form on 7 of 8 shapes and is gone in round 6: docs/history.md; VH_TUNE_BF16_GEMM = 2 now means the default)
 // default (set by measurement, tools/bench_bf16.py + tools/probe_tile16.hip): the one-slab / four-workgroup form for the
 // bf16 outputs (QKV scatter, linear_1 + GELU: -10 ... -25 %), the two-slab form with its early residual request for the
 // fp32 output + residual GEMMs (HBM-bound at 3.7 - 4.8 TB/s in both forms)
 static bool use_occ16(bool bf16_out) {
     const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
-    return knob == 0 ? bf16_out : knob == 3;
+    return (knob == 0 || knob == 2) ? bf16_out : knob == 3;
 }
 // round 6: the persistent 256^2 / 8-wave form (gemm16p.hip) where the shape allows it (N % 256 == 0, K % 128 == 0) and there
 // are enough rows to fill the part; VH_TUNE_BF16_GEMM = 4 forces it for every shape it takes, 1 / 2 / 3 keep the 128^2 forms
 static bool use_p256(const Gemm16Args& a, int out_kind) {
     const int knob = vh_tuning(VH_TUNE_BF16_GEMM);
-    if (knob != 0 && knob != 4) return false;
+    if (knob != 0 && knob != 2 && knob != 4) return false;
     if (!vh_gemm16_p256_ok(a, out_kind)) return false;
     return knob == 4 || (int64_t)((a.M + 255) / 256) * (a.N / 256) >= 128;
 }
@@ -757,9 +550,6 @@ extern "C" int vh_linear_bf16(const uint16_t* A, int lda, const uint16_t* W, con
     if (use_occ16(out_bf16 != 0)) {
         if (out_bf16) hipLaunchKernelGGL(gemm16_occ_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
         else hipLaunchKernelGGL(gemm16_occ_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
-    } else if (use_ring16()) {
-        if (out_bf16) hipLaunchKernelGGL(gemm16_ring_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
-        else hipLaunchKernelGGL(gemm16_ring_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
     } else {
         if (out_bf16) hipLaunchKernelGGL(gemm16_tile_kernel<G16_BF16>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
         else hipLaunchKernelGGL(gemm16_tile_kernel<G16_F32>, dim3(tm * tn), dim3(256), 0, s, a, tm, tn);
@@ -784,7 +574,6 @@ extern "C" int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wq
     const int tm = (a.M + T16M - 1) / T16M, tn = a.N / T16N;
     if (use_p256(a, G16_QKV)) return vh_gemm16_p256_launch(a, G16_QKV, (hipStream_t)stream);
     if (use_occ16(true)) hipLaunchKernelGGL(gemm16_occ_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
-    else if (use_ring16()) hipLaunchKernelGGL(gemm16_ring_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     else hipLaunchKernelGGL(gemm16_tile_kernel<G16_QKV>, dim3(tm * tn), dim3(256), 0, (hipStream_t)stream, a, tm, tn);
     VH_CHECK_LAUNCH("vh_linear_qkv_bf16");
     return VH_OK;
