@@ -4,6 +4,7 @@
 // hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include tools/probe_tile16.hip -o tools/probe_tile16.bin
 #define VH_TILE_PROBE16 1
 #include "../valle2_amd/csrc/bf16.hip"
+#include "../valle2_amd/csrc/gemm16p.hip"      // (bf16.hip's dispatcher refers to the 256^2 form; this probe forces forms 1 / 3)
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
