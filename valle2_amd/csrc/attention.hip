@@ -1026,6 +1026,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(BwdArgs a) {
         gload(t_first * KT);
         lstore(0);
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): K / V fragments landed on every path (see attn_bwd_fused_kernel)
     __syncthreads();
     for (int qt = t_first; qt < n_tiles; ++qt) {
         const int cur = (qt - t_first) & 1, q0t = qt * KT;
@@ -1251,6 +1252,10 @@ __global__ __launch_bounds__(FW * 64, FW == 8 ? 1 : 2) void attn_bwd_fused_kerne
         gload_late(t_first * KT);
         lstore();
     }
+    // vmcnt(0), unconditionally: the K / V fragments are first USED inside the loop and are still outstanding on the path
+    // around the conditional above — without this the wait insertion puts vmcnt(3..0) in front of the first score MFMAs
+    // of EVERY tile, which makes the tile wait for its own prefetch of the next Q / dO rows (seen in the ISA, round 6)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     for (int qt = t_first; qt < n_tiles; ++qt) {
         const int q0t = qt * KT;

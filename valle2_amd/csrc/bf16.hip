@@ -589,6 +589,7 @@ extern "C" int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wq
 //                                 disjoint bank groups)
 #define A16_QB 128
 #define A16_KT 64
+#define A16_RING 3
 #define A16_NEG (-1e30f)
 
 struct Attn16Args {
@@ -605,7 +606,7 @@ struct Attn16Args {
 };
 
 __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 2 * A16_KT * 128];     // [buf][K | V][64 keys][128 B] = 32 KB
+    __shared__ __attribute__((aligned(16))) char lds[A16_RING * 2 * A16_KT * 128];   // ring of [K | V][64 keys][128 B] = 48 KB
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // heaviest query blocks first (under the prefix mask the last blocks see the most keys)
@@ -620,6 +621,8 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     const int q0 = qb * A16_QB + 32 * w;                     // this wave's first query
     const int qi = min(q0 + r, a.Tq - 1);                    // this lane's query (clamped: rows beyond Tq are never stored)
     const int qpos = q_off + qi;
+    // this lane's query sees exactly the keys [0, klim): key < kv_len and (key < x_len or (qpos >= x_len and key <= qpos))
+    const int klim = prefix ? min(kvl, qpos >= xl ? qpos + 1 : xl) : kvl;
     // keys any query of the WORKGROUP can see: [0, kend)
     const int wg_qlast = q_off + min(qb * A16_QB + A16_QB, a.Tq) - 1;
     int kend = kvl;
@@ -630,6 +633,35 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     int wave_kend = kvl;
     if (prefix) wave_kend = min(kvl, wv_qlast >= xl ? max(xl, wv_qlast + 1) : xl);
 
+    // staging by LDS-DMA (global_load_lds_dwordx4: one 1-KiB piece = 8 key rows x 128 B per wave-instruction, no staging
+    // registers, no ds_write): a tile is 8 pieces of K + 8 of V; waves 0 / 1 bring the K rows 0..31 / 32..63, waves 2 / 3
+    // the V rows.  Lane L fills slot (row L >> 3 of the piece, 16-byte chunk L & 7) of the lane-linear image, so it FETCHES
+    // chunk (L & 7) ^ swz(row): the swizzle lives in the source address.  Keys beyond Tk re-read the last written row
+    // (a masked weight is 0, but 0 x the NaN an unwritten cache row may hold is NaN).  Three images in a ring: tile t + 2 is
+    // requested at the top of tile t (two tiles of flight time); the barrier at the end of tile t orders tile t + 1.
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const bool stage_v = ws >= 2;
+    const char* sbase = (const char*)((stage_v ? a.vc : a.kc) + ((int64_t)b * a.n_heads + head) * a.S_max * VH_HEAD_DIM);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds + (stage_v ? A16_KT * 128 : 0) + (ws & 1) * 4096;
+    int srow[4];
+    uint32_t schunk[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        srow[i] = 32 * (ws & 1) + 8 * i + (lane >> 3);
+        const int swz = stage_v ? ((srow[i] >> 1) & 1) << 2 : (srow[i] >> 1) & 7;
+        schunk[i] = (uint32_t)(((lane & 7) ^ swz) << 4);
+    }
+    auto dma_tile = [&](int k0, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t voff = (uint32_t)min(k0 + srow[i], a.Tk - 1) * 128u + schunk[i];
+            const uint32_t dst = lds0 + buf * (2 * A16_KT * 128) + i * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory");
+        }
+    };
+    if (n_tiles > 0) dma_tile(0, 0);
+    if (n_tiles > 1) dma_tile(A16_KT, 1);
+
     // Q^T fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[query r][d = 16 s + 8 h + j]
     bf16x8 qf[4];
     {
@@ -637,27 +669,6 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, ldq(qr + 16 * s));
     }
-    // staging: the tile's 64 keys x 8 chunks of K and of V = 512 + 512 chunks of 16 B, two of each per thread
-    const uint16_t* kbase = a.kc + ((int64_t)b * a.n_heads + head) * a.S_max * VH_HEAD_DIM;
-    const uint16_t* vbase = a.vc + ((int64_t)b * a.n_heads + head) * a.S_max * VH_HEAD_DIM;
-    u32x4 sk[2], sv[2];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, key = min(k0 + (id >> 3), a.Tk - 1), c = id & 7;   // keys beyond Tk: the last written row
-            // again (masked: weight 0 — but 0 x the NaN an unwritten cache row may hold would still be NaN)
-            sk[i] = ldq(kbase + (int64_t)key * VH_HEAD_DIM + 8 * c);
-            sv[i] = ldq(vbase + (int64_t)key * VH_HEAD_DIM + 8 * c);
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, key = id >> 3, c = id & 7;
-            stq(lds + buf * 2 * A16_KT * 128 + key * 128 + ((c ^ ((key >> 1) & 7)) << 4), sk[i]);
-            stq(lds + buf * 2 * A16_KT * 128 + A16_KT * 128 + key * 128 + ((c ^ (((key >> 1) & 1) << 2)) << 4), sv[i]);
-        }
-    };
 
     f32x16 oacc[2];
 #pragma unroll
@@ -673,12 +684,16 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     // columns d = 32 db + 16 (g & 1) + 4 p .. + 3 -> chunk 4 db + 2 (g & 1) + (p >> 1), byte 8 (p & 1) in it
     const int g = lane >> 4, q4 = (lane >> 2) & 3, p = lane & 3;
 
-    if (n_tiles > 0) { gload(0); lstore(0); }
+    // vmcnt(0), unconditionally and BEFORE the loop: the first two tiles and the Q fragments have landed.  (The Q fragments
+    // are first used inside the loop; left to the compiler's wait insertion, vmcnt(3..0) lands in front of the first four
+    // score MFMAs of EVERY tile — a wait for the tile's own prefetches.  Seen in the ISA in round 6.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
+    int buf = 0;
     for (int it = 0; it < n_tiles; ++it) {
-        const int k0 = it * A16_KT, buf = it & 1;
-        const bool more = it + 1 < n_tiles;
-        if (more) gload(k0 + A16_KT);
+        const int k0 = it * A16_KT;
+        const bool ahead = it + 2 < n_tiles;                 // (wave-uniform)
+        if (ahead) dma_tile(k0 + 2 * A16_KT, buf >= 1 ? buf - 1 : 2);      // into image (it + 2) % 3, free since the last barrier
         if (k0 < wave_kend) {
             const char* kl = lds + buf * 2 * A16_KT * 128;
             const char* vl = kl + A16_KT * 128;
@@ -694,18 +709,16 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
                     sacc[u] = VH_MFMA16(kf, qf[s], sacc[u]);
                 }
             }
-            // ---- mask (only on tiles that need it: wave-uniform test) and the tile's row maximum
+            // ---- mask (only on tiles that need it: wave-uniform test): register x of sub-tile u holds key
+            // k0 + 32 u + (x & 3) + 8 (x >> 2) + 4 h, visible iff it is below the lane's bound — one compare + select each
             const bool need_mask = k0 + A16_KT > kvl || (prefix && k0 + A16_KT > xl && (wv_qfirst < xl || k0 + A16_KT - 1 > wv_qfirst));
             float mx = A16_NEG;
             if (need_mask) {
+                const int t = klim - k0 - 4 * h;
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int x = 0; x < 16; ++x) {
-                        const int key = k0 + 32 * u + (x & 3) + 8 * (x >> 2) + 4 * h;
-                        const bool vis = key < kvl && (!prefix || key < xl || (qpos >= xl && key <= qpos));
-                        sacc[u][x] = vis ? sacc[u][x] : A16_NEG;
-                    }
+                    for (int x = 0; x < 16; ++x) sacc[u][x] = 32 * u + (x & 3) + 8 * (x >> 2) < t ? sacc[u][x] : A16_NEG;
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -764,8 +777,12 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
                         oacc[db] = VH_MFMA16(vf, pf[u][s], oacc[db]);
                     }
         }
-        if (more) lstore(buf ^ 1);
+        // tile it + 1 (this wave's pieces of it: the four requests BEFORE the ones issued above) has landed; after the barrier
+        // every wave's pieces have, and nobody reads image `buf` any more
+        if (ahead) __builtin_amdgcn_s_waitcnt(0x0F74);       // vmcnt(4)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
         __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
     }
     // ---- epilogue: O / l, narrowed, transposed through LDS (per wave: 32 queries x 64 d) and stored as whole 128-B rows
     float l_tot = l_run + __shfl_xor(l_run, 32, 64);
