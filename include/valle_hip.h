@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define VH_VERSION 126            /* 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
+#define VH_VERSION 127            /* 0.2.3: perf-mode q is PRE-SCALED by 1/sqrt(64) log2(e) between vh_linear_qkv_bf16 and vh_attn_rows_bf16; 0.2.2: head + greedy step in one launch (vh_head_greedy, opt-in: vh_ar_decoder_desc.head_ws); 0.2.1: shared-prompt decode attention (vh_attn_decode_shared); 0.2.0: bf16-MFMA perf mode of the prompt pass / NAR stage (vh_*_bf16); 0.1.2: five-product attention backward (vh_attn_rows_bwd_ws); 0.1.1: dropout fields (vh_dropout_spec) */
 #define VH_MAX_TABLES 8           /* EnCodec @6 kbps: 8 codebooks (valle/config.py:15-17) */
 #define VH_HEAD_DIM 64            /* every configuration of the path has d_model/n_heads = 64 */
 
@@ -648,8 +648,10 @@ int vh_transformer_forward(const vh_forward_desc* desc, void* stream);
  *                           K % 64 == 0, act NONE / GELU_ERF.
  *   vh_linear_qkv_bf16      vh_linear_qkv with bf16 operands: q_out (M, d) ldq bf16, K / V rows appended to bf16 caches
  *                           (B,h,S_max,64) — the layout vh_attn_decode_kv16 streams, so a perf-mode generate needs no
- *                           narrowing pass.  d_model % 128 == 0.
- *   vh_attn_rows_bf16       vh_attn_rows over bf16 q / K / V with a bf16 output; analytic masks only (FULL / PREFIX). */
+ *                           narrowing pass.  d_model % 128 == 0.  q_out holds q' = q / sqrt(64) * log2(e), scaled in fp32
+ *                           before the one narrowing (since 0.2.3): the form vh_attn_rows_bf16 consumes.
+ *   vh_attn_rows_bf16       vh_attn_rows over bf16 q' / K / V with a bf16 output; analytic masks only (FULL / PREFIX).
+ *                           q' is PRE-SCALED (above): the weights are 2^(q'.k - max), i.e. softmax(q.k / 8) of the unscaled q. */
 /* The 16-bit operand format ("h16") of everything called *bf16 / *kv16 / *16 in this header — operands of the perf-mode kernels and
  * the narrow K/V cache of the decode step: 0 = IEEE fp16 (the default build: same MFMA rate as bf16, 11 bits of significand
  * against 8 — teacher-forced logits of the 24-layer stack 5.5e-3 from the reference against 4.2e-2), 1 = bf16 (the round-5

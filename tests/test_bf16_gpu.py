@@ -203,7 +203,7 @@ def test_linear_qkv_bf16_scatter(K, gemm_form, B, T, h, with_len):
     vc = torch.zeros_like(kc)
     q = torch.empty(B * T, d, device=DEV, dtype=H16)
     K.linear_qkv_bf16(a.to(DEV), w.to(DEV), q, kc, vc, B, T, h, cache_len=None if cl is None else cl.to(DEV))
-    torch.testing.assert_close(q.cpu().float(), ref[:, :d], atol=1e-5, rtol=EPS)
+    torch.testing.assert_close(q.cpu().float(), ref[:, :d] * K.Q16_PRESCALE, atol=1e-5, rtol=EPS)     # q leaves pre-scaled
     kref = ref[:, d:2 * d].view(B, T, h, 64).permute(0, 2, 1, 3)
     vref = ref[:, 2 * d:].view(B, T, h, 64).permute(0, 2, 1, 3)
     for b in range(B):
@@ -220,14 +220,14 @@ def test_attn_rows_bf16(K, B, h, T, mode):
     2^-9 per weight): the tolerance is that rounding on O(1) values, not the fp32 path's 3e-5."""
     from oracle.valle_oracle import build_attn_mask
     d = 64 * h
-    q = torch.randn(B, T, d, generator=g(40)).to(H16)
+    q = (torch.randn(B, T, d, generator=g(40)) * K.Q16_PRESCALE).to(H16)      # the kernel's q' = q / 8 * log2(e), rounded once
     k = torch.randn(B, h, T, 64, generator=g(41)).to(H16)
     v = torch.randn(B, h, T, 64, generator=g(42)).to(H16)
     xl = T // 3
     kvl = torch.tensor([T - (5 * i) % (T // 2 + 1) for i in range(B)], dtype=torch.int32)
     keypad = torch.arange(T)[None, :] >= kvl[:, None]
     masked = (build_attn_mask(xl, T - xl)[None] | keypad[:, None, :]) if mode == 'prefix' else keypad[:, None, :].expand(B, T, T)
-    qh = q.view(B, T, h, 64).permute(0, 2, 1, 3).double()
+    qh = q.view(B, T, h, 64).permute(0, 2, 1, 3).double() / K.Q16_PRESCALE
     ref = F.scaled_dot_product_attention(qh, k.double(), v.double(), attn_mask=~masked[:, None])
     ref = ref.permute(0, 2, 1, 3).reshape(B * T, d)
     S_max = T + 9
@@ -247,7 +247,7 @@ def test_attn_rows_bf16_per_row_text_lengths(K):
     from oracle.valle_oracle import build_attn_mask
     B, h, T = 4, 2, 200
     d = 64 * h
-    q = torch.randn(B, T, d, generator=g(47)).to(H16)
+    q = (torch.randn(B, T, d, generator=g(47)) * K.Q16_PRESCALE).to(H16)
     k = torch.randn(B, h, T, 64, generator=g(48)).to(H16)
     v = torch.randn(B, h, T, 64, generator=g(49)).to(H16)
     xl = torch.tensor([10, 64, 1, 130], dtype=torch.int32)
@@ -259,7 +259,7 @@ def test_attn_rows_bf16_per_row_text_lengths(K):
     for b in range(B):
         n = int(kvl[b])
         masked = build_attn_mask(int(xl[b]), T - int(xl[b])) | (torch.arange(T)[None, :] >= n)
-        qh = q[b].view(T, h, 64).permute(1, 0, 2).double()
+        qh = q[b].view(T, h, 64).permute(1, 0, 2).double() / K.Q16_PRESCALE
         ref = F.scaled_dot_product_attention(qh[None], k[b:b + 1].double(), v[b:b + 1].double(), attn_mask=~masked[None, None])
         ref = ref[0].permute(1, 0, 2).reshape(T, d)
         torch.testing.assert_close(out[b, :n], ref[:n], atol=1e-3 if FP16 else 6e-3, rtol=2 * EPS)          # rows beyond the row's length: don't care
@@ -270,13 +270,13 @@ def test_attn_rows_bf16_peaked_softmax(K):
     B, h, T = 1, 2, 200
     k = torch.randn(B, h, T, 64, generator=g(44))
     v = torch.randn(B, h, T, 64, generator=g(45)).to(H16)
-    q = torch.randn(B, T, h, 64, generator=g(46)).to(H16)
+    q = (torch.randn(B, T, h, 64, generator=g(46)) * K.Q16_PRESCALE).to(H16)
     k[:, :, 170] *= 40.0
     k[:, :, 3] *= 15.0
     k = k.to(H16)
     out = torch.empty(B * T, 64 * h, device=DEV, dtype=H16)
     K.attn_rows_bf16(q.reshape(B * T, -1).to(DEV), k.to(DEV), v.to(DEV), out, B, h, T, T, mode=K.MASK_FULL)
-    ref = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3).double(), k.double(), v.double())
+    ref = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3).double() / K.Q16_PRESCALE, k.double(), v.double())
     torch.testing.assert_close(out.cpu().double(), ref.permute(0, 2, 1, 3).reshape(B * T, -1), atol=1e-3 if FP16 else 6e-3, rtol=2 * EPS)
 
 

@@ -313,9 +313,11 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
     int64_t dstride = a.ldo;                                // elements between consecutive rows (q / plain output)
     bool cache = false;
     int b = 0, t = 0, cl = 0;
+    float qs = 1.f;                                         // q leaves pre-scaled (VH_Q16_PRESCALE)
     if (OUT == G16_QKV) {
         const int which = en / a.d_model, c = en - which * a.d_model;     // d_model % 128 == 0: a tile lies in one of q | K | V
         if (which == 0) {
+            qs = VH_Q16_PRESCALE;
             dst = (uint16_t*)a.out + c;
         } else {
             cache = true;
@@ -340,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm16_tile_kernel(Gemm16Args a, int t
             v0 = f32x4{g0.x, g0.y, g1.x, g1.y};
             v1 = f32x4{g2.x, g2.y, g3.x, g3.y};
         }
+        if (OUT == G16_QKV) { v0 = v0 * qs; v1 = v1 * qs; }
         const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
         if (cache) {
             stq(dst + ((int64_t)b * a.n_heads * a.S_max + cl + t) * VH_HEAD_DIM, pk);
@@ -488,6 +491,7 @@ __global__ __launch_bounds__(256, 4) void gemm16_occ_kernel(Gemm16Args a, int ti
                     v0 = f32x4{g0.x, g0.y, g1.x, g1.y};
                     v1 = f32x4{g2.x, g2.y, g3.x, g3.y};
                 }
+                if (OUT == G16_QKV && which == 0) { v0 = v0 * VH_Q16_PRESCALE; v1 = v1 * VH_Q16_PRESCALE; }      // q leaves pre-scaled
                 const u32x4 pk = {pack_bf16(v0.x, v0.y), pack_bf16(v0.z, v0.w), pack_bf16(v1.x, v1.y), pack_bf16(v1.z, v1.w)};
                 if (OUT == G16_QKV && which != 0) {
                     const int b = m / a.T, t = m - b * a.T;
@@ -590,6 +594,7 @@ extern "C" int vh_linear_qkv_bf16(const uint16_t* A, int lda, const uint16_t* Wq
 #define A16_QB 128
 #define A16_KT 64
 #define A16_RING 3
+#define A16_LAZY 8.0f      // a row's reference point moves when a tile's maximum exceeds it by more than this (base-2 exponent)
 #define A16_NEG (-1e30f)
 
 struct Attn16Args {
@@ -607,7 +612,8 @@ struct Attn16Args {
 
 __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     __shared__ __attribute__((aligned(16))) char lds[A16_RING * 2 * A16_KT * 128];   // ring of [K | V][64 keys][128 B] = 48 KB
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     // heaviest query blocks first (under the prefix mask the last blocks see the most keys)
     const int qb = a.n_qb - 1 - (int)(blockIdx.x / (a.B * a.n_heads));
@@ -639,22 +645,23 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     // chunk (L & 7) ^ swz(row): the swizzle lives in the source address.  Keys beyond Tk re-read the last written row
     // (a masked weight is 0, but 0 x the NaN an unwritten cache row may hold is NaN).  Three images in a ring: tile t + 2 is
     // requested at the top of tile t (two tiles of flight time); the barrier at the end of tile t orders tile t + 1.
-    const int ws = __builtin_amdgcn_readfirstlane(w);
-    const bool stage_v = ws >= 2;
+    const bool stage_v = w >= 2;
     const char* sbase = (const char*)((stage_v ? a.vc : a.kc) + ((int64_t)b * a.n_heads + head) * a.S_max * VH_HEAD_DIM);
-    const uint32_t lds0 = (uint32_t)(uintptr_t)lds + (stage_v ? A16_KT * 128 : 0) + (ws & 1) * 4096;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)lds + (stage_v ? A16_KT * 128 : 0) + (w & 1) * 4096;
     int srow[4];
-    uint32_t schunk[4];
+    uint32_t schunk[4], soff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        srow[i] = 32 * (ws & 1) + 8 * i + (lane >> 3);
+        srow[i] = 32 * (w & 1) + 8 * i + (lane >> 3);
         const int swz = stage_v ? ((srow[i] >> 1) & 1) << 2 : (srow[i] >> 1) & 7;
         schunk[i] = (uint32_t)(((lane & 7) ^ swz) << 4);
+        soff[i] = (uint32_t)srow[i] * 128u + schunk[i];      // byte offset inside a tile that lies wholly below Tk
     }
     auto dma_tile = [&](int k0, int buf) {
+        const bool whole = k0 + A16_KT <= a.Tk;               // (wave-uniform) no row of the tile needs the clamp
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t voff = (uint32_t)min(k0 + srow[i], a.Tk - 1) * 128u + schunk[i];
+            const uint32_t voff = whole ? soff[i] + (uint32_t)k0 * 128u : (uint32_t)min(k0 + srow[i], a.Tk - 1) * 128u + schunk[i];
             const uint32_t dst = lds0 + buf * (2 * A16_KT * 128) + i * 1024;
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff), "s"(sbase) : "memory");
         }
@@ -662,21 +669,31 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     if (n_tiles > 0) dma_tile(0, 0);
     if (n_tiles > 1) dma_tile(A16_KT, 1);
 
-    // Q^T fragments (B operand of S^T = K Q^T): lane (r, h) holds Q[query r][d = 16 s + 8 h + j]
+    // Q^T fragments (B operand of S^T = K Q^T): lane (r, h) holds Q'[query r][d = 16 s + 8 h + j].  Q' = c Q with
+    // c = 1 / sqrt(64) * log2(e) comes PRE-SCALED from the producer (vh_linear_qkv_bf16 scales in fp32 before the one
+    // narrowing: no second rounding), so the score accumulators are base-2 exponents.
     bf16x8 qf[4];
     {
         const uint16_t* qr = a.q + ((int64_t)b * a.Tq + qi) * a.ldq + head * VH_HEAD_DIM + 8 * h;
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(bf16x8, ldq(qr + 16 * s));
     }
-
-    f32x16 oacc[2];
+    // Softmax without a per-element subtraction or sum (the kernel is bound by vector ISSUE slots, ~200 per 32 x 64 scores
+    // before this; profiles/r6_pmc_attn16.md): the reference point m_ref of a row moves only when a tile's maximum exceeds it
+    // by more than A16_LAZY (weights then reach at most 2^A16_LAZY: exact in the 16-bit formats, fp32 sums), and -m_ref sits
+    // in sixteen registers that are the INITIAL ACCUMULATOR of the score MFMAs — the chain delivers c S - m_ref, the weight
+    // is one v_exp_f32 of that.  The row sum comes out of the matrix pipe as well: a third accumulator block whose A operand
+    // is 1 on rows 0 and 4 (lacc[0] of every lane = its query's sum over both key halves, taken from the ROUNDED weights
+    // the products see).  Moving m_ref rescales O, the sums and the pending scores by 2^-delta, all of them (tile 0 always moves).
+    f32x16 oacc[2], lacc, minit;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) oacc[i][e] = 0.f;
-    float m_run = A16_NEG, l_run = 0.f;
-    const float c_exp = 0.125f * 1.4426950408889634f;        // 1 / sqrt(64) * log2(e)
+    for (int e = 0; e < 16; ++e) { oacc[0][e] = 0.f; oacc[1][e] = 0.f; lacc[e] = 0.f; minit[e] = 0.f; }
+    float m_ref = 0.f;
+    bf16x8 ones;
+    {
+        const uint32_t one2 = vh_pack_h16(1.f, 1.f), w1 = (r == 0 || r == 4) ? one2 : 0u;
+        ones = __builtin_bit_cast(bf16x8, u32x4{w1, w1, w1, w1});
+    }
 
     // K fragment addresses (A operand of S^T): key row 32 u + r, chunk (2 s + h) ^ ((r >> 1) & 7)
     const int kswz = (r >> 1) & 7;
@@ -697,22 +714,18 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
         if (k0 < wave_kend) {
             const char* kl = lds + buf * 2 * A16_KT * 128;
             const char* vl = kl + A16_KT * 128;
-            // ---- S^T = K Q^T for the two 32-key sub-tiles
+            // ---- c S^T - m_ref = K (c Q)^T + (-m_ref) for the two 32-key sub-tiles
             f32x16 sacc[2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[u][e] = 0.f;
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const bf16x8 kf = __builtin_bit_cast(bf16x8, ldq(kl + (32 * u + r) * 128 + (((2 * s + h) ^ kswz) << 4)));
-                    sacc[u] = VH_MFMA16(kf, qf[s], sacc[u]);
+                    sacc[u] = VH_MFMA16(kf, qf[s], s ? sacc[u] : minit);
                 }
-            }
             // ---- mask (only on tiles that need it: wave-uniform test): register x of sub-tile u holds key
             // k0 + 32 u + (x & 3) + 8 (x >> 2) + 4 h, visible iff it is below the lane's bound — one compare + select each
             const bool need_mask = k0 + A16_KT > kvl || (prefix && k0 + A16_KT > xl && (wv_qfirst < xl || k0 + A16_KT - 1 > wv_qfirst));
-            float mx = A16_NEG;
             if (need_mask) {
                 const int t = klim - k0 - 4 * h;
 #pragma unroll
@@ -720,45 +733,47 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
 #pragma unroll
                     for (int x = 0; x < 16; ++x) sacc[u][x] = 32 * u + (x & 3) + 8 * (x >> 2) < t ? sacc[u][x] : A16_NEG;
             }
+            // ---- the tile's row maximum relative to m_ref (the query's other key half sits in lane ^ 32)
+            float mx = A16_NEG;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int x = 0; x < 16; ++x) mx = fmaxf(mx, sacc[u][x]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));             // the query's other key half
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = vh_exp2((m_run - m_new) * c_exp);
-            const float mc = m_new * c_exp;
-            m_run = m_new;
-            // ---- P^T = 2^(S c - m c), its row sum, and the bf16 B operands (keys of a k-step in accumulator order)
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(uint32_t, mx), __builtin_bit_cast(uint32_t, mx), false, false);
+                mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+            }
+            if (it == 0 || __builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(mx > A16_LAZY) != 0)) {
+                // move the reference point: to the row's maximum on the first tile, up to it (never down) later
+                // (a row without any visible key in tile 0 — none under the analytic masks while kv_len >= 1 — stays at 0)
+                const float delta = it == 0 ? (mx > 0.5f * A16_NEG ? mx : 0.f) : fmaxf(mx, 0.f);
+                m_ref += delta;
+                const float alpha = vh_exp2(-delta);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { minit[e] = -m_ref; sacc[0][e] -= delta; sacc[1][e] -= delta; }
+                if (it) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { oacc[0][e] *= alpha; oacc[1][e] *= alpha; }
+                    lacc[0] *= alpha;
+                }
+            }
+            // ---- P^T = 2^(c S - m_ref) narrowed into the B operands (keys of a k-step in accumulator order)
             bf16x8 pf[2][2];
-            float psum = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                for (int x = 0; x < 16; ++x) {
-                    const float pv = vh_exp2(fmaf(sacc[u][x], c_exp, -mc));
-                    sacc[u][x] = pv;
-                    psum += pv;
-                }
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const u32x4 pk = {vh_pack_h16_unit(sacc[u][8 * s + 0], sacc[u][8 * s + 1]), vh_pack_h16_unit(sacc[u][8 * s + 2], sacc[u][8 * s + 3]),
-                                      vh_pack_h16_unit(sacc[u][8 * s + 4], sacc[u][8 * s + 5]), vh_pack_h16_unit(sacc[u][8 * s + 6], sacc[u][8 * s + 7])};
-                    pf[u][s] = __builtin_bit_cast(bf16x8, pk);
-                }
-            }
-            l_run = l_run * alpha + psum;
-            if (__builtin_amdgcn_readfirstlane(__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0)) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) oacc[i][e] *= alpha;
-            }
-            // ---- O^T += V^T P^T: A operand element j of lane half h = V[key 32 u + 16 s + 8 (j >> 2) + 4 h + (j & 3)][d = 32 db + r]
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s) {
+                    u32x4 pk;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[j] = vh_pack_h16_unit(vh_exp2(sacc[u][8 * s + 2 * j]), vh_exp2(sacc[u][8 * s + 2 * j + 1]));
+                    pf[u][s] = __builtin_bit_cast(bf16x8, pk);
+                }
+            // ---- O^T += V^T P^T: A operand element j of lane half h = V[key 32 u + 16 s + 8 (j >> 2) + 4 h + (j & 3)][d = 32 db + r];
+            // and the row sums, l += 1^T P^T
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
 #pragma unroll
                     for (int db = 0; db < 2; ++db) {
                         u32x2 lo, hi;
@@ -776,6 +791,8 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
                         const bf16x8 vf = __builtin_bit_cast(bf16x8, u32x4{lo.x, lo.y, hi.x, hi.y});
                         oacc[db] = VH_MFMA16(vf, pf[u][s], oacc[db]);
                     }
+                    lacc = VH_MFMA16(ones, pf[u][s], lacc);
+                }
         }
         // tile it + 1 (this wave's pieces of it: the four requests BEFORE the ones issued above) has landed; after the barrier
         // every wave's pieces have, and nobody reads image `buf` any more
@@ -785,8 +802,8 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
         buf = buf == 2 ? 0 : buf + 1;
     }
     // ---- epilogue: O / l, narrowed, transposed through LDS (per wave: 32 queries x 64 d) and stored as whole 128-B rows
-    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = (l_tot > 0.f && m_run > 0.5f * A16_NEG) ? 1.f / l_tot : 0.f;
+    const float l_tot = lacc[0];
+    const float inv = l_tot > 0.f ? 1.f / l_tot : 0.f;
     char* ow = lds + w * 32 * 144;                           // 144-B rows (128 + 16 of padding)
 #pragma unroll
     for (int db = 0; db < 2; ++db)

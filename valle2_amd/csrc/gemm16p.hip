@@ -424,6 +424,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_p256_kernel(Gemm16Args a, int t
                             const vh_f32x2 g0 = gelu16_2(vh_f32x2{v0, v1}), g1 = gelu16_2(vh_f32x2{v2, v3});
                             v0 = g0.x; v1 = g0.y; v2 = g1.x; v3 = g1.y;
                         }
+                        if (OUT == G16_QKV && which == 0) {      // (wave-uniform) q leaves pre-scaled: vh_common.h
+                            v0 *= VH_Q16_PRESCALE; v1 *= VH_Q16_PRESCALE; v2 *= VH_Q16_PRESCALE; v3 *= VH_Q16_PRESCALE;
+                        }
                         const u32x2 pk = {pack_bf16(v0, v1), pack_bf16(v2, v3)};
                         *reinterpret_cast<u32x2*>(scb + c * 64 + (((2 * q + h) ^ ((c >> 1) & 7)) << 3)) = pk;
                     }

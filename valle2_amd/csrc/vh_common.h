@@ -67,6 +67,10 @@ __device__ __forceinline__ float vh_h16_hi(uint32_t w) {
 #define VH_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #endif
 
+// perf mode: the QKV product writes q PRE-SCALED by 1 / sqrt(64) * log2(e) (in fp32, before the one narrowing), so that the score
+// accumulators of the many-row attention are base-2 exponents (include/valle_hip.h, vh_linear_qkv_bf16 / vh_attn_rows_bf16)
+#define VH_Q16_PRESCALE 0.18033688011112042f
+
 #define VH_WAVE 64
 
 // ---- host side: argument checking ------------------------------------------------------------

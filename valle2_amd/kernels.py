@@ -472,6 +472,9 @@ def linear_bf16(a, w, bias=None, residual=None, out=None, act=ACT_NONE, out_bf16
     return out
 
 
+Q16_PRESCALE = 0.125 * 1.4426950408889634     # perf mode: q leaves linear_qkv_bf16 scaled by 1/sqrt(64) * log2(e); attn_rows_bf16 expects it
+
+
 def linear_qkv_bf16(a, wqkv, q_out, kcache16, vcache16, B, T, n_heads, cache_len=None):
     d = a.shape[1]
     S_max = kcache16.shape[2]
