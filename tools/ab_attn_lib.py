@@ -75,7 +75,7 @@ def main():
     for name, B, h, T, mode, xl in (('fwd16 prompt pass 32x1024 prefix', 32, 8, 1024, MASK_PREFIX, 256),
                                    ('fwd16 NAR stage 64x1024 full', 64, 8, 1024, MASK_FULL, 0)):
         d = h * 64
-        q = torch.randn(B * T, d, generator=g).to(H16).to(dev)
+        q = (torch.randn(B * T, d, generator=g) * 0.18033688).to(H16).to(dev)     # pre-scaled by 1/sqrt(64) log2(e) (ABI 127)
         kc = torch.randn(B, h, T, 64, generator=g).to(H16).to(dev)
         vc = torch.randn(B, h, T, 64, generator=g).to(H16).to(dev)
         out = torch.zeros(B * T, d, device=dev, dtype=H16)

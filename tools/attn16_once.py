@@ -13,7 +13,7 @@ prompt = len(sys.argv) > 1 and sys.argv[1] == 'prompt'
 B, h, T, mode, xl = (32, 8, 1024, K.MASK_PREFIX, 256) if prompt else (64, 8, 1024, K.MASK_FULL, 0)
 g = torch.Generator().manual_seed(0)
 d = h * 64
-q = torch.randn(B * T, d, generator=g).to(h16_dtype()).cuda()
+q = (torch.randn(B * T, d, generator=g) * K.Q16_PRESCALE).to(h16_dtype()).cuda()
 kc = torch.randn(B, h, T, 64, generator=g).to(h16_dtype()).cuda()
 vc = torch.randn(B, h, T, 64, generator=g).to(h16_dtype()).cuda()
 out = torch.zeros(B * T, d, device='cuda', dtype=h16_dtype())

@@ -87,7 +87,7 @@ def main():
         k32 = torch.randn(B, h, T, 64, generator=g).to(DEV)
         v32 = torch.randn(B, h, T, 64, generator=g).to(DEV)
         o32 = torch.empty(B * T, d, device=DEV)
-        q, k, v = q32.to(H16), k32.to(H16), v32.to(H16)
+        q, k, v = (q32 * K.Q16_PRESCALE).to(H16), k32.to(H16), v32.to(H16)      # q as the QKV product hands it over: pre-scaled
         o = torch.empty(B * T, d, device=DEV, dtype=H16)
         kw = dict(mode=K.MASK_FULL) if mode == 'full' else dict(mode=K.MASK_PREFIX, x_len=256)
         t16 = timeit(lambda: K.attn_rows_bf16(q, k, v, o, B, h, T, T, **kw), args.reps)

@@ -28,7 +28,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     for name, B, h, T, mode, xl in (('prompt pass 32x1024 prefix', 32, 8, 1024, 1, 256), ('NAR stage 64x1024 full', 64, 8, 1024, 0, 0)):
         d = h * 64
-        q = torch.randn(B * T, d, generator=g).to(H16).cuda()
+        q = (torch.randn(B * T, d, generator=g) * 0.18033688).to(H16).cuda()      # pre-scaled by 1/sqrt(64) log2(e) (ABI 127)
         kc = torch.randn(B, h, T, 64, generator=g).to(H16).cuda()
         vc = torch.randn(B, h, T, 64, generator=g).to(H16).cuda()
         out = torch.zeros(B * T, d, device='cuda', dtype=H16)

@@ -615,9 +615,22 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // heaviest query blocks first (under the prefix mask the last blocks see the most keys)
-    const int qb = a.n_qb - 1 - (int)(blockIdx.x / (a.B * a.n_heads));
-    const int bh = blockIdx.x % (a.B * a.n_heads);
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2; the grid is padded to 8 x ceil(n_bh / 8) (batch row,
+    // head) pairs x n_qb query blocks.  FULL mask (every block of a pair costs the same): XCD x takes the pairs x, x + 8, ... and
+    // runs the query blocks of ONE pair back to back, so the pair's K / V (2 x Tk x 128 B) is fetched once into that L2 and
+    // re-read from there by the other blocks (NAR-stage shape: 0.93x the time of the order below).  PREFIX mask: the last
+    // query block of a pair sees up to 4x the keys of the first, and the launch wants the heaviest blocks of ALL pairs
+    // first (grouped by pair it took 1.4x the time at the prompt-pass shape); a pair's blocks still share an XCD.
+    const int n_bh8 = (a.B * a.n_heads + 7) & ~7;
+    int bh, qb;
+    if (a.mode == VH_MASK_FULL) {
+        bh = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / a.n_qb);
+        qb = (int)((blockIdx.x >> 3) % a.n_qb);
+    } else {
+        bh = (int)(blockIdx.x % n_bh8);
+        qb = a.n_qb - 1 - (int)(blockIdx.x / n_bh8);
+    }
+    if (bh >= a.B * a.n_heads) return;                       // (the whole workgroup)
     const int b = bh / a.n_heads, head = bh - b * a.n_heads;
     const int q_off = a.Tk - a.Tq;
     const int kvl = a.kv_len ? min(a.kv_len[b], a.Tk) : a.Tk;
@@ -837,7 +850,7 @@ extern "C" int vh_attn_rows_bf16(const uint16_t* q, int ldq_, const uint16_t* kc
                "vh_attn_rows_bf16: pointers must be 16-byte aligned");
     Attn16Args a{q, ldq_, kcache16, vcache16, out, ldo, B, n_heads, Tq, Tk, S_max, mode, x_len, x_len_dev, kv_len,
                  (Tq + A16_QB - 1) / A16_QB};
-    const int64_t grid = (int64_t)a.n_qb * B * n_heads;
+    const int64_t grid = (int64_t)a.n_qb * 8 * (((int64_t)B * n_heads + 7) / 8);     // (see the kernel: 8 XCDs x pairs x query blocks)
     VH_REQUIRE(grid < (1ll << 31), VH_EUNSUPPORTED, "vh_attn_rows_bf16: grid too large");
     hipLaunchKernelGGL(attn16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
     VH_CHECK_LAUNCH("vh_attn_rows_bf16");
