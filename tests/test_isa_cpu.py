@@ -21,3 +21,12 @@ def test_attention_backward_isa_properties():
     import check_isa
     problems = check_isa.check_attention(check_isa.compile_attention_asm())
     assert not problems, '\n'.join(problems)
+
+
+@pytest.mark.skipif(not os.path.exists('/opt/rocm/bin/hipcc'), reason='hipcc not installed')
+def test_attention_tile_loops_do_not_wait_for_their_own_prefetch():
+    """Round 6: no `s_waitcnt vmcnt` directly in front of an MFMA inside a loop of the attention kernels."""
+    import check_isa
+    problems = check_isa.check_loop_waits(check_isa.compile_attention_asm(), check_isa.ATTN_WAIT_KERNELS)
+    problems += check_isa.check_loop_waits(check_isa.compile_bf16_asm(), check_isa.BF16_WAIT_KERNELS)
+    assert not problems, '\n'.join(problems)

@@ -16,6 +16,9 @@ from pathlib import Path
 
 REPO = Path(__file__).resolve().parent.parent
 HIPCC = '/opt/rocm/bin/hipcc'
+ATTN_WAIT_KERNELS = ['_Z21attn_bwd_fused_kernelILi8EEv7BwdArgs', '_Z21attn_bwd_fused_kernelILi4EEv7BwdArgs', '_Z19attn_bwd_dkv_kernel7BwdArgs',
+                     '_Z16attn_rows_kernel8RowsArgs']
+BF16_WAIT_KERNELS = ['_Z13attn16_kernel10Attn16Args']
 
 
 def compile_asm():
@@ -114,8 +117,46 @@ def check_attention(asm):
     return problems
 
 
+def compile_bf16_asm():
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / 'bf16.s'
+        subprocess.run([HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-S', '--cuda-device-only',
+                        '-mllvm', '-amdgpu-kernarg-preload-count=16',
+                        f'-I{REPO / "include"}', str(REPO / 'valle2_amd/csrc/bf16.hip'), '-o', str(out)],
+                       check=True, capture_output=True)
+        return out.read_text()
+
+
+def check_loop_waits(asm, kernels):
+    """Round 6: fragments loaded BEFORE a tile loop and first used INSIDE it made the compiler's wait insertion put
+    `s_waitcnt vmcnt(n)` in front of the first MFMAs of every iteration whenever a path around the pre-loop wait existed — a
+    wait for the iteration's own prefetches (attn16_kernel, attn_bwd_fused_kernel<8>, attn_bwd_dkv_kernel).  The
+    kernels carry an unconditional vmcnt(0) before their loops now; this asserts that no vmcnt wait stands directly in front of
+    an MFMA inside any loop of the named kernels."""
+    problems = []
+    for mangled in kernels:
+        m = re.search(r'^%s:[^\n]*\n(.*?)^\.Lfunc_end' % re.escape(mangled), asm, re.S | re.M)
+        if not m:
+            problems.append(f'{mangled} not found')
+            continue
+        lines = m.group(1).splitlines()
+        inloop = False
+        for i, l in enumerate(lines):
+            if 'Loop Header' in l or 'in Loop:' in l:
+                inloop = True
+            elif re.match(r'^\.LBB', l):
+                inloop = False
+            t = l.strip()
+            if inloop and t.startswith('s_waitcnt') and 'vmcnt' in t:
+                nxt = next((x.strip() for x in lines[i + 1:i + 4] if x.strip() and not x.strip().startswith(';')), '')
+                if nxt.startswith('v_mfma'):
+                    problems.append(f'{mangled}: "{t}" in front of an MFMA inside a loop')
+    return problems
+
+
 if __name__ == '__main__':
     probs = check(compile_asm()) + check_attention(compile_attention_asm())
+    probs += check_loop_waits(compile_attention_asm(), ATTN_WAIT_KERNELS) + check_loop_waits(compile_bf16_asm(), BF16_WAIT_KERNELS)
     for p in probs:
         print('ISA check:', p)
     print('ISA check:', 'FAILED' if probs else 'ok')
