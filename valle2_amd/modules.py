@@ -321,8 +321,8 @@ class MultiHeadAttention(nn.Module):
     def _forward_any_head_dim(self, x, attn_mask, padding_mask, kv_cache, use_cache, _ln, _residual):
         """The same forward for a head width other than 64 (modules.py:109-111 allows any divisor; 64 is what every
         configuration of the path has and what the flash / decode kernels are built for): the projection on the general
-        GEMMs and materialised attention (kernels.attn_generic) — correct, not tuned; the cache is the reference's own
-        protocol, (k, v) tensors grown by a device copy per call."""
+        GEMMs and materialised attention (kernels.attn_generic) — correct, not tuned; the cache keeps the reference's
+        protocol ((k, v) tensors in, (k, v) tensors out) and grows in place behind it."""
         b, n, d = x.shape
         h, hd = self.n_heads, self.head_dim
         if hd % 4:
@@ -333,9 +333,23 @@ class MultiHeadAttention(nn.Module):
         f32 = dict(device=x.device, dtype=torch.float32)
         qkv = kernels.linear(x2, self.qkv.weight.detach(), out=torch.empty(b * n, 3 * d, **f32))
         q, k, v = (qkv.view(b, n, 3, h, hd)[:, :, j].permute(0, 2, 1, 3) for j in range(3))
-        if use_cache and kv_cache is not None:
-            k = torch.cat([kv_cache[0].to(x.device), k], dim=2)
-            v = torch.cat([kv_cache[1].to(x.device), v], dim=2)
+        info = None
+        if use_cache:
+            # the cache grows IN PLACE (round 6; the reference does a torch.cat of the whole cache per call, modules.py:151-157):
+            # the (k, v) views a call returns carry their buffer, and the next call writes its n new rows behind them; a foreign
+            # cache (or a full buffer) is adopted once into a buffer of twice the size — amortised O(1) copies per row
+            past = 0 if kv_cache is None else kv_cache[0].shape[-2]
+            info = getattr(kv_cache[0], '_vh_cache', None) if kv_cache is not None else None
+            if (info is None or info.length != past or info.kbuf.shape[2] < past + n or info.kbuf.shape[-1] != hd
+                    or info.kbuf.shape[0] != b or info.kbuf.device != x.device):
+                cap = max(2 * (past + n), past + n + 64)
+                info = _CacheView(torch.empty(b, h, cap, hd, **f32), torch.empty(b, h, cap, hd, **f32), past)
+                if past:
+                    info.kbuf[:, :, :past] = kv_cache[0]
+                    info.vbuf[:, :, :past] = kv_cache[1]
+            info.kbuf[:, :, past:past + n] = k
+            info.vbuf[:, :, past:past + n] = v
+            k, v = info.kbuf[:, :, :past + n], info.vbuf[:, :, :past + n]
         total = k.shape[2]
         spec = _mask_spec(attn_mask, padding_mask, n, total, x.device)
         attn = torch.empty(b * n, d, **f32)
@@ -343,7 +357,7 @@ class MultiHeadAttention(nn.Module):
         res2 = _residual.reshape(b * n, d) if _residual is not None else None
         out = kernels.linear(attn, self.out.weight.detach(), self.out.bias.detach(), residual=res2,
                              out=torch.empty(b * n, d, **f32))
-        kv = (k.contiguous(), v.contiguous()) if use_cache else None
+        kv = _tag(k, v, _CacheView(info.kbuf, info.vbuf, total)) if use_cache else None
         return out.view(b, n, d), kv
 
     def merge_masks(self, batch_size, attn_mask, key_padding_mask):
