@@ -200,6 +200,24 @@ def bf16_weights(transformer):
     return out
 
 
+def head16(module, weight):
+    """The h16 copy of a head matrix (V, d) for the perf-mode NAR stage (valle_nar.py: the stage's projection over every target
+    frame is a large-M product like the stack's; fp32 it was 0.5 of a 10 ms stage) — None when the 16-bit tile GEMM does not
+    take the shape.  Built once per weight version, cached on the owning module like the other derived forms."""
+    V, d = weight.shape
+    if V % 128 or d % 64:
+        return None
+    cache = _derived(module).setdefault('head16', {})
+    key = (_WEIGHTS_EPOCH, weight.data_ptr(), weight._version)
+    hit = cache.get(id(weight))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad(), torch.inference_mode(False):
+        w16 = kernels.to_bf16(weight.detach())
+    cache[id(weight)] = (key, w16)
+    return w16
+
+
 # perf mode's decode step over h16 copies of its four matrices (+ the head): built in round 6, measured SLOWER (471.1 vs 463.9 us per
 # step at 32 rows x 12L/512d, profiles/r6_ab_decode_w16.log — the chain's launches are round trips, not byte streams, and an 8-byte
 # fragment per lane halves the useful part of every line it touches) — so it is opt-in: VALLE2_DECODE_W16=1

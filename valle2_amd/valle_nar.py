@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, dropout, kernels
-from .engine import ForwardScratch, ForwardScratch16, KVCache, transformer_forward, transformer_forward_bf16
+from .engine import ForwardScratch, ForwardScratch16, KVCache, head16, transformer_forward, transformer_forward_bf16
 from .modules import PositionalEncoding, TokenEmbedding, Transformer, _on_device
 from .valle_ar import _Base
 
@@ -104,8 +104,17 @@ class ValleNAR(_Base):
             transformer_forward(self.transformer, x, cache, mode=kernels.MASK_FULL,
                                 embedding=self.stage_embs[stage - 1].weight)  # (the parameter itself: adaln_table keys on it)
         z = x[:, tx + p:].reshape(b * (t - p), d)
-        logits = kernels.linear(z, self.proj_layers[stage - 1].weight.detach())
+        logits = self._head(z, stage, perf_mode)
         return logits.reshape(b, t - p, -1), p
+
+    def _head(self, z, stage: int, perf_mode):
+        """The stage's projection (valle_nar.py:97-98) over the packed target frames z (rows, d); in perf mode on the 16-bit
+        matrix cores like the stack's products (fp32 accumulate, fp32 logits) when the tile GEMM takes the shape."""
+        w = self.proj_layers[stage - 1].weight
+        w16 = head16(self, w) if perf_mode else None
+        if w16 is None:
+            return kernels.linear(z, w.detach())
+        return kernels.linear_bf16(kernels.to_bf16(z), w16)
 
     def _stage_logits_with_graph(self, batch, stage: int):
         """`stage_logits` composed from autograd Functions (training path)."""
@@ -242,7 +251,7 @@ class ValleNAR(_Base):
             forward(self.transformer, x, cache, mode=kernels.MASK_FULL, kv_len=kv_len,
                     embedding=self.stage_embs[n - 1].weight, scratch=scratch)                # (cached AdaLN table per stage)
             z = x.view(B * total, d).index_select(0, idx)                      # target frames of every row
-            logits = kernels.linear(z, self.proj_layers[n - 1].weight.detach())
+            logits = self._head(z, n, perf_mode)
             kernels.categorical_rows(logits, toks, temperature=cfg.temperature, greedy=greedy, seed=seed,
                                      stream_id=n)
             out[:, :, n][valid] = toks                                          # packed row-major -> (B, ty_max)
