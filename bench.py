@@ -857,7 +857,8 @@ def main():
                         'ms': st_p['prefill_ms'], 'prefill_bf16': bool(st_p.get('prefill_bf16')),
                         'tflops': prefill_flop / (st_p['prefill_ms'] * 1e-3) / 1e12, 'mfma_bf16_peak_tflops': MFMA_BF16_PEAK_TF,
                         'frac_of_bf16_peak': prefill_flop / (st_p['prefill_ms'] * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF,
-                        'vs_f32_prefill': st['prefill_ms'] / st_p['prefill_ms']}}
+                        # (against the headline run's prompt pass — `st` has been overwritten by the roofline leg's eager pass by now)
+                        'vs_f32_prefill': (result['prefill']['ms'] / st_p['prefill_ms']) if 'prefill' in result else None}}
 
     if rank == 0 and world == 1 and not args.no_rows64 and not args.small:
         # A LABELLED SECONDARY line: the same fp32 generate with TWICE the rows BASELINE.json names (64 distinct utterances,
