@@ -623,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void attn16_kernel(Attn16Args a) {
     // first (grouped by pair it took 1.4x the time at the prompt-pass shape); a pair's blocks still share an XCD.
     const int n_bh8 = (a.B * a.n_heads + 7) & ~7;
     int bh, qb;
-    if (a.mode == VH_MASK_FULL) {
+    // (grouped only when the pairs deal evenly over the 8 XCDs, or are many: 4 pairs would leave half the chip without work)
+    if (a.mode == VH_MASK_FULL && (a.B * a.n_heads == n_bh8 || a.B * a.n_heads >= 64)) {
         bh = (int)(blockIdx.x & 7) + 8 * (int)((blockIdx.x >> 3) / a.n_qb);
         qb = (int)((blockIdx.x >> 3) % a.n_qb);
     } else {
