@@ -280,6 +280,26 @@ def test_attn_rows_bf16_peaked_softmax(K):
     torch.testing.assert_close(out.cpu().double(), ref.permute(0, 2, 1, 3).reshape(B * T, -1), atol=1e-3 if FP16 else 6e-3, rtol=2 * EPS)
 
 
+@pytest.mark.parametrize('step', [5.0, 9.0, -6.0])
+def test_attn_rows_bf16_drifting_maximum(K, step):
+    """The row's reference point moves lazily (round 6: only when a tile's maximum exceeds it by more than 2^8): scores whose
+    maximum drifts by `step` base-2 exponents per 64-key tile — below the threshold (the reference point lags: weights up to 2^8),
+    above it (it moves every tile), and downwards (the first tile holds the maximum: it never moves again)."""
+    B, h, T = 2, 2, 640
+    d = 64 * h
+    q = 0.05 * torch.randn(B, T, h, 64, generator=g(60))
+    k = 0.05 * torch.randn(B, h, T, 64, generator=g(61))
+    v = torch.randn(B, h, T, 64, generator=g(62)).to(H16)
+    q[..., 0] = 1.0                                       # exponent of key j (pre-scaled q): ~ step * j / 64
+    k[..., 0] = step * torch.arange(T) / 64.0
+    q, k = q.to(H16), k.to(H16)
+    out = torch.empty(B * T, d, device=DEV, dtype=H16)
+    K.attn_rows_bf16(q.reshape(B * T, d).to(DEV), k.to(DEV), v.to(DEV), out, B, h, T, T, mode=K.MASK_FULL)
+    ref = F.scaled_dot_product_attention(q.permute(0, 2, 1, 3).double() / K.Q16_PRESCALE, k.double(), v.double())
+    assert bool(torch.isfinite(out.float()).all())
+    torch.testing.assert_close(out.cpu().double(), ref.permute(0, 2, 1, 3).reshape(B * T, d), atol=2e-3 if FP16 else 1e-2, rtol=2 * EPS)
+
+
 # ---- model level: the perf-mode forward against the REAL reference's goldens (atol 5e-2, SURVEY 8c) --------------------
 def build(name, kw, sd):
     from valle2_amd import get_model_class
