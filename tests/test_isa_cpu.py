@@ -28,5 +28,7 @@ def test_attention_tile_loops_do_not_wait_for_their_own_prefetch():
     """Round 6: no `s_waitcnt vmcnt` directly in front of an MFMA inside a loop of the attention kernels."""
     import check_isa
     problems = check_isa.check_loop_waits(check_isa.compile_attention_asm(), check_isa.ATTN_WAIT_KERNELS)
-    problems += check_isa.check_loop_waits(check_isa.compile_bf16_asm(), check_isa.BF16_WAIT_KERNELS)
+    bf16 = check_isa.compile_bf16_asm()
+    problems += check_isa.check_loop_waits(bf16, check_isa.BF16_WAIT_KERNELS)
+    problems += check_isa.check_m0(bf16, check_isa.BF16_WAIT_KERNELS)         # the LDS-DMA staging writes M0 from inline asm
     assert not problems, '\n'.join(problems)

@@ -154,9 +154,32 @@ def check_loop_waits(asm, kernels):
     return problems
 
 
+def check_m0(asm, kernels):
+    """Kernels that issue LDS-DMA from inline assembly write M0 behind the compiler's back (no clobber list tracks it): every
+    reference to m0 in them must be one of our own `s_mov_b32 m0, ...` (the same rule check() applies to the tile GEMMs)."""
+    problems = []
+    for mangled in kernels:
+        m = re.search(r'^%s:[^\n]*\n(.*?)^\.Lfunc_end' % re.escape(mangled), asm, re.S | re.M)
+        if not m:
+            problems.append(f'{mangled} not found')
+            continue
+        n_dma = 0
+        for l in m.group(1).splitlines():
+            t = l.strip()
+            if not t or t.startswith(';'):
+                continue
+            n_dma += t.startswith('global_load_lds_dwordx4')
+            if re.search(r'\bm0\b', t) and not t.startswith('s_mov_b32 m0,'):
+                problems.append(f'{mangled}: m0 used outside the DMA sequence: {t}')
+        if n_dma == 0:
+            problems.append(f'{mangled}: no global_load_lds_dwordx4 found (the staging is expected to be LDS-DMA)')
+    return problems
+
+
 if __name__ == '__main__':
     probs = check(compile_asm()) + check_attention(compile_attention_asm())
     probs += check_loop_waits(compile_attention_asm(), ATTN_WAIT_KERNELS) + check_loop_waits(compile_bf16_asm(), BF16_WAIT_KERNELS)
+    probs += check_m0(compile_bf16_asm(), BF16_WAIT_KERNELS)
     for p in probs:
         print('ISA check:', p)
     print('ISA check:', 'FAILED' if probs else 'ok')
